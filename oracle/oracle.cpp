@@ -1,0 +1,240 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C ABI over the CPU restatement (ctypes-friendly).
+// See oracle_models.h for the scope note.  PARITY UNPINNED.
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <omp.h>
+#include "oracle_models.h"
+#include "oracle_hmm.h"
+#include "oracle_phylo.h"
+
+using namespace orc;
+
+extern "C" {
+
+/* ---------------- models ---------------- */
+void* orc_model_new(int type, const double* pi, const double* par) { return new Model(make_model(type, pi, par)); }
+void orc_model_free(void* m) { delete (Model*) m; }
+void orc_model_pr(void* m, double t, double* P) { ((Model*) m)->Pr(t, P); }
+void orc_model_get(void* m, double* pi4, double* Q16) {
+	Model* M = (Model*) m;
+	for(int i = 0; i < 4; ++i) pi4[i] = M->pi[i];
+	if(Q16) for(int i = 0; i < 16; ++i) Q16[i] = M->Q[i];
+}
+
+/* ---------------- profile HMM ---------------- */
+struct HmmHandle { Hmm h; std::vector<VitWork> work; };
+
+void* orc_hmm_new(int K, int L, const double* EM, const double* EI, const double* T, const int* p2cs, int mode) {
+	HmmHandle* H = new HmmHandle;
+	H->h.init(K, L, EM, EI, T, p2cs);
+	H->h.setMode(mode);
+	H->work.resize(omp_get_max_threads() > 0 ? omp_get_max_threads() : 1);
+	return H;
+}
+void orc_hmm_free(void* h) { delete (HmmHandle*) h; }
+void orc_hmm_set_mode(void* h, int mode) { ((HmmHandle*) h)->h.setMode(mode); }
+void orc_hmm_get(void* h, double* entryC, double* exitC, double* tsp4) {
+	Hmm& H = ((HmmHandle*) h)->h;
+	for(int k = 0; k <= H.K; ++k) { entryC[k] = H.entryC[k]; exitC[k] = H.exitC[k]; }
+	tsp4[0] = H.T_NN; tsp4[1] = H.T_NB; tsp4[2] = H.T_EC; tsp4[3] = H.T_CC;
+}
+void orc_build_align_path(void* h, int locStart, int locEnd, const char* CS, int csFrom, int csTo, int* out6) {
+	VPath v = ((HmmHandle*) h)->h.buildAlignPath(locStart, locEnd, std::string(CS), csFrom, csTo);
+	out6[0] = v.start; out6[1] = v.end; out6[2] = v.from; out6[3] = v.to; out6[4] = v.nIns; out6[5] = v.nDel;
+}
+static std::vector<VPath> to_vpaths(const int* vp, int nvp) {
+	std::vector<VPath> v;
+	for(int i = 0; i < nvp; ++i) {
+		VPath p{vp[i*6], vp[i*6+1], vp[i*6+2], vp[i*6+3], vp[i*6+4], vp[i*6+5]};
+		if(p.isValid()) v.push_back(p);
+	}
+	return v;
+}
+static void export_aln(const HmmAlignment& a, int* ints, double* cost, char* align, char* trace, int traceCap) {
+	ints[0] = a.seqStart; ints[1] = a.seqEnd; ints[2] = a.hmmStart; ints[3] = a.hmmEnd;
+	ints[4] = a.csStart; ints[5] = a.csEnd; ints[6] = a.usedFull ? 1 : 0; ints[7] = a.isValid() ? 1 : 0;
+	*cost = a.cost;
+	if(align && (int) a.align.size() == a.L) std::memcpy(align, a.align.data(), a.L);
+	if(trace && traceCap > 0) { int n = std::min((int) a.trace.size(), traceCap - 1); std::memcpy(trace, a.trace.data(), n); trace[n] = 0; }
+}
+/* alignSeq after the seed lookup; returns 1 if a valid alignment was produced */
+int orc_align(void* h, const char* read, int n, const int* vpaths, int nvp, int* ints, double* cost, char* align, char* trace, int traceCap) {
+	HmmHandle* H = (HmmHandle*) h;
+	for(int i = 0; i < n; ++i) if(ABC.encode(read[i]) < 0) { for(int k = 0; k < 8; ++k) ints[k] = 0; *cost = INF; return 0; }
+	HmmAlignment a = alignSeq(H->h, H->work[0], std::string(read, n), to_vpaths(vpaths, nvp));
+	export_aln(a, ints, cost, align, trace, traceCap);
+	return a.isValid() ? 1 : 0;
+}
+/* DigitalSeq(abc, name, str) (src/DigitalSeq.cpp:41-48): upper-case, drop invalid chars */
+int orc_digitize(const char* s, int n, int8_t* out) {
+	int m = 0;
+	for(int i = 0; i < n; ++i) { char c = (char) ::toupper(s[i]); int8_t b = ABC.encode(c); if(b != -1) out[m++] = b; }
+	return m;
+}
+/* PE merge (src/hmmufotu.cpp:629-639): returns 0 and leaves fwd untouched on bad orientation */
+int orc_merge(int L, int* intsF, double* costF, char* alignF, const int* intsR, const double* costR, const char* alignR) {
+	if(!(intsF[4] <= intsR[4] && intsF[5] <= intsR[5])) return 0;
+	HmmAlignment a, b;
+	a.K = b.K = 0; a.L = b.L = L;
+	a.seqStart = intsF[0]; a.seqEnd = intsF[1]; a.hmmStart = intsF[2]; a.hmmEnd = intsF[3]; a.csStart = intsF[4]; a.csEnd = intsF[5]; a.cost = *costF; a.align.assign(alignF, L);
+	b.seqStart = intsR[0]; b.seqEnd = intsR[1]; b.hmmStart = intsR[2]; b.hmmEnd = intsR[3]; b.csStart = intsR[4]; b.csEnd = intsR[5]; b.cost = *costR; b.align.assign(alignR, L);
+	a.merge(b);
+	intsF[0] = a.seqStart; intsF[1] = a.seqEnd; intsF[2] = a.hmmStart; intsF[3] = a.hmmEnd; intsF[4] = a.csStart; intsF[5] = a.csEnd; *costF = a.cost;
+	std::memcpy(alignF, a.align.data(), L);
+	return 1;
+}
+
+/* ---------------- tree ---------------- */
+void* orc_tree_new(int nNodes, int csLen, const int* parent, const double* blen, const int8_t* seq,
+		const double* up, const double* down, const double* height, const int* annoId,
+		void* model, int dgK, const double* dgR, long winStart, long winLen) {
+	Tree* t = new Tree;
+	t->nNodes = nNodes; t->csLen = csLen; t->parent = parent; t->blen = blen; t->seq = seq;
+	t->up = up; t->down = down; t->height = height; t->annoId = annoId;
+	t->model = *(Model*) model; t->dgK = dgK;
+	for(int k = 0; k < dgK && k < 16; ++k) t->dgR[k] = dgR[k];
+	t->winStart = winStart; t->winLen = winLen > 0 ? winLen : csLen;
+	t->root = 0;
+	for(int i = 0; i < nNodes; ++i) if(parent[i] < 0) t->root = i;
+	return t;
+}
+void orc_tree_free(void* t) { delete (Tree*) t; }
+
+int orc_get_seed(void* tr, const int8_t* seq, int start, int end, double maxDiff, double maxHeight, int tieMode, int maxNSeed,
+		long* ids, long* d, long* N, double* dist) {
+	std::vector<PTLoc> s = getSeed(*(Tree*) tr, seq, start, end, maxDiff, maxHeight, tieMode, (size_t) maxNSeed);
+	for(size_t i = 0; i < s.size(); ++i) { ids[i] = s[i].id; d[i] = s[i].d; N[i] = s[i].N; dist[i] = s[i].dist; }
+	return (int) s.size();
+}
+void orc_pdist_all(void* tr, const int8_t* seq, int start, int end, long* d, long* N) {
+	Tree* t = (Tree*) tr;
+	for(int i = 0; i < t->nNodes; ++i) pdist_counts(t->S(i), seq, start, end, d[i], N[i]);
+}
+/* out: ratio, wnr, loglik, wuv; nodes: cNode, pNode, aNode */
+void orc_estimate(void* tr, const int8_t* seq, int start, int end, long id, double dist, int weighted, double* out, int* nodes) {
+	PTLoc l; l.start = start; l.end = end; l.id = id; l.dist = dist; l.d = l.N = 0;
+	Placement p = estimateSeq(*(Tree*) tr, seq, l, weighted != 0);
+	out[0] = p.ratio; out[1] = p.wnr; out[2] = p.loglik; out[3] = p.wuv;
+	nodes[0] = p.cNode; nodes[1] = p.pNode; nodes[2] = p.aNode;
+}
+/* out: loglik, wnr, ratio, height; returns outer iteration count */
+int orc_place(void* tr, const int8_t* seq, int start, int end, int cNode, double ratio0, double wnr0, double maxHeight, double* out, int* aNode) {
+	Tree* t = (Tree*) tr;
+	Placement p; p.start = start; p.end = end; p.cNode = cNode; p.pNode = t->parent[cNode]; p.ratio = ratio0; p.wnr = wnr0; p.wuv = t->blen[cNode];
+	placeSeq(*t, seq, p, maxHeight);
+	out[0] = p.loglik; out[1] = p.wnr; out[2] = p.ratio; out[3] = p.height; *aNode = p.aNode;
+	return p.iters;
+}
+
+struct OrcOpts { double maxDiff, maxHeight, maxError; int maxNSeed, weighted, onlyML, prior, tieMode; };
+static AssignOpts to_opts(const OrcOpts* o) {
+	AssignOpts a; a.maxDiff = o->maxDiff; a.maxHeight = o->maxHeight; a.maxError = o->maxError; a.maxNSeed = o->maxNSeed;
+	a.weighted = o->weighted; a.onlyML = o->onlyML; a.prior = o->prior; a.tieMode = o->tieMode; return a;
+}
+static void export_place(const Placement& p, int* ni, double* nd) {
+	ni[0] = p.cNode; ni[1] = p.pNode; ni[2] = p.aNode; ni[3] = p.iters;
+	nd[0] = p.ratio; nd[1] = p.wnr; nd[2] = p.loglik; nd[3] = p.height; nd[4] = p.qPlace; nd[5] = p.qTaxon; nd[6] = p.annoDist(); nd[7] = p.estLoglik;
+}
+/* full SEP for one aligned read; outputs all final placements in output order (ints [n][4], dbl [n][8]),
+ * seeds (ids/d/N) and per-seed estimates (est [nSeeds][3] = ratio,wnr,loglik).  Returns #placements. */
+int orc_assign(void* tr, const int8_t* seq, int start, int end, const OrcOpts* o,
+		int* ni, double* nd, int* nSeeds, long* seedIds, long* seedD, long* seedN, double* est) {
+	std::vector<PTLoc> seeds; std::vector<Placement> ests;
+	std::vector<Placement> pl = assignSeq(*(Tree*) tr, seq, start, end, to_opts(o), &seeds, &ests);
+	for(size_t i = 0; i < pl.size(); ++i) export_place(pl[i], ni + 4 * i, nd + 8 * i);
+	if(nSeeds) *nSeeds = (int) seeds.size();
+	for(size_t i = 0; i < seeds.size(); ++i) {
+		if(seedIds) { seedIds[i] = seeds[i].id; seedD[i] = seeds[i].d; seedN[i] = seeds[i].N; }
+		if(est) { est[3*i] = ests[i].ratio; est[3*i+1] = ests[i].wnr; est[3*i+2] = ests[i].loglik; }
+	}
+	return (int) pl.size();
+}
+
+void orc_tree_evaluate(int nNodes, int csLen, const int* parent, const double* blen, int8_t* seq,
+		void* model, int dgK, const double* dgR, double* up, double* down, double* rootMsg, double* height) {
+	treeEvaluate(nNodes, csLen, parent, blen, seq, *(Model*) model, dgK, dgR, up, down, rootMsg, height);
+}
+
+/* ---------------- whole per-read task, batched with OpenMP (CPU baseline) ----------------
+ * reads: concatenated chars, offs[nReads+1]; mates optional (already reverse-complemented);
+ * vpaths [nReads][2][6] (invalid rows skipped), mvpaths likewise.  Per read outputs:
+ * ai[r][8] (alignment ints as orc_align + status in [7]: 1 ok, 0 invalid, 2 chimera-by-orientation),
+ * cost[r], align (optional, [r][L]), best placement bi[r][4], bd[r][8], nCand[r].
+ * stageSec[4]: summed wall seconds over threads for align / seed / estimate / place.  */
+void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, const long* offs,
+		const char* mates, const long* moffs, const int* vpaths, const int* mvpaths,
+		const OrcOpts* o, int nThreads,
+		int* ai, double* cost, char* alignOut, int* bi, double* bd, int* nCand, double* stageSec) {
+	HmmHandle* H = (HmmHandle*) hmm; Tree* t = (Tree*) tr;
+	const int L = H->h.L;
+	AssignOpts opts = to_opts(o);
+	if(nThreads <= 0) nThreads = omp_get_max_threads();
+	if((int) H->work.size() < nThreads) H->work.resize(nThreads);
+	double acc[4] = {0, 0, 0, 0};
+	#pragma omp parallel num_threads(nThreads)
+	{
+		double loc[4] = {0, 0, 0, 0};
+		VitWork& w = H->work[omp_get_thread_num()];
+		std::vector<int8_t> dseq(L);
+		#pragma omp for schedule(dynamic, 4)
+		for(int r = 0; r < nReads; ++r) {
+			auto t0 = std::chrono::steady_clock::now();
+			int* a8 = ai + 8 * r;
+			for(int k = 0; k < 4; ++k) bi[4*r+k] = -1;
+			for(int k = 0; k < 8; ++k) bd[8*r+k] = NAN;
+			nCand[r] = 0;
+			std::string rd(reads + offs[r], offs[r+1] - offs[r]);
+			bool bad = false;
+			for(char c : rd) if(ABC.encode(c) < 0) bad = true;
+			HmmAlignment aln;
+			if(!bad) aln = alignSeq(H->h, w, rd, to_vpaths(vpaths + 12 * r, 2));
+			int status = (!bad && aln.isValid()) ? 1 : 0;
+			if(status == 1 && mates) {
+				std::string md(mates + moffs[r], moffs[r+1] - moffs[r]);
+				bool mbad = false;
+				for(char c : md) if(ABC.encode(c) < 0) mbad = true;
+				HmmAlignment ra;
+				if(!mbad) ra = alignSeq(H->h, w, md, to_vpaths(mvpaths + 12 * r, 2));
+				if(mbad || !ra.isValid()) status = 0;
+				else if(!(aln.csStart <= ra.csStart && aln.csEnd <= ra.csEnd)) status = 2;
+				else aln.merge(ra);
+			}
+			double c = aln.cost;
+			export_aln(aln, a8, &c, alignOut ? alignOut + (size_t) r * L : nullptr, nullptr, 0);
+			a8[7] = status; cost[r] = c;
+			auto t1 = std::chrono::steady_clock::now();
+			loc[0] += std::chrono::duration<double>(t1 - t0).count();
+			if(status != 1) continue;
+			int m = orc_digitize(aln.align.data(), L, dseq.data());
+			if(m != L) { a8[7] = 0; continue; }
+			const int start = aln.csStart - 1, end = aln.csEnd - 1;
+			std::vector<PTLoc> seeds = getSeed(*t, dseq.data(), start, end, opts.maxDiff, opts.maxHeight, opts.tieMode, (size_t) opts.maxNSeed);
+			auto t2 = std::chrono::steady_clock::now();
+			loc[1] += std::chrono::duration<double>(t2 - t1).count();
+			std::vector<Placement> places;
+			for(const PTLoc& l : seeds) places.push_back(estimateSeq(*t, dseq.data(), l, opts.weighted != 0));
+			filterPlacements(places, opts.maxError);
+			auto t3 = std::chrono::steady_clock::now();
+			loc[2] += std::chrono::duration<double>(t3 - t2).count();
+			for(Placement& p : places) placeSeq(*t, dseq.data(), p, opts.maxHeight);
+			if(opts.onlyML)
+				std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; });
+			else {
+				calcQValues(*t, places, opts.prior);
+				std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.qPlace < r.qPlace; });
+			}
+			auto t4 = std::chrono::steady_clock::now();
+			loc[3] += std::chrono::duration<double>(t4 - t3).count();
+			nCand[r] = (int) places.size();
+			if(!places.empty()) export_place(places[0], bi + 4 * r, bd + 8 * r);
+		}
+		#pragma omp critical
+		for(int k = 0; k < 4; ++k) acc[k] += loc[k];
+	}
+	if(stageSec) for(int k = 0; k < 4; ++k) stageSec[k] = acc[k];
+}
+
+int orc_max_threads(void) { return omp_get_max_threads(); }
+
+} // extern "C"

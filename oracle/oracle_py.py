@@ -1,0 +1,217 @@
+"""ctypes binding of the CPU oracle (liboracle.so).  TEST INFRASTRUCTURE ONLY: import this from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from hmmufotu_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "oracle_models.h", "oracle_hmm.h", "oracle_phylo.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_model_new.restype = C.c_void_p
+        L.orc_hmm_new.restype = C.c_void_p
+        L.orc_tree_new.restype = C.c_void_p
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OrcOpts(C.Structure):
+    _fields_ = [("maxDiff", C.c_double), ("maxHeight", C.c_double), ("maxError", C.c_double),
+                ("maxNSeed", C.c_int), ("weighted", C.c_int), ("onlyML", C.c_int), ("prior", C.c_int), ("tieMode", C.c_int)]
+
+
+def default_opts(**kw):
+    o = OrcOpts(float("inf"), float("inf"), 20.0, 50, 0, 0, 0, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Model:
+    def __init__(self, type_id: int, pi, par):
+        self.pi = np.ascontiguousarray(pi, np.float64)
+        self.par = np.ascontiguousarray(np.concatenate([np.asarray(par, np.float64).ravel(), np.zeros(16)]))
+        self.h = C.c_void_p(lib().orc_model_new(C.c_int(type_id), _p(self.pi, C.c_double), _p(self.par, C.c_double)))
+
+    def P(self, t: float):
+        out = np.empty(16)
+        lib().orc_model_pr(self.h, C.c_double(t), _p(out, C.c_double))
+        return out.reshape(4, 4)
+
+    def Q(self):
+        pi = np.empty(4); q = np.empty(16)
+        lib().orc_model_get(self.h, _p(pi, C.c_double), _p(q, C.c_double))
+        return q.reshape(4, 4)
+
+    def __del__(self):
+        try:
+            lib().orc_model_free(self.h)
+        except Exception:
+            pass
+
+
+class Hmm:
+    def __init__(self, K, L, EM, EI, T, p2cs, mode=0):
+        self.K, self.L = int(K), int(L)
+        self.EM = np.ascontiguousarray(EM, np.float64); self.EI = np.ascontiguousarray(EI, np.float64)
+        self.T = np.ascontiguousarray(T, np.float64); self.p2cs = np.ascontiguousarray(p2cs, np.int32)
+        self.h = C.c_void_p(lib().orc_hmm_new(C.c_int(K), C.c_int(L), _p(self.EM, C.c_double), _p(self.EI, C.c_double),
+                                              _p(self.T, C.c_double), _p(self.p2cs, C.c_int), C.c_int(mode)))
+
+    def set_mode(self, mode):
+        lib().orc_hmm_set_mode(self.h, C.c_int(mode))
+
+    def params(self):
+        e = np.empty(self.K + 1); x = np.empty(self.K + 1); t = np.empty(4)
+        lib().orc_hmm_get(self.h, _p(e, C.c_double), _p(x, C.c_double), _p(t, C.c_double))
+        return e, x, t
+
+    def build_align_path(self, loc_start, loc_end, cs: str, cs_from, cs_to):
+        out = np.zeros(6, np.int32)
+        lib().orc_build_align_path(self.h, C.c_int(loc_start), C.c_int(loc_end), cs.encode(), C.c_int(cs_from), C.c_int(cs_to), _p(out, C.c_int))
+        return out
+
+    def align(self, read: str, vpaths=None):
+        vp = np.ascontiguousarray(vpaths if vpaths is not None else np.zeros((0, 6)), np.int32).reshape(-1, 6)
+        ints = np.zeros(8, np.int32); cost = C.c_double(0)
+        aln = C.create_string_buffer(self.L + 1); tr = C.create_string_buffer(4 * (len(read) + self.K) + 16)
+        ok = lib().orc_align(self.h, read.encode(), C.c_int(len(read)), _p(vp, C.c_int), C.c_int(len(vp)), _p(ints, C.c_int),
+                             C.byref(cost), aln, tr, C.c_int(len(tr)))
+        return dict(ok=bool(ok), seqStart=int(ints[0]), seqEnd=int(ints[1]), hmmStart=int(ints[2]), hmmEnd=int(ints[3]),
+                    csStart=int(ints[4]), csEnd=int(ints[5]), usedFull=bool(ints[6]), cost=cost.value,
+                    align=aln.raw[:self.L].decode("latin1") if ok else "", trace=tr.value.decode())
+
+    def __del__(self):
+        try:
+            lib().orc_hmm_free(self.h)
+        except Exception:
+            pass
+
+
+def digitize(align: str) -> np.ndarray:
+    out = np.empty(len(align), np.int8)
+    n = lib().orc_digitize(align.encode("latin1"), C.c_int(len(align)), _p(out, C.c_int8))
+    return out[:n]
+
+
+def merge(L, intsF, costF, alignF: bytes, intsR, costR, alignR: bytes):
+    i = np.ascontiguousarray(intsF, np.int32).copy(); c = C.c_double(costF); a = C.create_string_buffer(alignF, L)
+    ir = np.ascontiguousarray(intsR, np.int32); cr = C.c_double(costR)
+    ok = lib().orc_merge(C.c_int(L), _p(i, C.c_int), C.byref(c), a, _p(ir, C.c_int), C.byref(cr), alignR)
+    return bool(ok), i, c.value, a.raw[:L]
+
+
+class Tree:
+    def __init__(self, parent, blen, seq, up, down, height, model: Model, dg_r=None, anno_id=None, win_start=0, win_len=0):
+        self.parent = np.ascontiguousarray(parent, np.int32); self.blen = np.ascontiguousarray(blen, np.float64)
+        self.seq = np.ascontiguousarray(seq, np.int8); self.up = np.ascontiguousarray(up, np.float64)
+        self.down = np.ascontiguousarray(down, np.float64); self.height = np.ascontiguousarray(height, np.float64)
+        self.anno = None if anno_id is None else np.ascontiguousarray(anno_id, np.int32)
+        self.model = model
+        self.dgr = np.ascontiguousarray(dg_r if dg_r is not None else np.zeros(0), np.float64)
+        n, L = self.seq.shape
+        self.n, self.L = n, L
+        self.h = C.c_void_p(lib().orc_tree_new(C.c_int(n), C.c_int(L), _p(self.parent, C.c_int), _p(self.blen, C.c_double),
+                                               _p(self.seq, C.c_int8), _p(self.up, C.c_double), _p(self.down, C.c_double),
+                                               _p(self.height, C.c_double), _p(self.anno, C.c_int) if self.anno is not None else None,
+                                               model.h, C.c_int(len(self.dgr)), _p(self.dgr, C.c_double), C.c_long(win_start), C.c_long(win_len)))
+
+    def get_seed(self, seq, start, end, max_diff=float("inf"), max_height=float("inf"), tie=0, max_n=50):
+        seq = np.ascontiguousarray(seq, np.int8)
+        ids = np.zeros(max(max_n, 1), np.int64); d = np.zeros_like(ids); N = np.zeros_like(ids); dist = np.zeros(len(ids))
+        n = lib().orc_get_seed(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.c_double(max_diff), C.c_double(max_height),
+                               C.c_int(tie), C.c_int(max_n), _p(ids, C.c_long), _p(d, C.c_long), _p(N, C.c_long), _p(dist, C.c_double))
+        return ids[:n], d[:n], N[:n], dist[:n]
+
+    def pdist_all(self, seq, start, end):
+        seq = np.ascontiguousarray(seq, np.int8)
+        d = np.zeros(self.n, np.int64); N = np.zeros(self.n, np.int64)
+        lib().orc_pdist_all(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), _p(d, C.c_long), _p(N, C.c_long))
+        return d, N
+
+    def estimate(self, seq, start, end, node, dist, weighted=False):
+        seq = np.ascontiguousarray(seq, np.int8)
+        out = np.zeros(4); nodes = np.zeros(3, np.int32)
+        lib().orc_estimate(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.c_long(int(node)), C.c_double(dist),
+                           C.c_int(int(weighted)), _p(out, C.c_double), _p(nodes, C.c_int))
+        return dict(ratio=out[0], wnr=out[1], loglik=out[2], wuv=out[3], cNode=int(nodes[0]), pNode=int(nodes[1]), aNode=int(nodes[2]))
+
+    def place(self, seq, start, end, c_node, ratio0, wnr0, max_height=float("inf")):
+        seq = np.ascontiguousarray(seq, np.int8)
+        out = np.zeros(4); a = C.c_int(0)
+        it = lib().orc_place(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.c_int(int(c_node)), C.c_double(ratio0),
+                             C.c_double(wnr0), C.c_double(max_height), _p(out, C.c_double), C.byref(a))
+        return dict(loglik=out[0], wnr=out[1], ratio=out[2], height=out[3], aNode=a.value, iters=it)
+
+    def assign(self, seq, start, end, opts=None):
+        opts = opts or default_opts()
+        seq = np.ascontiguousarray(seq, np.int8)
+        m = max(opts.maxNSeed, 1)
+        ni = np.zeros((m, 4), np.int32); nd = np.zeros((m, 8)); ns = C.c_int(0)
+        sid = np.zeros(m, np.int64); sd = np.zeros(m, np.int64); sn = np.zeros(m, np.int64); est = np.zeros((m, 3))
+        n = lib().orc_assign(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.byref(opts), _p(ni, C.c_int), _p(nd, C.c_double),
+                             C.byref(ns), _p(sid, C.c_long), _p(sd, C.c_long), _p(sn, C.c_long), _p(est, C.c_double))
+        k = ns.value
+        return dict(n=n, nodes=ni[:n], vals=nd[:n], seed_ids=sid[:k], seed_d=sd[:k], seed_N=sn[:k], est=est[:k])
+
+    def __del__(self):
+        try:
+            lib().orc_tree_free(self.h)
+        except Exception:
+            pass
+
+
+def tree_evaluate(parent, blen, leaf_seq, model: Model, dg_r=None):
+    parent = np.ascontiguousarray(parent, np.int32); blen = np.ascontiguousarray(blen, np.float64)
+    seq = np.ascontiguousarray(leaf_seq, np.int8).copy()
+    n, L = seq.shape
+    dgr = np.ascontiguousarray(dg_r if dg_r is not None else np.zeros(0), np.float64)
+    up = np.zeros((n, L, 4)); down = np.zeros((n, L, 4)); root = np.zeros((L, 4)); h = np.zeros(n)
+    lib().orc_tree_evaluate(C.c_int(n), C.c_int(L), _p(parent, C.c_int), _p(blen, C.c_double), _p(seq, C.c_int8), model.h,
+                            C.c_int(len(dgr)), _p(dgr, C.c_double), _p(up, C.c_double), _p(down, C.c_double), _p(root, C.c_double), _p(h, C.c_double))
+    up[0] = root
+    return up, down, seq, h
+
+
+def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, want_align=False):
+    """Whole per-read task on the CPU (OpenMP over reads).  reads/mates: list of str."""
+    opts = opts or default_opts()
+    n = len(reads)
+    cat = "".join(reads).encode(); offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
+    vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 2, 6)
+    if mates is not None:
+        mcat = "".join(mates).encode(); moffs = np.zeros(n + 1, np.int64); moffs[1:] = np.cumsum([len(r) for r in mates])
+        mvp = np.ascontiguousarray(mvpaths, np.int32).reshape(n, 2, 6)
+    ai = np.zeros((n, 8), np.int32); cost = np.zeros(n); bi = np.zeros((n, 4), np.int32); bd = np.zeros((n, 8))
+    nc = np.zeros(n, np.int32); st = np.zeros(4)
+    aln = np.zeros((n, hmm.L), np.uint8) if want_align else None
+    lib().orc_pipeline_batch(hmm.h, tree.h, C.c_int(n), cat, _p(offs, C.c_long),
+                             mcat if mates is not None else None, _p(moffs, C.c_long) if mates is not None else None,
+                             _p(vp, C.c_int), _p(mvp, C.c_int) if mates is not None else None, C.byref(opts), C.c_int(threads),
+                             _p(ai, C.c_int), _p(cost, C.c_double), _p(aln, C.c_char) if aln is not None else None,
+                             _p(bi, C.c_int), _p(bd, C.c_double), _p(nc, C.c_int), _p(st, C.c_double))
+    return dict(aln_ints=ai, cost=cost, align=aln, best_nodes=bi, best_vals=bd, n_cand=nc, stage_sec=st)
+
+
+def max_threads():
+    return lib().orc_max_threads()
