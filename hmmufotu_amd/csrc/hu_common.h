@@ -1,0 +1,94 @@
+// Shared host/device declarations of the engine.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/hmmufotu_amd.h"
+
+#define HU_MAX_DGK 16
+#define HU_MAX_SEEDS 64          /* capacity of per-read seed lists (max_nseed <= 64)           */
+#define HU_READ_TILE 16          /* reads per workgroup tile in the seed p-distance scan        */
+#define HU_NODE_PAD 256          /* node count is padded to a multiple of this                  */
+#define HU_MIN_LOGLIK_EXP (-510.0) /* DBL_MIN_EXP / 2 in integer arithmetic, PhyloTreeUnrooted.cpp:68 */
+#define HU_BRANCH_EPS 1e-5
+#define HU_MAX_ITER 100
+
+/* Every reversible model of the reference has Q(i,j) = s(i,j) pi(j) with symmetric s, hence a
+ * real spectral form; the engine evaluates DNASubModel::Pr(t) as U diag(exp(lam t)) U1 for all
+ * six model types (GTR does exactly this in the reference, src/GTR.h:116-121; the closed forms
+ * of TN93/HKY85/F81/K80/JC69 are the same matrix exponentials written out). */
+struct HuModelDev {
+	int32_t type, dgK;
+	double pi[4];
+	double logpi[4];
+	double U[16], U1[16], lam[4];
+	double rate[HU_MAX_DGK];   /* rate[0] = 1 when dgK == 0 */
+};
+
+struct HuDbDev {
+	int32_t nNodes, nNodesPad, csLen, W, WQ, root;
+	int64_t winStart, winLen;
+	const uint4* planes;       /* [WQ][3][nNodesPad]: 4 words (128 sites) of bit-plane p per node */
+	const int32_t* parent;
+	const double* blen;
+	const double* height;
+	const double* up;          /* [n][winLen][4] */
+	const double* down;
+	/* profile */
+	int32_t K, L;
+	const double* EM;          /* [K+1][4] */
+	const double* EI;
+	const double* T;           /* [K+1][8] (7 used) */
+	const double* entryC;
+	const double* exitC;
+	const int32_t* p2cs;       /* [K+2] */
+};
+
+/* one dynamic-programming phase of the banded Viterbi (src/BandedHMMP7.cpp:794-881) */
+struct HuRegion {
+	int32_t j0, j1, i0, i1;    /* inclusive profile / read ranges                                  */
+	int32_t withB;             /* B-entry term present (absent in the downstream rectangle)       */
+	int32_t band;              /* 1: only cells with -nDel <= (i-from)-(j-start) <= nIns           */
+	int32_t from, start, nIns, nDel;
+	int64_t off;               /* first cell of this region in the read's scratch                 */
+};
+#define HU_MAX_REGIONS 6
+
+struct HuReadDesc {
+	int64_t baseOff;           /* offset of the read's codes in the batch's code buffer          */
+	int32_t len;
+	int32_t nRegions;
+	int64_t scratchOff;        /* first cell of the read in the DP scratch                        */
+	int64_t traceOff;
+	HuRegion reg[HU_MAX_REGIONS];
+};
+
+void hu_set_error(const char* fmt, ...);
+
+/* host-side model preparation */
+int hu_model_prepare(const hu_model_desc* d, HuModelDev* out);
+
+/* host-side profile preparation (hu_profile.cpp) */
+struct HuProfileHost {
+	int K = 0, L = 0;
+	std::vector<double> EM, EI, T7, entryC, exitC;
+	std::vector<int32_t> p2cs, cs2p;
+	int init(const hu_profile_desc* d);
+};
+void hu_mode_costs(int K, int mode, double* tNN, double* tNB, double* tEC, double* tCC);
+
+/* file readers (hu_formats.cpp) */
+struct HuTreeHost {
+	int32_t n = 0, csLen = 0, root = 0;
+	std::vector<int32_t> parent;
+	std::vector<double> blen, height, annoDist;
+	std::vector<int8_t> seq;
+	std::vector<double> up, down;
+	std::vector<std::string> names, annos;
+	std::vector<int32_t> annoId;
+	hu_model_desc model;
+};
+int hu_read_hmm(const char* path, HuProfileHost& out, std::vector<double>& EM, std::vector<double>& EI,
+		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L);
+int hu_read_ptu(const char* path, HuTreeHost& out);

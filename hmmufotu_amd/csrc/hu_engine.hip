@@ -1,0 +1,912 @@
+// C ABI implementation: database packing into HBM, batch workspace, stage launches and the
+// host-side pieces of the per-read task (filterPlacements, calcQValues, final sort), which call
+// literally the same std::sort as the reference so that tie permutations agree.
+// gfx950 only; there is NO CPU fallback: every compute entry point fails with HU_ERR_DEVICE
+// when no device is present.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include "hu_common.h"
+#include "hu_kern_sep.h"
+#include "hu_kern_align.h"
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
+
+static const double kInf = std::numeric_limits<double>::infinity();
+
+struct hu_db {
+	int device = 0;
+	HuDbDev dev;
+	HuModelDev mdl;
+	hu_model_desc mdesc;
+	HuProfileHost prof;
+	std::vector<double> hT7, hEM, hEI;
+	std::vector<int32_t> parent, annoId;
+	std::vector<double> blen, height, annoDist;
+	std::vector<int8_t> seq;
+	std::vector<void*> allocs;
+	int64_t hbmBytes = 0;
+};
+
+template<class X> static int dev_alloc(hu_db* db, X** p, size_t n) {
+	size_t bytes = std::max<size_t>(n, 1) * sizeof(X);
+	hipError_t e = hipMalloc((void**) p, bytes);
+	if(e != hipSuccess) { hu_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return HU_ERR_NOMEM; }
+	db->allocs.push_back(*p);
+	db->hbmBytes += (int64_t) bytes;
+	return HU_OK;
+}
+template<class X> static int dev_upload(hu_db* db, X** p, const X* src, size_t n) {
+	int rc = dev_alloc(db, p, n);
+	if(rc != HU_OK) return rc;
+	if(n) HIPCHK(hipMemcpy(*p, src, n * sizeof(X), hipMemcpyHostToDevice));
+	return HU_OK;
+}
+
+extern "C" int hu_device_count(void) {
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	int ok = 0;
+	for(int i = 0; i < n; ++i) {
+		hipDeviceProp_t p;
+		if(hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+	}
+	return ok;
+}
+
+static int init_sym_map() {
+	int8_t m[128];
+	for(int i = 0; i < 128; ++i) m[i] = -1;
+	/* IUPACNucl: symbols ACGT, degenerate codes -> first expansion, gaps "-._" (src/IUPACNucl.cpp:33-50,
+	 * src/DegenAlphabet.cpp:43-64) */
+	m['A'] = 0; m['C'] = 1; m['G'] = 2; m['T'] = 3; m['U'] = 3;
+	m['M'] = 0; m['R'] = 0; m['W'] = 0; m['S'] = 1; m['Y'] = 1; m['K'] = 2;
+	m['V'] = 0; m['H'] = 0; m['D'] = 0; m['B'] = 1; m['N'] = 0;
+	m['-'] = -2; m['.'] = -2; m['_'] = -2;
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_sym_map), m, sizeof(m)));
+	return HU_OK;
+}
+static int8_t host_sym(char c) {
+	switch(c) {
+	case 'A': case 'M': case 'R': case 'W': case 'V': case 'H': case 'D': case 'N': return 0;
+	case 'C': case 'S': case 'Y': case 'B': return 1;
+	case 'G': case 'K': return 2;
+	case 'T': case 'U': return 3;
+	case '-': case '.': case '_': return -2;
+	default: return -1;
+	}
+}
+
+/* ------------------------------------------------------------------------------ database */
+extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu_model_desc* model,
+		int device, hu_db** out) {
+	if(!prof || !tree || !model || !out) { hu_set_error("hu_db_create: null argument"); return HU_ERR_ARG; }
+	*out = nullptr;
+	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
+	HIPCHK(hipSetDevice(device));
+	hu_db* db = new hu_db;
+	db->device = device;
+	int rc = db->prof.init(prof);
+	if(rc == HU_OK) rc = hu_model_prepare(model, &db->mdl);
+	if(rc != HU_OK) { delete db; return rc; }
+	db->mdesc = *model;
+	const int n = tree->n_nodes, L = tree->cs_len;
+	if(n < 2 || n >= (1 << 24) || L != prof->L) { hu_set_error("tree: n_nodes %d / cs_len %d inconsistent with profile L %d", n, L, prof->L); delete db; return HU_ERR_ARG; }
+	const int64_t winStart = tree->win_len > 0 ? tree->win_start : 0, winLen = tree->win_len > 0 ? tree->win_len : L;
+	if(winStart < 0 || winStart + winLen > L) { hu_set_error("tree: message window out of range"); delete db; return HU_ERR_ARG; }
+	db->parent.assign(tree->parent, tree->parent + n);
+	db->blen.assign(tree->blen, tree->blen + n);
+	db->height.assign(tree->height, tree->height + n);
+	db->seq.assign(tree->seq, tree->seq + (size_t) n * L);
+	if(tree->anno_id) db->annoId.assign(tree->anno_id, tree->anno_id + n);
+	else { db->annoId.resize(n); for(int i = 0; i < n; ++i) db->annoId[i] = i; }
+	if(tree->anno_dist) db->annoDist.assign(tree->anno_dist, tree->anno_dist + n); else db->annoDist.assign(n, 0.0);
+	int root = -1, nroot = 0;
+	for(int i = 0; i < n; ++i) {
+		if(db->parent[i] < 0) { root = i; nroot++; }
+		else if(db->parent[i] >= n) { hu_set_error("tree: parent of node %d out of range", i); delete db; return HU_ERR_ARG; }
+	}
+	if(nroot != 1) { hu_set_error("tree: %d roots", nroot); delete db; return HU_ERR_ARG; }
+	HuDbDev& d = db->dev;
+	memset(&d, 0, sizeof(d));
+	d.nNodes = n; d.csLen = L; d.root = root;
+	d.nNodesPad = (n + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD;
+	d.W = (L + 31) / 32; d.WQ = (L + 127) / 128;
+	d.winStart = winStart; d.winLen = winLen;
+	d.K = prof->K; d.L = L;
+	auto fail = [&](int code) { hu_db_destroy(db); return code; };
+	/* bit-planes of the node sequences, [WQ][3][nNodesPad] x uint4 */
+	{
+		const size_t np = d.nNodesPad, cnt = (size_t) d.WQ * 3 * np;
+		std::vector<uint4> pl(cnt, make_uint4(0, 0, 0, 0));
+		for(int i = 0; i < n; ++i) {
+			const int8_t* s = &db->seq[(size_t) i * L];
+			for(int c = 0; c < L; ++c) {
+				const int code = s[c];
+				if(code < 0) continue;
+				const int q = c >> 7, w = (c >> 5) & 3; const uint32_t bit = 1u << (c & 31);
+				uint32_t* p0 = &pl[((size_t) q * 3 + 0) * np + i].x + w;
+				uint32_t* p1 = &pl[((size_t) q * 3 + 1) * np + i].x + w;
+				uint32_t* pv = &pl[((size_t) q * 3 + 2) * np + i].x + w;
+				if(code & 1) *p0 |= bit;
+				if(code & 2) *p1 |= bit;
+				*pv |= bit;
+			}
+		}
+		uint4* dp = nullptr;
+		if((rc = dev_upload(db, &dp, pl.data(), cnt)) != HU_OK) return fail(rc);
+		d.planes = dp;
+	}
+	{
+		int32_t* p; double* q;
+		if((rc = dev_upload(db, &p, db->parent.data(), (size_t) n)) != HU_OK) return fail(rc); d.parent = p;
+		if((rc = dev_upload(db, &q, db->blen.data(), (size_t) n)) != HU_OK) return fail(rc); d.blen = q;
+		if((rc = dev_upload(db, &q, db->height.data(), (size_t) n)) != HU_OK) return fail(rc); d.height = q;
+	}
+	if(tree->msgs_on_device) { d.up = tree->up; d.down = tree->down; db->hbmBytes += 2 * (int64_t) n * winLen * 32; }
+	else {
+		double* q;
+		const size_t cnt = (size_t) n * winLen * 4;
+		if((rc = dev_upload(db, &q, tree->up, cnt)) != HU_OK) return fail(rc); d.up = q;
+		if((rc = dev_upload(db, &q, tree->down, cnt)) != HU_OK) return fail(rc); d.down = q;
+	}
+	{ /* profile */
+		const int K = d.K;
+		std::vector<double> T8((size_t)(K + 1) * 8, kInf);
+		for(int k = 0; k <= K; ++k) for(int t = 0; t < 7; ++t) T8[(size_t) k * 8 + t] = db->prof.T7[(size_t) k * 7 + t];
+		std::vector<int32_t> p2(K + 2, 0);
+		for(int k = 0; k <= K; ++k) p2[k] = db->prof.p2cs[k];
+		double* q; int32_t* p;
+		if((rc = dev_upload(db, &q, db->prof.EM.data(), (size_t) 4 * (K + 1))) != HU_OK) return fail(rc); d.EM = q;
+		if((rc = dev_upload(db, &q, db->prof.EI.data(), (size_t) 4 * (K + 1))) != HU_OK) return fail(rc); d.EI = q;
+		if((rc = dev_upload(db, &q, T8.data(), T8.size())) != HU_OK) return fail(rc); d.T = q;
+		if((rc = dev_upload(db, &q, db->prof.entryC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.entryC = q;
+		if((rc = dev_upload(db, &q, db->prof.exitC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.exitC = q;
+		if((rc = dev_upload(db, &p, p2.data(), p2.size())) != HU_OK) return fail(rc); d.p2cs = p;
+	}
+	if((rc = init_sym_map()) != HU_OK) return fail(rc);
+	*out = db;
+	return HU_OK;
+}
+
+extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) {
+	if(!hmm_path || !ptu_path || !out) { hu_set_error("hu_db_load: null argument"); return HU_ERR_ARG; }
+	HuProfileHost prof; std::vector<double> EM, EI, T; std::vector<int32_t> p2cs; int K, L;
+	int rc = hu_read_hmm(hmm_path, prof, EM, EI, T, p2cs, K, L);
+	if(rc != HU_OK) return rc;
+	HuTreeHost t;
+	if((rc = hu_read_ptu(ptu_path, t)) != HU_OK) return rc;
+	if(K > t.csLen) { hu_set_error("HMM profile size is greater than the tree's CS length"); return HU_ERR_ARG; }
+	hu_profile_desc pd{K, t.csLen, EM.data(), EI.data(), T.data(), p2cs.data()};
+	hu_tree_desc td;
+	memset(&td, 0, sizeof(td));
+	td.n_nodes = t.n; td.cs_len = t.csLen; td.parent = t.parent.data(); td.blen = t.blen.data(); td.seq = t.seq.data();
+	td.up = t.up.data(); td.down = t.down.data(); td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
+	return hu_db_create(&pd, &td, &t.model, device, out);
+}
+
+/* host-only parse of the two files (no device needed): used by the format tests */
+extern "C" int hu_files_parse(const char* hmm_path, const char* ptu_path, int32_t* K, int32_t* L, int32_t* n_nodes, int32_t* root,
+		double* EM, double* EI, double* T, int32_t* p2cs, double* entryC, double* exitC,
+		int32_t* parent, double* blen, int8_t* seq, double* height, double* up, double* down, hu_model_desc* model, int fill) {
+	int k = 0, l = 0;
+	HuProfileHost prof; std::vector<double> vEM, vEI, vT; std::vector<int32_t> vp;
+	if(hmm_path) {
+		int rc = hu_read_hmm(hmm_path, prof, vEM, vEI, vT, vp, k, l);
+		if(rc != HU_OK) return rc;
+		if(K) *K = k; if(L) *L = l;
+		if(fill) {
+			if(EM) memcpy(EM, vEM.data(), vEM.size() * 8); if(EI) memcpy(EI, vEI.data(), vEI.size() * 8);
+			if(T) memcpy(T, vT.data(), vT.size() * 8); if(p2cs) memcpy(p2cs, vp.data(), vp.size() * 4);
+			if(entryC) memcpy(entryC, prof.entryC.data(), prof.entryC.size() * 8);
+			if(exitC) memcpy(exitC, prof.exitC.data(), prof.exitC.size() * 8);
+		}
+	}
+	if(ptu_path) {
+		HuTreeHost t;
+		int rc = hu_read_ptu(ptu_path, t);
+		if(rc != HU_OK) return rc;
+		if(n_nodes) *n_nodes = t.n; if(root) *root = t.root; if(L && !hmm_path) *L = t.csLen;
+		if(model) *model = t.model;
+		if(fill) {
+			if(parent) memcpy(parent, t.parent.data(), t.parent.size() * 4); if(blen) memcpy(blen, t.blen.data(), t.blen.size() * 8);
+			if(seq) memcpy(seq, t.seq.data(), t.seq.size()); if(height) memcpy(height, t.height.data(), t.height.size() * 8);
+			if(up) memcpy(up, t.up.data(), t.up.size() * 8); if(down) memcpy(down, t.down.data(), t.down.size() * 8);
+		}
+	}
+	return HU_OK;
+}
+
+extern "C" void hu_db_destroy(hu_db* db) {
+	if(!db) return;
+	for(void* p : db->allocs) (void) hipFree(p);
+	delete db;
+}
+extern "C" int hu_db_info(const hu_db* db, int32_t* K, int32_t* cs_len, int32_t* n_nodes, int32_t* root, int64_t* hbm_bytes) {
+	if(!db) return HU_ERR_ARG;
+	if(K) *K = db->dev.K; if(cs_len) *cs_len = db->dev.csLen; if(n_nodes) *n_nodes = db->dev.nNodes;
+	if(root) *root = db->dev.root; if(hbm_bytes) *hbm_bytes = db->hbmBytes;
+	return HU_OK;
+}
+extern "C" int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double* T, int32_t* p2cs, double* entry_cost, double* exit_cost) {
+	if(!db) return HU_ERR_ARG;
+	const HuProfileHost& p = db->prof;
+	if(EM) memcpy(EM, p.EM.data(), p.EM.size() * 8); if(EI) memcpy(EI, p.EI.data(), p.EI.size() * 8);
+	if(T) memcpy(T, p.T7.data(), p.T7.size() * 8); if(p2cs) memcpy(p2cs, p.p2cs.data(), p.p2cs.size() * 4);
+	if(entry_cost) memcpy(entry_cost, p.entryC.data(), p.entryC.size() * 8);
+	if(exit_cost) memcpy(exit_cost, p.exitC.data(), p.exitC.size() * 8);
+	return HU_OK;
+}
+extern "C" int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, int8_t* seq, double* height) {
+	if(!db) return HU_ERR_ARG;
+	if(parent) memcpy(parent, db->parent.data(), db->parent.size() * 4); if(blen) memcpy(blen, db->blen.data(), db->blen.size() * 8);
+	if(seq) memcpy(seq, db->seq.data(), db->seq.size()); if(height) memcpy(height, db->height.data(), db->height.size() * 8);
+	return HU_OK;
+}
+extern "C" int hu_db_get_model(const hu_db* db, hu_model_desc* out) { if(!db || !out) return HU_ERR_ARG; *out = db->mdesc; return HU_OK; }
+
+__global__ void k_model_pr(HuModelDev mdl, int n, const double* __restrict__ t, double* __restrict__ P) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	double E[4];
+	for(int k = 0; k < 4; ++k) E[k] = exp(mdl.lam[k] * t[i]);
+	for(int col = 0; col < 4; ++col) {
+		double a[4], c[4];
+		for(int m = 0; m < 4; ++m) a[m] = mdl.U1[m*4+col];
+		if(t[i] == 0) { for(int r = 0; r < 4; ++r) c[r] = r == col ? 1.0 : 0.0; } else conv_eig(mdl, E, a, c);
+		for(int r = 0; r < 4; ++r) P[(size_t) i * 16 + r * 4 + col] = c[r];
+	}
+}
+extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P) {
+	if(!db || n < 0) return HU_ERR_ARG;
+	HIPCHK(hipSetDevice(db->device));
+	double *dt, *dP;
+	HIPCHK(hipMalloc((void**) &dt, std::max(n, 1) * 8)); HIPCHK(hipMalloc((void**) &dP, std::max(n, 1) * 128));
+	HIPCHK(hipMemcpy(dt, t, n * 8, hipMemcpyHostToDevice));
+	if(n) k_model_pr<<<(n + 63) / 64, 64>>>(db->mdl, n, dt, dP);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(P, dP, (size_t) n * 128, hipMemcpyDeviceToHost));
+	(void) hipFree(dt); (void) hipFree(dP);
+	return HU_OK;
+}
+
+/* ------------------------------------------------------------------------------ batch */
+template<class X> struct DBuf {
+	X* p = nullptr; size_t cap = 0;
+	int ensure(size_t n) {
+		if(n <= cap) return HU_OK;
+		if(p) (void) hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = n + n / 8 + 16;
+		hipError_t e = hipMalloc((void**) &p, want * sizeof(X));
+		if(e != hipSuccess) { hu_set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(X), hipGetErrorString(e)); return HU_ERR_NOMEM; }
+		cap = want;
+		return HU_OK;
+	}
+	void free_() { if(p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostPlace {
+	int32_t seedIdx, cNode, pNode, aNode, iters;
+	double wuv, ratio, wnr, loglik, height, qPlace, qTaxon, estLoglik;
+	double annoDist() const { return aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr; }
+};
+
+enum { ST_NONE = 0, ST_READS = 1, ST_ALIGNED = 2, ST_SEEDED = 3, ST_ESTIMATED = 4, ST_FILTERED = 5, ST_PLACED = 6, ST_FINISHED = 7 };
+
+struct hu_batch {
+	hu_db* db = nullptr;
+	int maxReads = 0, n = 0, nSeq = 0, state = ST_NONE;
+	bool paired = false, fromCodes = false, profile = false;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[2 * HU_T_COUNT];
+	float ms[HU_T_COUNT];
+	/* device */
+	DBuf<char> dBases, dTraces, dRows;
+	DBuf<HuReadDesc> dDescs;
+	DBuf<double> dScratch;
+	DBuf<HuVitOut> dVit;
+	DBuf<HuAlnDev> dAlns;
+	DBuf<int8_t> dCodes;
+	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId;
+	DBuf<uint32_t> dRp, dPairs, dSeedDN;
+	DBuf<int2> dTileQ;
+	DBuf<HuEstOut> dEst;
+	DBuf<HuCand> dCands;
+	DBuf<HuPlaceOut> dPlaceOut;
+	/* host */
+	std::vector<HuReadDesc> hDescs;
+	std::vector<char> hBases;
+	std::vector<HuVitOut> hVit;
+	std::vector<HuAlnDev> hAlns;
+	std::vector<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
+	std::vector<uint32_t> hSeedDN;
+	std::vector<HuEstOut> hEst;
+	std::vector<HuCand> hCands;
+	std::vector<HuPlaceOut> hPlaceOut;
+	std::vector<int64_t> candOffs;
+	std::vector<HostPlace> places;    /* candidates in filterPlacements order, all reads */
+	std::vector<hu_place_rec> best;
+	int maxRegion = 0;
+};
+
+struct Timer {
+	hu_batch* b; int id;
+	Timer(hu_batch* b, int id) : b(b), id(id) { if(b->profile) (void) hipEventRecord(b->ev[2 * id], b->stream); }
+	~Timer() { if(b->profile) (void) hipEventRecord(b->ev[2 * id + 1], b->stream); }
+};
+
+extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) {
+	if(!db || !out || max_reads < 1) { hu_set_error("hu_batch_create: bad argument"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(db->device));
+	hu_batch* b = new hu_batch;
+	b->db = db; b->maxReads = max_reads;
+	HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+	for(int i = 0; i < 2 * HU_T_COUNT; ++i) HIPCHK(hipEventCreate(&b->ev[i]));
+	for(int i = 0; i < HU_T_COUNT; ++i) b->ms[i] = 0;
+	*out = b;
+	return HU_OK;
+}
+extern "C" void hu_batch_destroy(hu_batch* b) {
+	if(!b) return;
+	(void) hipSetDevice(b->db->device);
+	(void) hipStreamSynchronize(b->stream);
+	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dVit.free_(); b->dAlns.free_();
+	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
+	b->dSeedDN.free_(); b->dTileQ.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
+	(void) hipStreamDestroy(b->stream);
+	delete b;
+}
+extern "C" int hu_batch_sync(hu_batch* b) { if(!b) return HU_ERR_ARG; HIPCHK(hipStreamSynchronize(b->stream)); return HU_OK; }
+extern "C" int hu_batch_profile(hu_batch* b, int enable) { if(!b) return HU_ERR_ARG; b->profile = enable != 0; return HU_OK; }
+extern "C" int hu_batch_timings(hu_batch* b, float* ms) {
+	if(!b || !ms) return HU_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(b->stream));
+	for(int i = 0; i < HU_T_COUNT; ++i) {
+		float t = 0;
+		if(b->profile && hipEventElapsedTime(&t, b->ev[2 * i], b->ev[2 * i + 1]) == hipSuccess) b->ms[i] = t;
+		ms[i] = b->ms[i];
+	}
+	return HU_OK;
+}
+
+/* banded phases of calcViterbiScores as region descriptors (src/BandedHMMP7.cpp:794-881) */
+static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */, HuReadDesc& rd) {
+	const int K = db->dev.K;
+	const double kMinGapFrac = 0.2;
+	struct VP { int start, end, from, to, nIns, nDel; } v[2];
+	int nv = 0;
+	for(int p = 0; p < 2 && vp; ++p) {
+		VP x{vp[p*6], vp[p*6+1], vp[p*6+2], vp[p*6+3], vp[p*6+4], vp[p*6+5]};
+		bool valid = x.start > 0 && x.start <= x.end && x.from > 0 && x.from <= x.to && x.nIns >= 0 && x.nDel >= 0;
+		if(valid && x.end <= K && x.to <= L) v[nv++] = x;
+	}
+	rd.nRegions = 0;
+	int64_t off = 0;
+	auto add = [&](int j0, int j1, int i0, int i1, int withB, int band, const VP* bp) {
+		HuRegion& g = rd.reg[rd.nRegions++];
+		g.j0 = j0; g.j1 = j1; g.i0 = i0; g.i1 = i1; g.withB = withB; g.band = band;
+		g.from = bp ? bp->from : 0; g.start = bp ? bp->start : 0; g.nIns = bp ? bp->nIns : 0; g.nDel = bp ? bp->nDel : 0;
+		g.off = off;
+		if(j1 >= j0 && i1 >= i0) off += (int64_t)(j1 - j0 + 1) * (i1 - i0 + 1);
+	};
+	if(nv == 0) add(1, K, 1, L, 1, 0, nullptr); /* full Viterbi (src/BandedHMMP7.cpp:748-771) */
+	else {
+		for(int p = 0; p < nv; ++p) {
+			int upQLen = p == 0 ? v[p].from - 1 : v[p].from - v[p - 1].to;
+			if(upQLen < 0) upQLen = 0;
+			int up_start = p == 0 ? v[p].start - upQLen * (1 + kMinGapFrac) : v[p - 1].end;
+			if(up_start < 1) up_start = 1;
+			int up_from = p == 0 ? v[p].from - upQLen * (1 + kMinGapFrac) : v[p - 1].to;
+			if(up_from < 1) up_from = 1;
+			add(up_start, v[p].start, up_from, v[p].from, 1, 0, nullptr);
+			add(v[p].start, v[p].end, v[p].from, v[p].to, 1, 1, &v[p]);
+		}
+		const VP& last = v[nv - 1];
+		int downQLen = L - last.to;
+		int down_end = last.end + downQLen * (1 + kMinGapFrac);
+		int down_to = last.to + downQLen * (1 + kMinGapFrac);
+		if(down_end > K) down_end = K;
+		if(down_to > L) down_to = L;
+		add(last.end, down_end, last.to, down_to, 0, 0, nullptr);
+	}
+	rd.scratchOff = off; /* total cells for now; turned into an offset by the caller */
+}
+
+static int upload_descs(hu_batch* b) {
+	int rc;
+	if((rc = b->dDescs.ensure(b->hDescs.size())) != HU_OK) return rc;
+	HIPCHK(hipMemcpyAsync(b->dDescs.p, b->hDescs.data(), b->hDescs.size() * sizeof(HuReadDesc), hipMemcpyHostToDevice, b->stream));
+	return HU_OK;
+}
+
+extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const int64_t* offs, const int32_t* vpaths,
+		const char* mates, const int64_t* moffs, const int32_t* mvpaths) {
+	if(!b || n < 0 || n > b->maxReads || (n > 0 && (!bases || !offs))) { hu_set_error("hu_batch_set_reads: bad argument"); return HU_ERR_ARG; }
+	if(mates && !moffs) { hu_set_error("hu_batch_set_reads: mates without offsets"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(b->db->device));
+	b->n = n; b->paired = mates != nullptr; b->nSeq = b->paired ? 2 * n : n; b->fromCodes = false;
+	b->hDescs.assign(b->nSeq, HuReadDesc());
+	b->hBases.clear();
+	int64_t cells = 0, tr = 0;
+	for(int s = 0; s < b->nSeq; ++s) {
+		const bool isMate = s >= n;
+		const int r = isMate ? s - n : s;
+		const char* src = isMate ? mates + moffs[r] : bases + offs[r];
+		const int64_t len64 = isMate ? moffs[r + 1] - moffs[r] : offs[r + 1] - offs[r];
+		HuReadDesc& rd = b->hDescs[s];
+		memset(&rd, 0, sizeof(rd));
+		rd.baseOff = (int64_t) b->hBases.size();
+		rd.len = (int32_t) len64;
+		bool bad = len64 < 1 || len64 > 65535;
+		for(int64_t i = 0; i < len64 && !bad; ++i) if(host_sym(src[i]) < 0) bad = true; /* PrimarySeq::encodeAt < 0 */
+		if(!bad) {
+			b->hBases.insert(b->hBases.end(), src, src + len64);
+			const int32_t* vp = isMate ? (mvpaths ? mvpaths + (size_t) r * 12 : nullptr) : (vpaths ? vpaths + (size_t) r * 12 : nullptr);
+			build_regions(b->db, rd.len, vp, rd);
+			const int64_t c = rd.scratchOff;
+			rd.scratchOff = cells; cells += c;
+		}
+		else { rd.len = 0; rd.nRegions = 0; }
+		rd.traceOff = tr;
+		tr += rd.len + b->db->dev.K + 8;
+	}
+	int rc;
+	if((rc = b->dBases.ensure(b->hBases.size() + 1)) != HU_OK) return rc;
+	if((rc = b->dScratch.ensure((size_t) cells * 3 + 1)) != HU_OK) return rc;
+	if((rc = b->dTraces.ensure((size_t) tr + 1)) != HU_OK) return rc;
+	if((rc = b->dVit.ensure(b->nSeq)) != HU_OK) return rc;
+	if(!b->hBases.empty()) HIPCHK(hipMemcpyAsync(b->dBases.p, b->hBases.data(), b->hBases.size(), hipMemcpyHostToDevice, b->stream));
+	if((rc = upload_descs(b)) != HU_OK) return rc;
+	b->state = ST_READS;
+	return HU_OK;
+}
+
+static int ensure_read_buffers(hu_batch* b) {
+	const HuDbDev& d = b->db->dev;
+	const size_t n = (size_t) b->n;
+	const size_t tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
+	int rc;
+	if((rc = b->dCodes.ensure(n * d.csLen)) != HU_OK) return rc;
+	if((rc = b->dStart.ensure(n)) != HU_OK) return rc;
+	if((rc = b->dEnd.ensure(n)) != HU_OK) return rc;
+	if((rc = b->dRp.ensure(tiles * d.WQ * HU_READ_TILE * 16)) != HU_OK) return rc;
+	if((rc = b->dTileQ.ensure(tiles)) != HU_OK) return rc;
+	return HU_OK;
+}
+
+__global__ void k_tile_ranges(int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int2* __restrict__ tileQ) {
+	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+	if(tile * HU_READ_TILE >= n) return;
+	int lo = 0x7fffffff, hi = -1;
+	for(int t = 0; t < HU_READ_TILE; ++t) {
+		const int r = tile * HU_READ_TILE + t;
+		if(r >= n) break;
+		const int s = rstart[r], e = rend[r];
+		if(e < s) continue;
+		lo = s < lo ? s : lo; hi = e > hi ? e : hi;
+	}
+	tileQ[tile] = hi >= 0 ? make_int2(lo >> 7, hi >> 7) : make_int2(0, -1);
+}
+
+extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) {
+	if(!b || n < 0 || n > b->maxReads || (n > 0 && (!codes || !start || !end))) { hu_set_error("hu_batch_set_aligned: bad argument"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const HuDbDev& d = b->db->dev;
+	b->n = n; b->nSeq = n; b->paired = false; b->fromCodes = true;
+	int rc;
+	if((rc = ensure_read_buffers(b)) != HU_OK) return rc;
+	b->hAlns.assign(n, HuAlnDev());
+	b->hStart.assign(start, start + n); b->hEnd.assign(end, end + n);
+	for(int r = 0; r < n; ++r) {
+		HuAlnDev& a = b->hAlns[r];
+		memset(&a, 0, sizeof(a));
+		const bool ok = start[r] >= 0 && start[r] <= end[r] && end[r] < d.csLen && start[r] >= d.winStart && end[r] < d.winStart + d.winLen;
+		a.status = ok ? HU_READ_OK : HU_READ_INVALID;
+		a.csStart = start[r] + 1; a.csEnd = end[r] + 1;
+		if(!ok) { b->hStart[r] = 0; b->hEnd[r] = -1; }
+	}
+	if(n) {
+		HIPCHK(hipMemcpyAsync(b->dCodes.p, codes, (size_t) n * d.csLen, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipMemcpyAsync(b->dStart.p, b->hStart.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipMemcpyAsync(b->dEnd.p, b->hEnd.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
+		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
+		HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
+		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p);
+		k_tile_ranges<<<(tiles + 63) / 64, 64, 0, b->stream>>>(n, b->dStart.p, b->dEnd.p, b->dTileQ.p);
+		HIPCHK(hipGetLastError());
+	}
+	b->state = ST_ALIGNED;
+	return HU_OK;
+}
+
+extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_READS || b->fromCodes) { hu_set_error("hu_align_batch: no reads set"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const HuDbDev& d = b->db->dev;
+	double tNN, tNB, tEC, tCC;
+	hu_mode_costs(d.K, o->align_mode, &tNN, &tNB, &tEC, &tCC);
+	int rc;
+	if((rc = ensure_read_buffers(b)) != HU_OK) return rc;
+	if((rc = b->dRows.ensure((size_t) b->nSeq * d.csLen)) != HU_OK) return rc;
+	if((rc = b->dAlns.ensure(b->nSeq)) != HU_OK) return rc;
+	b->hVit.resize(b->nSeq);
+	if(b->nSeq) {
+		{
+			Timer t(b, HU_T_VITERBI);
+			k_viterbi<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p);
+		}
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		/* banded version failed -> regular HMM (src/HmmUFOtu_main.cpp:89-93), one sequence at a time */
+		std::vector<int> redo;
+		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL && !(b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) redo.push_back(s);
+		for(int s : redo) {
+			HuReadDesc rd = b->hDescs[s];
+			build_regions(b->db, rd.len, nullptr, rd);
+			const int64_t cells = rd.scratchOff;
+			DBuf<double> scr; DBuf<HuReadDesc> dd; DBuf<HuVitOut> vo;
+			if((rc = scr.ensure((size_t) cells * 3)) != HU_OK || (rc = dd.ensure(1)) != HU_OK || (rc = vo.ensure(1)) != HU_OK) { scr.free_(); dd.free_(); vo.free_(); return rc; }
+			rd.scratchOff = 0;
+			HIPCHK(hipMemcpyAsync(dd.p, &rd, sizeof(rd), hipMemcpyHostToDevice, b->stream));
+			k_viterbi<<<1, 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
+			HIPCHK(hipMemcpyAsync(&b->hVit[s], vo.p, sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
+			HIPCHK(hipStreamSynchronize(b->stream));
+			if(b->hVit[s].status == HU_READ_NEEDS_FULL) b->hVit[s].status = HU_READ_INVALID;
+			b->hVit[s].traceLen = b->hVit[s].traceLen; /* trace already written at rd.traceOff */
+			HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
+			scr.free_(); dd.free_(); vo.free_();
+			b->hDescs[s].nRegions = -1; /* mark: full DP was used */
+		}
+		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL) {
+			b->hVit[s].status = HU_READ_INVALID;
+			HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
+		}
+		{
+			Timer t(b, HU_T_ALIGN_BUILD);
+			k_align_rows<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dTraces.p, b->dVit.p, b->dRows.p, b->dAlns.p);
+			if(b->paired) k_merge_rows<<<b->n, 256, 0, b->stream>>>(d, b->n, o->ignore_orient, b->dRows.p, b->dAlns.p);
+			const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
+			HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
+			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p);
+			k_tile_ranges<<<(tiles + 63) / 64, 64, 0, b->stream>>>(b->n, b->dStart.p, b->dEnd.p, b->dTileQ.p);
+		}
+		HIPCHK(hipGetLastError());
+		b->hAlns.resize(b->nSeq);
+		b->hStart.resize(b->n); b->hEnd.resize(b->n);
+		HIPCHK(hipMemcpyAsync(b->hAlns.data(), b->dAlns.p, (size_t) b->nSeq * sizeof(HuAlnDev), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hStart.data(), b->dStart.p, (size_t) b->n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hEnd.data(), b->dEnd.p, (size_t) b->n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		for(int s = 0; s < b->nSeq; ++s) b->hAlns[s].usedFull |= (b->hDescs[s].nRegions == -1 || (b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) ? 1 : 0;
+		/* reads whose region leaves the resident message window cannot be placed */
+		for(int r = 0; r < b->n; ++r) if(b->hAlns[r].status == HU_READ_OK && (b->hStart[r] < d.winStart || b->hEnd[r] >= d.winStart + d.winLen)) {
+			hu_set_error("read %d aligns to CS columns [%d,%d] outside the resident message window", r, b->hStart[r], b->hEnd[r]);
+			return HU_ERR_ARG;
+		}
+	}
+	b->state = ST_ALIGNED;
+	return HU_OK;
+}
+
+extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch: reads are not aligned"); return HU_ERR_STATE; }
+	if(o->max_nseed < 1 || o->max_nseed > HU_MAX_SEEDS) { hu_set_error("max_nseed must be in 1..%d", HU_MAX_SEEDS); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const HuDbDev& d = b->db->dev;
+	const size_t n = (size_t) b->n;
+	int rc;
+	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad)) != HU_OK) return rc;
+	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
+	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if(n) {
+		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
+		{
+			Timer t(b, HU_T_SEED_PDIST);
+			k_seed_pdist<HU_READ_TILE><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dPairs.p, b->n);
+		}
+		{
+			Timer t(b, HU_T_SEED_TOPK);
+			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);
+		}
+		HIPCHK(hipGetLastError());
+	}
+	b->state = ST_SEEDED;
+	return HU_OK;
+}
+
+extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_SEEDED) { hu_set_error("hu_estimate_batch: no seeds"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const size_t n = (size_t) b->n;
+	int rc;
+	if((rc = b->dEst.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if(n) {
+		Timer t(b, HU_T_ESTIMATE);
+		k_estimate<<<b->n * HU_MAX_SEEDS, 64, 0, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p,
+				b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p);
+	}
+	HIPCHK(hipGetLastError());
+	b->state = ST_ESTIMATED;
+	return HU_OK;
+}
+
+static bool cmpLoglik(const HostPlace& l, const HostPlace& r) { return l.loglik < r.loglik; }
+static bool cmpQPlace(const HostPlace& l, const HostPlace& r) { return l.qPlace < r.qPlace; }
+
+extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_ESTIMATED) { hu_set_error("hu_filter_batch: no estimates"); return HU_ERR_STATE; }
+	if(!(o->max_error >= 0)) { hu_set_error("max_error must be >= 0"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const hu_db* db = b->db;
+	const size_t n = (size_t) b->n;
+	b->hSeedCnt.resize(n); b->hSeedId.resize(n * HU_MAX_SEEDS); b->hSeedDN.resize(n * HU_MAX_SEEDS); b->hEst.resize(n * HU_MAX_SEEDS);
+	if(n) {
+		HIPCHK(hipMemcpyAsync(b->hSeedCnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hSeedId.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hSeedDN.data(), b->dSeedDN.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hEst.data(), b->dEst.p, n * HU_MAX_SEEDS * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	b->places.clear(); b->hCands.clear();
+	b->candOffs.assign(n + 1, 0);
+	std::vector<HostPlace> pl;
+	for(size_t r = 0; r < n; ++r) {
+		pl.clear();
+		const int cnt = b->hAlns[r].status == HU_READ_OK ? b->hSeedCnt[r] : 0;
+		for(int s = 0; s < cnt; ++s) {
+			const HuEstOut& e = b->hEst[r * HU_MAX_SEEDS + s];
+			HostPlace p;
+			memset(&p, 0, sizeof(p));
+			p.seedIdx = s; p.cNode = b->hSeedId[r * HU_MAX_SEEDS + s]; p.pNode = db->parent[p.cNode];
+			p.ratio = e.ratio; p.wnr = e.wnr; p.loglik = e.loglik; p.estLoglik = e.loglik; p.wuv = db->blen[p.cNode];
+			p.aNode = p.ratio <= 0.5 ? p.cNode : p.pNode;
+			pl.push_back(p);
+		}
+		if(!pl.empty()) { /* filterPlacements (src/HmmUFOtu_main.cpp:162-173) */
+			std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
+			const double bestLL = pl[0].loglik;
+			size_t g = 0;
+			for(; g < pl.size(); ++g) if(bestLL - pl[g].loglik > o->max_error) break;
+			pl.erase(pl.begin() + g, pl.end());
+		}
+		for(const HostPlace& p : pl) {
+			b->places.push_back(p);
+			HuCand c; c.read = (int32_t) r; c.node = p.cNode; c.ratio0 = p.ratio; c.wnr0 = p.wnr;
+			b->hCands.push_back(c);
+		}
+		b->candOffs[r + 1] = (int64_t) b->places.size();
+	}
+	b->state = ST_FILTERED;
+	return HU_OK;
+}
+
+extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_FILTERED) { hu_set_error("hu_place_batch: candidates are not filtered"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const size_t nc = b->hCands.size();
+	int rc;
+	if((rc = b->dCands.ensure(nc)) != HU_OK) return rc;
+	if((rc = b->dPlaceOut.ensure(nc)) != HU_OK) return rc;
+	b->hPlaceOut.resize(nc);
+	if(nc) {
+		int maxR = 1;
+		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
+		const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
+		if(lds > 160 * 1024) { hu_set_error("alignment region of %d columns does not fit the placement kernel's LDS", maxR); return HU_ERR_ARG; }
+		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
+		{
+			Timer t(b, HU_T_PLACE);
+			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p);
+		}
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(b->hPlaceOut.data(), b->dPlaceOut.p, nc * sizeof(HuPlaceOut), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	b->state = ST_PLACED;
+	return HU_OK;
+}
+
+static double add_scaled(double a, double c) { double s = std::max(a, c); return std::log(std::exp(a - s) + std::exp(c - s)) + s; }
+static double p2q(double p) { return -10 * std::log(p) / std::log(10.0); }
+
+extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
+	if(!b || !o) return HU_ERR_ARG;
+	if(b->state < ST_PLACED) { hu_set_error("hu_finish_batch: candidates are not placed"); return HU_ERR_STATE; }
+	const hu_db* db = b->db;
+	const size_t n = (size_t) b->n;
+	b->best.assign(n, hu_place_rec());
+	/* the root message is re-initialised to INVALID_LOGLIK = 1 before treeLoglik reads it, so every
+	 * placement's final loglik is (end-start+1) * log(sum_i pi_i e^1) (src/PhyloTreeUnrooted.cpp:918-922,
+	 * SURVEY.md F4); reproduced, not fixed */
+	const double e1 = std::exp(1.0);
+	const double siteLL = std::log((db->mdl.pi[0] * e1 + db->mdl.pi[2] * e1) + (db->mdl.pi[1] * e1 + db->mdl.pi[3] * e1));
+	std::vector<HostPlace> pl;
+	std::vector<std::pair<int32_t, double>> tax;
+	for(size_t r = 0; r < n; ++r) {
+		hu_place_rec& br = b->best[r];
+		br.c_node = br.p_node = br.a_node = -1; br.n_cand = 0;
+		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = NAN;
+		const int64_t lo = b->candOffs[r], hi = b->candOffs[r + 1];
+		if(hi <= lo) continue;
+		pl.assign(b->places.begin() + lo, b->places.begin() + hi);
+		const int nsite = b->hEnd[r] - b->hStart[r] + 1;
+		double ll = 0;
+		for(int j = 0; j < nsite; ++j) ll += siteLL;
+		for(int64_t c = lo; c < hi; ++c) { /* PTUnrooted::placeSeq const (src/PhyloTreeUnrooted.cpp:936-952) */
+			HostPlace& p = pl[c - lo];
+			const HuPlaceOut& po = b->hPlaceOut[c];
+			p.loglik = ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters;
+			p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
+			b->places[c] = p;
+		}
+		if(o->only_ml) std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
+		else { /* calcQValues (src/HmmUFOtu_main.cpp:182-216) */
+			tax.clear();
+			double norm = -kInf;
+			std::vector<double> pp(pl.size());
+			for(size_t i = 0; i < pl.size(); ++i) {
+				const HostPlace& p = pl[i];
+				const double logPrior = o->prior == HU_PRIOR_UNIFORM ? -0.0 : -(p.annoDist() - p.wnr + p.height);
+				const double v = p.loglik + logPrior;
+				pp[i] = v;
+				const int32_t key = db->annoId[p.aNode];
+				bool found = false;
+				for(auto& kv : tax) if(kv.first == key) { kv.second = add_scaled(kv.second, v); found = true; break; }
+				if(!found) tax.push_back({key, v});
+				norm = add_scaled(norm, v);
+			}
+			double mx = pp[0];
+			for(double v : pp) mx = std::max(mx, v);
+			double sum = 0;
+			std::vector<double> pr(pl.size());
+			for(size_t i = 0; i < pl.size(); ++i) { pr[i] = std::exp(pp[i] - mx); sum += pr[i]; }
+			for(size_t i = 0; i < pl.size(); ++i) { const double q = p2q(1 - pr[i] / sum); pl[i].qPlace = q > 250 ? 250 : q; }
+			for(size_t i = 0; i < pl.size(); ++i) {
+				const int32_t key = db->annoId[pl[i].aNode];
+				double tp = 0;
+				for(auto& kv : tax) if(kv.first == key) tp = kv.second;
+				const double q = p2q(1 - std::exp(tp - norm));
+				pl[i].qTaxon = q > 250 ? 250 : q;
+			}
+			std::sort(pl.rbegin(), pl.rend(), cmpQPlace);
+		}
+		const HostPlace& p = pl[0];
+		br.c_node = p.cNode; br.p_node = p.pNode; br.a_node = p.aNode; br.n_cand = (int32_t) pl.size();
+		br.wuv = p.wuv; br.ratio = p.ratio; br.wnr = p.wnr; br.loglik = p.loglik; br.height = p.height;
+		br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik;
+	}
+	b->state = ST_FINISHED;
+	return HU_OK;
+}
+
+extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
+	int rc;
+	if(!b || !o) return HU_ERR_ARG;
+	if(!b->fromCodes && (rc = hu_align_batch(b, o)) != HU_OK) return rc;
+	if((rc = hu_seed_batch(b, o)) != HU_OK) return rc;
+	if((rc = hu_estimate_batch(b, o)) != HU_OK) return rc;
+	if((rc = hu_filter_batch(b, o)) != HU_OK) return rc;
+	if((rc = hu_place_batch(b, o)) != HU_OK) return rc;
+	return hu_finish_batch(b, o);
+}
+
+/* ------------------------------------------------------------------------------ results */
+extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align, char* trace, int trace_stride) {
+	if(!b) return HU_ERR_ARG;
+	if(b->state < ST_ALIGNED) { hu_set_error("no alignments yet"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const HuDbDev& d = b->db->dev;
+	if(recs) for(int r = 0; r < b->n; ++r) {
+		const HuAlnDev& a = b->hAlns[r];
+		recs[r].seq_start = a.seqStart; recs[r].seq_end = a.seqEnd; recs[r].hmm_start = a.hmmStart; recs[r].hmm_end = a.hmmEnd;
+		recs[r].cs_start = a.csStart; recs[r].cs_end = a.csEnd; recs[r].status = a.status; recs[r].used_full = a.usedFull; recs[r].cost = a.cost;
+	}
+	if(align && !b->fromCodes && b->n) {
+		HIPCHK(hipMemcpyAsync(align, b->dRows.p, (size_t) b->n * d.csLen, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	if(trace && !b->fromCodes && trace_stride > 0) {
+		std::vector<char> all(b->hDescs.empty() ? 0 : (size_t)(b->hDescs.back().traceOff + b->hDescs.back().len + d.K + 8));
+		if(!all.empty()) { HIPCHK(hipMemcpyAsync(all.data(), b->dTraces.p, all.size(), hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+		for(int r = 0; r < b->n; ++r) {
+			const int len = std::min(b->hVit[r].traceLen, trace_stride - 1);
+			memcpy(trace + (size_t) r * trace_stride, all.data() + b->hDescs[r].traceOff, len > 0 ? len : 0);
+			trace[(size_t) r * trace_stride + (len > 0 ? len : 0)] = 0;
+		}
+	}
+	return HU_OK;
+}
+extern "C" int hu_batch_get_codes(hu_batch* b, int8_t* codes, int32_t* start, int32_t* end) {
+	if(!b) return HU_ERR_ARG;
+	if(b->state < ST_ALIGNED) { hu_set_error("no alignments yet"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	if(codes && b->n) { HIPCHK(hipMemcpyAsync(codes, b->dCodes.p, (size_t) b->n * b->db->dev.csLen, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+	if(start) memcpy(start, b->hStart.data(), (size_t) b->n * 4);
+	if(end) memcpy(end, b->hEnd.data(), (size_t) b->n * 4);
+	return HU_OK;
+}
+extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N) {
+	if(!b || read < 0 || read >= b->n) return HU_ERR_ARG;
+	if(b->state < ST_SEEDED) { hu_set_error("no seed scan yet"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const int nn = b->db->dev.nNodes;
+	std::vector<uint32_t> v(nn);
+	HIPCHK(hipMemcpyAsync(v.data(), b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	for(int i = 0; i < nn; ++i) { if(d) d[i] = (int32_t)(v[i] >> 16); if(N) N[i] = (int32_t)(v[i] & 0xffffu); }
+	return HU_OK;
+}
+extern "C" int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N) {
+	if(!b) return HU_ERR_ARG;
+	if(b->state < ST_SEEDED) { hu_set_error("no seeds yet"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const size_t n = (size_t) b->n;
+	std::vector<int32_t> cnt(n), id(n * HU_MAX_SEEDS); std::vector<uint32_t> dn(n * HU_MAX_SEEDS);
+	if(n) {
+		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(id.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(dn.data(), b->dSeedDN.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	for(size_t r = 0; r < n; ++r) {
+		if(n_seeds) n_seeds[r] = cnt[r];
+		for(int s = 0; s < HU_MAX_SEEDS; ++s) {
+			const bool ok = s < cnt[r];
+			const size_t k = r * HU_MAX_SEEDS + s;
+			if(ids) ids[k] = ok ? id[k] : -1;
+			if(d) d[k] = ok ? (int32_t)(dn[k] >> 16) : 0;
+			if(N) N[k] = ok ? (int32_t)(dn[k] & 0xffffu) : 0;
+		}
+	}
+	return HU_OK;
+}
+extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik) {
+	if(!b) return HU_ERR_ARG;
+	if(b->state < ST_ESTIMATED) { hu_set_error("no estimates yet"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const size_t n = (size_t) b->n;
+	std::vector<HuEstOut> e(n * HU_MAX_SEEDS); std::vector<int32_t> cnt(n);
+	if(n) {
+		HIPCHK(hipMemcpyAsync(e.data(), b->dEst.p, e.size() * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	for(size_t r = 0; r < n; ++r) for(int s = 0; s < HU_MAX_SEEDS; ++s) {
+		const size_t k = r * HU_MAX_SEEDS + s; const bool ok = s < cnt[r];
+		if(ratio) ratio[k] = ok ? e[k].ratio : NAN;
+		if(wnr) wnr[k] = ok ? e[k].wnr : NAN;
+		if(loglik) loglik[k] = ok ? e[k].loglik : NAN;
+	}
+	return HU_OK;
+}
+extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters) {
+	if(!b) return HU_ERR_ARG;
+	if(b->state < ST_FILTERED) { hu_set_error("no candidates yet"); return HU_ERR_STATE; }
+	if(offs) memcpy(offs, b->candOffs.data(), b->candOffs.size() * 8);
+	for(size_t c = 0; c < b->places.size(); ++c) {
+		const HostPlace& p = b->places[c];
+		if(c_node) c_node[c] = p.cNode; if(ratio) ratio[c] = p.ratio; if(wnr) wnr[c] = p.wnr;
+		if(est_loglik) est_loglik[c] = p.estLoglik; if(iters) iters[c] = p.iters;
+	}
+	return HU_OK;
+}
+extern "C" int hu_batch_get_placements(hu_batch* b, hu_place_rec* best) {
+	if(!b || !best) return HU_ERR_ARG;
+	if(b->state < ST_FINISHED) { hu_set_error("batch is not finished"); return HU_ERR_STATE; }
+	memcpy(best, b->best.data(), b->best.size() * sizeof(hu_place_rec));
+	return HU_OK;
+}

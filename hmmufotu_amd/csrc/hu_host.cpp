@@ -1,0 +1,395 @@
+// Host-side preparation: substitution-model spectral forms, profile post-load chain,
+// readers of the reference's on-disk formats.  No device code in this file.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include "hu_common.h"
+
+static thread_local char g_err[512] = "";
+
+void hu_set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+extern "C" const char* hu_last_error(void) { return g_err; }
+
+extern "C" void hu_default_opts(hu_opts* o) {
+	o->align_mode = HU_MODE_GLOBAL;
+	o->max_nseed = 50;
+	o->max_diff = std::numeric_limits<double>::infinity();
+	o->max_height = std::numeric_limits<double>::infinity();
+	o->max_error = 20;
+	o->weighted = 0;
+	o->only_ml = 0;
+	o->prior = HU_PRIOR_UNIFORM;
+	o->ignore_orient = 0;
+}
+
+/* ------------------------------------------------------------------ substitution models */
+static void sym_eig4(double A[16], double V[16], double w[4]) {
+	for(int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+	for(int sweep = 0; sweep < 64; ++sweep) {
+		double off = 0;
+		for(int p = 0; p < 4; ++p) for(int q = p + 1; q < 4; ++q) off += A[p*4+q] * A[p*4+q];
+		if(off < 1e-300) break;
+		for(int p = 0; p < 4; ++p) for(int q = p + 1; q < 4; ++q) {
+			double apq = A[p*4+q];
+			if(apq == 0) continue;
+			double theta = (A[q*4+q] - A[p*4+p]) / (2 * apq);
+			double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+			double c = 1 / std::sqrt(t * t + 1), s = t * c;
+			for(int k = 0; k < 4; ++k) { double a = A[k*4+p], b = A[k*4+q]; A[k*4+p] = c * a - s * b; A[k*4+q] = s * a + c * b; }
+			for(int k = 0; k < 4; ++k) { double a = A[p*4+k], b = A[q*4+k]; A[p*4+k] = c * a - s * b; A[q*4+k] = s * a + c * b; }
+			for(int k = 0; k < 4; ++k) { double a = V[k*4+p], b = V[k*4+q]; V[k*4+p] = c * a - s * b; V[k*4+q] = s * a + c * b; }
+		}
+	}
+	for(int i = 0; i < 4; ++i) w[i] = A[i*4+i];
+}
+
+/* Rate matrix of each model type as implied by the reference's Pr(t):
+ *   GTR   Q = R*diag(pi), diagonal = -rowsum, divided by -trace(Q)   (src/GTR.cpp:124-131; note
+ *         DNASubModel::scale is called with its default pi = Ones(), src/DNASubModel.h:154)
+ *   TN93  Q(i,j) = beta pi(j) k(i,j), k = kr for A<->G, ky for C<->T, 1 otherwise (src/TN93.h:113-154)
+ *   HKY85 kr = ky = kappa (src/HKY85.h:111-153); F81 k = 1 (src/F81.h:110-118)
+ *   K80   pi = 1/4, transitions kappa*beta, transversions beta, beta = 1/(2 kappa) (src/K80.h:98-118)
+ *   JC69  pi = 1/4, every rate 1/3 (src/JC69.h:97-101) */
+int hu_model_prepare(const hu_model_desc* d, HuModelDev* out) {
+	memset(out, 0, sizeof(*out));
+	out->type = d->type;
+	double pi[4], Q[16];
+	for(int i = 0; i < 4; ++i) pi[i] = (d->type == HU_K80 || d->type == HU_JC69) ? 0.25 : d->pi[i];
+	for(int i = 0; i < 4; ++i) if(!(pi[i] > 0)) { hu_set_error("model: base frequency %d is not positive", i); return HU_ERR_ARG; }
+	auto ti = [](int i, int j) { return (i ^ j) == 2; }; /* A(0)<->G(2), C(1)<->T(3) */
+	switch(d->type) {
+	case HU_GTR: {
+		for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) Q[i*4+j] = i == j ? 0.0 : d->par[i*4+j] * pi[j];
+		double tr = 0;
+		for(int i = 0; i < 4; ++i) { double s = 0; for(int j = 0; j < 4; ++j) if(j != i) s += Q[i*4+j]; Q[i*4+i] = -s; tr += -s; }
+		for(int i = 0; i < 16; ++i) Q[i] = Q[i] / -tr;
+		break;
+	}
+	case HU_TN93: case HU_HKY85: case HU_F81: {
+		double kr = 1, ky = 1, beta;
+		if(d->type == HU_TN93) { kr = d->par[0]; ky = d->par[1]; beta = d->par[2]; }
+		else if(d->type == HU_HKY85) { kr = ky = d->par[0]; beta = d->par[1]; }
+		else beta = d->par[0];
+		for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j)
+			Q[i*4+j] = i == j ? 0.0 : beta * pi[j] * (ti(i, j) ? ((i == 0 || i == 2) ? kr : ky) : 1.0);
+		break;
+	}
+	case HU_K80: {
+		double kappa = d->par[0], beta = 1 / (2 * kappa);
+		for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) Q[i*4+j] = i == j ? 0.0 : (ti(i, j) ? kappa * beta : beta);
+		break;
+	}
+	case HU_JC69:
+		for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) Q[i*4+j] = i == j ? 0.0 : 1.0 / 3;
+		break;
+	default:
+		hu_set_error("model: unknown type %d", d->type);
+		return HU_ERR_ARG;
+	}
+	if(d->type != HU_GTR)
+		for(int i = 0; i < 4; ++i) { double s = 0; for(int j = 0; j < 4; ++j) if(j != i) s += Q[i*4+j]; Q[i*4+i] = -s; }
+	double S[16], V[16], sq[4], isq[4];
+	for(int i = 0; i < 4; ++i) { sq[i] = std::sqrt(pi[i]); isq[i] = 1 / sq[i]; }
+	for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) S[i*4+j] = sq[i] * Q[i*4+j] * isq[j];
+	for(int i = 0; i < 4; ++i) for(int j = i + 1; j < 4; ++j) { double a = 0.5 * (S[i*4+j] + S[j*4+i]); S[i*4+j] = S[j*4+i] = a; }
+	sym_eig4(S, V, out->lam);
+	for(int i = 0; i < 4; ++i) for(int k = 0; k < 4; ++k) { out->U[i*4+k] = isq[i] * V[i*4+k]; out->U1[k*4+i] = V[i*4+k] * sq[i]; }
+	/* the zero eigenvalue is exact in theory: snap it so that P(t) rows keep summing to 1 for huge t */
+	int z = 0;
+	for(int k = 1; k < 4; ++k) if(std::fabs(out->lam[k]) < std::fabs(out->lam[z])) z = k;
+	out->lam[z] = 0.0;
+	for(int i = 0; i < 4; ++i) { out->pi[i] = pi[i]; out->logpi[i] = std::log(pi[i]); }
+	out->dgK = d->dg_k;
+	if(d->dg_k < 0 || d->dg_k > HU_MAX_DGK) { hu_set_error("model: dg_k %d out of range", d->dg_k); return HU_ERR_ARG; }
+	out->rate[0] = 1.0;
+	for(int k = 0; k < d->dg_k; ++k) out->rate[k] = d->dg_rate[k];
+	return HU_OK;
+}
+
+/* host-only export for CPU tests of the spectral forms */
+extern "C" int hu_model_spectral(const hu_model_desc* d, double* U, double* lam, double* U1) {
+	HuModelDev m;
+	int rc = hu_model_prepare(d, &m);
+	if(rc != HU_OK) return rc;
+	memcpy(U, m.U, sizeof(m.U)); memcpy(lam, m.lam, sizeof(m.lam)); memcpy(U1, m.U1, sizeof(m.U1));
+	return HU_OK;
+}
+
+/* ------------------------------------------------------------------ profile (BandedHMMP7) */
+/* post-load chain of operator>> (src/BandedHMMP7.cpp:104-109): extend_index,
+ * adjustProfileLocalMode (:721-733), wingRetract (:1083-1120) */
+int HuProfileHost::init(const hu_profile_desc* d) {
+	if(d->K < 1 || d->L < d->K || d->L > 65535) { hu_set_error("profile: bad sizes K=%d L=%d", d->K, d->L); return HU_ERR_ARG; }
+	K = d->K; L = d->L;
+	EM.assign(d->EM, d->EM + 4 * (K + 1));
+	EI.assign(d->EI, d->EI + 4 * (K + 1));
+	T7.assign(d->T, d->T + 7 * (K + 1));
+	p2cs.assign(d->p2cs, d->p2cs + K + 1);
+	p2cs[0] = 0;
+	for(int k = 1; k <= K; ++k)
+		if(p2cs[k] < 1 || p2cs[k] > L || (k > 1 && p2cs[k] <= p2cs[k - 1])) { hu_set_error("profile: MAP of column %d invalid", k); return HU_ERR_ARG; }
+	cs2p.assign(L + 2, 0);
+	for(int k = 1; k <= K; ++k) cs2p[p2cs[k]] = k;
+	for(int i = p2cs[K] + 1; i <= L; ++i) cs2p[i] = K;
+	const double* Tc = T7.data();
+	std::vector<double> entry(K + 1, 0.0), exitp(K + 1, 0.0);
+	double t0 = std::exp(-Tc[0]), tK = std::exp(-Tc[(size_t) K * 7]);
+	for(int k = 1; k <= K; ++k) { entry[k] = t0; exitp[k] = tK; }
+	{ /* B->D1->...->Dj-1->Mj folded into B->Mj; the partial sums are shared between consecutive j */
+		double chain = Tc[2]; /* Tmat_cost[0](M,D) */
+		for(int j = 2; j <= K; ++j) {
+			if(j > 2) chain += Tc[(size_t)(j - 2) * 7 + 6];
+			double cost = chain + Tc[(size_t)(j - 1) * 7 + 5];
+			entry[j] += std::exp(-cost);
+			if(entry[j] > 1) entry[j] = 1;
+		}
+	}
+	for(int i = 1; i <= K - 1; ++i) { /* Mi->Di+1->...->DK->E folded into Mi->E */
+		double cost = Tc[(size_t) i * 7 + 2];
+		for(int j = i + 1; j < K; ++j) cost += Tc[(size_t) j * 7 + 6];
+		cost += Tc[(size_t) K * 7 + 5];
+		exitp[i] += std::exp(-cost);
+		if(exitp[i] > 1) exitp[i] = 1;
+	}
+	entryC.resize(K + 1); exitC.resize(K + 1);
+	for(int k = 0; k <= K; ++k) { entryC[k] = -std::log(entry[k]); exitC[k] = -std::log(exitp[k]); }
+	return HU_OK;
+}
+
+/* setSequenceMode (src/BandedHMMP7.cpp:561-583) with p1 of src/BandedHMMP7Bg.cpp:33-35 */
+void hu_mode_costs(int K, int mode, double* tNN, double* tNB, double* tEC, double* tCC) {
+	double p1 = K >= 350 ? K / (K + 1.0) : 350 / (350 + 1.0);
+	double term = 1 - p1, nn = 0, cc = 0;
+	switch(mode) {
+	case HU_MODE_LOCAL: nn = cc = term; break;
+	case HU_MODE_NGCL: cc = term; break;
+	case HU_MODE_CGNL: nn = term; break;
+	default: break;
+	}
+	*tNN = -std::log(nn); *tNB = -std::log(1.0 - nn); *tEC = -std::log(1.0); *tCC = -std::log(cc);
+}
+
+/* ------------------------------------------------------------------ .hmm reader */
+static double hmm_value(const std::string& s) { return s != "*" ? atof(s.c_str()) : std::numeric_limits<double>::infinity(); }
+
+/* HMMER3/f-style text as BandedHMMP7's operator>> accepts it (src/BandedHMMP7.cpp:100-246) */
+int hu_read_hmm(const char* path, HuProfileHost& prof, std::vector<double>& EM, std::vector<double>& EI,
+		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L) {
+	std::ifstream in(path);
+	if(!in) { hu_set_error("cannot open HMM file '%s'", path); return HU_ERR_IO; }
+	std::string line;
+	K = 0; L = 0;
+	int k = 0;
+	bool mapYes = false, done = false;
+	std::map<std::string, std::string> tags;
+	while(std::getline(in, line)) {
+		if(line == "//") { done = true; break; }
+		if(line.empty()) continue;
+		std::istringstream iss(line);
+		std::string tag;
+		if(!isspace((unsigned char) line[0])) {
+			iss >> tag;
+			if(tag.substr(0, 6) == "HMMER3") {
+				if(tag.length() < 8 || tag[7] < 'f') { hu_set_error("obsolete HMM file version %s", tag.c_str()); return HU_ERR_IO; }
+			}
+			else if(tag == "LENG") {
+				iss >> K;
+				if(K < 1 || K > 65535) { hu_set_error("HMM LENG %d out of range", K); return HU_ERR_IO; }
+				EM.assign((size_t) 4 * (K + 1), std::numeric_limits<double>::infinity());
+				EI = EM;
+				T.assign((size_t) 7 * (K + 1), std::numeric_limits<double>::infinity());
+				p2cs.assign(K + 1, 0);
+			}
+			else if(tag == "ALPH") { std::string a; iss >> a; if(a != "DNA") { hu_set_error("HMM alphabet must be DNA"); return HU_ERR_IO; } }
+			else if(tag == "MAXL") iss >> L;
+			else if(tag == "HMM") { std::string skip; std::getline(in, skip); }
+			else { std::string val; iss >> val; tags[tag] = val; if(tag == "MAP") mapYes = (val == "yes"); }
+		}
+		else {
+			if(K == 0) { hu_set_error("HMM body before LENG"); return HU_ERR_IO; }
+			iss >> tag;
+			std::string tmp;
+			bool compo = tag == "COMPO";
+			int idx = 0;
+			bool isInt = sscanf(tag.c_str(), "%d", &idx) == 1;
+			if(k > K) { hu_set_error("HMM has more than LENG states"); return HU_ERR_IO; }
+			if(compo || isInt) {
+				if((compo && k != 0) || (!compo && idx != k)) { hu_set_error("HMM state line %s out of order", tag.c_str()); return HU_ERR_IO; }
+				for(int i = 0; i < 4; ++i) { iss >> tmp; EM[(size_t) k * 4 + i] = hmm_value(tmp); }
+				if(!compo) {
+					if(!mapYes) { hu_set_error("HMM file must have the MAP flag set to 'yes'"); return HU_ERR_IO; }
+					iss >> tmp; p2cs[k] = atoi(tmp.c_str());
+				}
+				for(int i = 0; i < 4; ++i) { in >> tmp; EI[(size_t) k * 4 + i] = hmm_value(tmp); }
+				for(int i = 0; i < 7; ++i) { in >> tmp; T[(size_t) k * 7 + i] = hmm_value(tmp); }
+			}
+			else { /* non-COMPO begin-state line: tag is the first insert emission */
+				if(k != 0) { hu_set_error("unexpected HMM line"); return HU_ERR_IO; }
+				EI[0] = hmm_value(tag);
+				for(int i = 1; i < 4; ++i) { iss >> tmp; EI[i] = hmm_value(tmp); }
+				for(int i = 0; i < 7; ++i) { in >> tmp; T[i] = hmm_value(tmp); }
+			}
+			std::getline(in, tmp); /* rest of the transition line */
+			k++;
+		}
+	}
+	if(!done || k != K + 1) { hu_set_error("HMM file '%s' truncated (read %d of %d states)", path, k, K + 1); return HU_ERR_IO; }
+	if(L == 0) L = p2cs[K];
+	hu_profile_desc d{K, L, EM.data(), EI.data(), T.data(), p2cs.data()};
+	return prof.init(&d);
+}
+
+/* ------------------------------------------------------------------ .ptu reader */
+namespace {
+struct Rd {
+	std::ifstream in;
+	bool ok = true;
+	template<class X> X get() { X v{}; in.read((char*) &v, sizeof(X)); if(!in) ok = false; return v; }
+	std::string str() {
+		uint64_t n = get<uint64_t>();
+		if(!ok || n > (1ull << 32)) { ok = false; return std::string(); }
+		std::string s(n, '\0');
+		if(n) in.read(&s[0], n);
+		if(!in) ok = false;
+		return s;
+	}
+};
+}
+
+/* model text block embedded in the .ptu (readers: src/GTR.cpp:43-81, TN93.cpp:40-77,
+ * HKY85.cpp:40-75, F81.cpp:40-73, K80.cpp:41-71, JC69.cpp:39-65); consumes exactly the bytes
+ * the reference consumes so that the binary dG block that follows stays aligned */
+static int read_model_text(std::ifstream& in, hu_model_desc& m) {
+	memset(&m, 0, sizeof(m));
+	std::string type, tag, line, value;
+	in >> type;
+	in.ignore();
+	static const char* names[] = {"GTR", "TN93", "HKY85", "F81", "K80", "JC69"};
+	m.type = -1;
+	for(int i = 0; i < 6; ++i) if(type == names[i]) m.type = i;
+	if(m.type < 0) { hu_set_error("ptu: unknown model type '%s'", type.c_str()); return HU_ERR_IO; }
+	for(int i = 0; i < 4; ++i) m.pi[i] = 0.25;
+	while(in >> tag) {
+		if(tag[0] == '#') { std::getline(in, line); continue; }
+		if(tag == "Type:") {
+			in >> value;
+			if(value != type) { hu_set_error("ptu: model block type mismatch"); return HU_ERR_IO; }
+			if(m.type == HU_JC69) { std::getline(in, line); break; }
+		}
+		else if(tag == "pi:") { for(int i = 0; i < 4; ++i) in >> m.pi[i]; }
+		else if(tag == "R:" && m.type == HU_GTR) { for(int i = 0; i < 16; ++i) in >> m.par[i]; }
+		else if(tag == "Q:" && m.type == HU_GTR) { for(int i = 0; i <= 4; ++i) std::getline(in, line); break; }
+		else if(tag == "kr:" && m.type == HU_TN93) in >> m.par[0];
+		else if(tag == "ky:" && m.type == HU_TN93) in >> m.par[1];
+		else if(tag == "kappa:" && m.type == HU_HKY85) in >> m.par[0];
+		else if(tag == "kappa:" && m.type == HU_K80) { in >> m.par[0]; std::getline(in, line); break; }
+		else if(tag == "beta:" && (m.type == HU_TN93 || m.type == HU_HKY85 || m.type == HU_F81)) {
+			in >> m.par[m.type == HU_TN93 ? 2 : m.type == HU_HKY85 ? 1 : 0];
+			std::getline(in, line);
+			break;
+		}
+		else { hu_set_error("ptu: unrecognised model tag '%s'", tag.c_str()); return HU_ERR_IO; }
+	}
+	return in ? HU_OK : HU_ERR_IO;
+}
+
+/* PTUnrooted::load (src/PhyloTreeUnrooted.cpp:496-535 and :99-114, :605-621, :632-697,
+ * :1068-1083; src/DigitalSeq.cpp:105-121; src/util/ProgEnv.cpp:24-64) */
+int hu_read_ptu(const char* path, HuTreeHost& t) {
+	Rd r;
+	r.in.open(path, std::ios::binary);
+	if(!r.in) { hu_set_error("cannot open PTU file '%s'", path); return HU_ERR_IO; }
+	char magic[8];
+	r.in.read(magic, 8);
+	if(!r.in || memcmp(magic, "HmmUFOtu", 8) != 0) { hu_set_error("'%s' is not a HmmUFOtu database file", path); return HU_ERR_IO; }
+	for(int i = 0; i < 3; ++i) r.get<int32_t>();
+	uint64_t n = r.get<uint64_t>();
+	int32_t csLen = r.get<int32_t>();
+	if(!r.ok || n == 0 || n > (1u << 24) || csLen < 1 || csLen > 65535) { hu_set_error("ptu: bad header"); return HU_ERR_IO; }
+	t.n = (int32_t) n; t.csLen = csLen;
+	t.parent.assign(n, -1); t.blen.assign(n, 0.0); t.height.assign(n, 0.0); t.annoDist.assign(n, 0.0);
+	t.seq.assign((size_t) n * csLen, (int8_t) -2);
+	t.names.resize(n); t.annos.resize(n);
+	for(uint64_t i = 0; i < n; ++i) {
+		int64_t id = r.get<int64_t>();
+		if(!r.ok || id != (int64_t) i) { hu_set_error("ptu: node %llu has id %lld", (unsigned long long) i, (long long) id); return HU_ERR_IO; }
+		t.names[i] = r.str();
+		bool withAbc = r.get<uint8_t>() != 0;
+		if(withAbc) r.str();
+		r.str(); /* seq name */
+		std::string s = r.str();
+		if(!r.ok) break;
+		if(!s.empty()) {
+			if((int) s.size() != csLen) { hu_set_error("ptu: node %llu sequence length %zu != csLen", (unsigned long long) i, s.size()); return HU_ERR_IO; }
+			memcpy(&t.seq[(size_t) i * csLen], s.data(), csLen);
+		}
+		t.annos[i] = r.str();
+		t.annoDist[i] = r.get<double>();
+	}
+	uint64_t nEdges = r.get<uint64_t>();
+	if(!r.ok || nEdges != 2 * (n - 1)) { hu_set_error("ptu: edge count %llu does not match %llu nodes", (unsigned long long) nEdges, (unsigned long long) n); return HU_ERR_IO; }
+	t.up.assign((size_t) n * csLen * 4, 0.0);
+	t.down.assign((size_t) n * csLen * 4, 0.0);
+	/* first pass cannot know parents before all isParent flags are seen, so keep the edge list */
+	struct Edge { int64_t a, b; bool aParent; double len; std::streampos pos; };
+	std::vector<Edge> edges(nEdges);
+	for(uint64_t e = 0; e < nEdges; ++e) {
+		Edge& E = edges[e];
+		E.a = r.get<int64_t>(); E.b = r.get<int64_t>(); E.aParent = r.get<uint8_t>() != 0;
+		E.len = r.get<double>();
+		uint64_t N = r.get<uint64_t>();
+		if(!r.ok || N != (uint64_t) 4 * csLen || E.a < 0 || E.b < 0 || E.a >= (int64_t) n || E.b >= (int64_t) n) { hu_set_error("ptu: bad edge %llu", (unsigned long long) e); return HU_ERR_IO; }
+		E.pos = r.in.tellg();
+		/* message of a->b: if a is the parent it is down[b], else up[a] */
+		double* dst = E.aParent ? &t.down[(size_t) E.b * csLen * 4] : &t.up[(size_t) E.a * csLen * 4];
+		r.in.read((char*) dst, sizeof(double) * N);
+		if(!r.in) { r.ok = false; break; }
+		if(E.aParent) { t.parent[E.b] = (int32_t) E.a; t.blen[E.b] = E.len; }
+	}
+	int64_t rootId = r.get<int64_t>();
+	if(!r.ok || rootId < 0 || rootId >= (int64_t) n) { hu_set_error("ptu: bad root"); return HU_ERR_IO; }
+	t.root = (int32_t) rootId;
+	r.in.read((char*) &t.up[(size_t) rootId * csLen * 4], sizeof(double) * 4 * csLen);
+	for(uint64_t i = 0; i < n; ++i) {
+		int64_t id = r.get<int64_t>(); double h = r.get<double>();
+		if(!r.ok || id < 0 || id >= (int64_t) n) { hu_set_error("ptu: bad height record"); return HU_ERR_IO; }
+		t.height[id] = h;
+	}
+	uint32_t nIdx = r.get<uint32_t>();
+	for(uint32_t i = 0; i < nIdx && r.ok; ++i) { r.get<uint32_t>(); r.get<int64_t>(); }
+	if(!r.ok) { hu_set_error("ptu: truncated file"); return HU_ERR_IO; }
+	int rc = read_model_text(r.in, t.model);
+	if(rc != HU_OK) return rc;
+	bool hasDG = r.get<uint8_t>() != 0;
+	if(hasDG) {
+		int32_t K = r.get<int32_t>();
+		r.get<double>(); /* alpha */
+		if(!r.ok || K < 1 || K > HU_MAX_DGK) { hu_set_error("ptu: bad discrete-Gamma block"); return HU_ERR_IO; }
+		for(int i = 0; i <= K; ++i) r.get<double>();
+		for(int i = 0; i < K; ++i) t.model.dg_rate[i] = r.get<double>();
+		t.model.dg_k = K;
+	}
+	if(!r.ok) { hu_set_error("ptu: truncated file"); return HU_ERR_IO; }
+	int roots = 0;
+	for(uint64_t i = 0; i < n; ++i) if(t.parent[i] < 0) roots++;
+	if(roots != 1 || t.parent[t.root] >= 0) { hu_set_error("ptu: tree is not rooted at a single node"); return HU_ERR_IO; }
+	/* annotation classes: equal strings share an id (calcQValues groups by getTaxonName()) */
+	std::map<std::string, int32_t> cls;
+	t.annoId.resize(n);
+	for(uint64_t i = 0; i < n; ++i) {
+		auto it = cls.find(t.annos[i]);
+		if(it == cls.end()) it = cls.insert({t.annos[i], (int32_t) cls.size()}).first;
+		t.annoId[i] = it->second;
+	}
+	return HU_OK;
+}

@@ -1,0 +1,371 @@
+// HIP kernels of the banded-HMM alignment stage (gfx950, wave64).  Included by hu_engine.hip.
+//
+//   k_viterbi      prepareViterbiScores + calcViterbiScores (banded or full) + S + minCoeff +
+//                  buildViterbiTrace   (src/BandedHMMP7.cpp:735-892, 943-1006)
+//   k_align_rows   buildGlobalAlign + getPaddingSeq (src/BandedHMMP7.cpp:1008-1081, 1137-1186)
+//   k_merge_rows   PE orientation check + HmmAlignment::merge (src/hmmufotu.cpp:629-639,
+//                  src/BandedHMMP7.cpp:1188-1213)
+//   k_encode_rows  DigitalSeq(abc, id, aln.align) (src/DigitalSeq.cpp:41-48) + bit-planes of the
+//                  aligned read restricted to [csStart-1, csEnd-1] for the seed scan
+//
+// The DP is evaluated phase by phase exactly as the reference orders it (upstream rectangle,
+// seed band, ..., downstream rectangle without the B-entry term), each phase as an
+// anti-diagonal wavefront: M(i,j) needs (i-1,j-1), I(i,j) needs (i-1,j), D(i,j) needs (i,j-1),
+// so every cell of one anti-diagonal is independent and every value is produced by the same
+// additions and minima as the reference's j-major/i-minor loop => bit-identical costs.
+// All three matrices of every computed cell are kept (per-read scratch in HBM) because the
+// reference's traceback re-evaluates the candidate sums on the FINAL matrices.
+#pragma once
+#include "hu_common.h"
+
+struct HuVitOut { int32_t alnStart, alnEnd, alnFrom, alnTo, traceLen, status; double minScore; };
+
+__device__ inline bool reg_contains(const HuRegion& g, int i, int j) {
+	if(j < g.j0 || j > g.j1 || i < g.i0 || i > g.i1) return false;
+	if(g.band) { int dist = (i - g.from) - (j - g.start); if(!(dist <= g.nIns && dist >= -g.nDel)) return false; }
+	return true;
+}
+
+struct VitCtx {
+	const HuReadDesc* rd;
+	const double* scr;   /* the read's scratch: 3 doubles per cell */
+	double tNN, tNB;
+};
+
+/* value of (M, I, D)(i, j) as the reference's dense matrices would hold it, looking at the
+ * first `upto` phases (later phases overwrite earlier ones) */
+__device__ inline void vit_lookup(const VitCtx& c, int upto, int i, int j, double& m, double& ii, double& d) {
+	const HuReadDesc& rd = *c.rd;
+	for(int r = upto - 1; r >= 0; --r) {
+		const HuRegion& g = rd.reg[r];
+		if(reg_contains(g, i, j)) {
+			const int64_t idx = (g.off + (int64_t)(j - g.j0) * (g.i1 - g.i0 + 1) + (i - g.i0)) * 3;
+			m = c.scr[idx]; ii = c.scr[idx + 1]; d = c.scr[idx + 2];
+			return;
+		}
+	}
+	if(j == 0 && i >= 1) { /* B state column (src/BandedHMMP7.cpp:735-746) */
+		double v = (i == 1) ? 0.0 : __dmul_rn(c.tNN, (double)(i - 1));
+		v = __dadd_rn(v, c.tNB);
+		m = v; ii = v; d = INFINITY;
+		return;
+	}
+	m = ii = d = INFINITY;
+}
+__device__ inline double vit_bcol(const VitCtx& c, int i) {
+	double v = (i == 1) ? 0.0 : __dmul_rn(c.tNN, (double)(i - 1));
+	return __dadd_rn(v, c.tNB);
+}
+
+__constant__ int8_t c_sym_map[128];
+
+__global__ __launch_bounds__(64) void k_viterbi(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		double* __restrict__ scratch, char* __restrict__ traces, double tNN, double tNB, double tEC, double tCC,
+		HuVitOut* __restrict__ outs) {
+	const int s = blockIdx.x, lane = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const int L = rd.len, K = db.K;
+	if(rd.nRegions <= 0) { if(lane == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	const char* __restrict__ x = bases + rd.baseOff;
+	double* scr = scratch + rd.scratchOff * 3;
+	VitCtx ctx = { &rd, scr, tNN, tNB };
+	for(int r = 0; r < rd.nRegions; ++r) {
+		const HuRegion g = rd.reg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		for(int dg = 0; dg <= ni + nj - 2; ++dg) {
+			const int lo = dg - (nj - 1) > 0 ? dg - (nj - 1) : 0, hi = dg < ni - 1 ? dg : ni - 1;
+			for(int q = lo + lane; q <= hi; q += 64) {
+				const int i = g.i0 + q, j = g.j0 + dg - q;
+				if(g.band) { int dist = (i - g.from) - (j - g.start); if(!(dist <= g.nIns && dist >= -g.nDel)) continue; }
+				const int b = c_sym_map[(int) x[i - 1] & 127];
+				double mD, iD, dD, mU, iU, dU, mL, iL, dL;
+				vit_lookup(ctx, r + 1, i - 1, j - 1, mD, iD, dD);
+				vit_lookup(ctx, r + 1, i - 1, j, mU, iU, dU);
+				vit_lookup(ctx, r + 1, i, j - 1, mL, iL, dL);
+				const double* tp = db.T + (size_t)(j - 1) * 8;
+				const double* tj = db.T + (size_t) j * 8;
+				double best = fmin(mD + tp[0], fmin(iD + tp[3], dD + tp[5]));
+				if(g.withB) best = fmin(vit_bcol(ctx, i) + db.entryC[j], best);
+				const double M = db.EM[(size_t) j * 4 + b] + best;
+				const double I = db.EI[(size_t) j * 4 + b] + fmin(mU + tj[1], iU + tj[4]);
+				/* D1 and DK are retracted: no phase ever assigns them, they stay +inf */
+				const double D = (j > 1 && j < K) ? fmin(mL + tp[2], dL + tp[6]) : INFINITY;
+				const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + q) * 3;
+				scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+			}
+			__syncthreads();
+		}
+	}
+	/* S = M + exit (+ I(.,K) + t_K(I,M) in the extra column) + E->C + C->C loops; minCoeff with
+	 * Eigen's column-major first-minimum rule; a cell counts in the LAST phase that covers it */
+	double bestS = INFINITY; int bestCol = 0x7fffffff, bestRow = 0x7fffffff;
+	for(int r = 0; r < rd.nRegions; ++r) {
+		const HuRegion g = rd.reg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		const int64_t ncell = (int64_t) ni * nj;
+		for(int64_t cidx = lane; cidx < ncell; cidx += 64) {
+			const int i = g.i0 + (int)(cidx % ni), j = g.j0 + (int)(cidx / ni);
+			if(!reg_contains(g, i, j)) continue;
+			bool later = false;
+			for(int r2 = r + 1; r2 < rd.nRegions; ++r2) if(reg_contains(rd.reg[r2], i, j)) later = true;
+			if(later) continue;
+			const int64_t idx = (g.off + cidx) * 3;
+			const double cc = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+			double sv = __dadd_rn(__dadd_rn(scr[idx], db.exitC[j]), tEC);
+			if(i < L) sv = __dadd_rn(sv, cc);
+			if(sv < bestS || (sv == bestS && (j < bestCol || (j == bestCol && i < bestRow)))) { bestS = sv; bestCol = j; bestRow = i; }
+			if(j == K) {
+				double s2 = __dadd_rn(__dadd_rn(scr[idx + 1], db.T[(size_t) K * 8 + 3]), tEC);
+				if(i < L) s2 = __dadd_rn(s2, cc);
+				if(s2 < bestS || (s2 == bestS && (K + 1 < bestCol || (K + 1 == bestCol && i < bestRow)))) { bestS = s2; bestCol = K + 1; bestRow = i; }
+			}
+		}
+	}
+	for(int m = 32; m > 0; m >>= 1) {
+		const double os = __shfl_xor(bestS, m); const int oc = __shfl_xor(bestCol, m), orow = __shfl_xor(bestRow, m);
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	if(lane != 0) return;
+	HuVitOut o;
+	o.minScore = bestS; o.traceLen = 0; o.alnStart = o.alnEnd = o.alnFrom = o.alnTo = 0;
+	if(!(bestS < INFINITY)) { o.status = HU_READ_NEEDS_FULL; outs[s] = o; return; }
+	/* buildViterbiTrace (src/BandedHMMP7.cpp:943-1006) */
+	char* tr = traces + rd.traceOff;
+	int n = 0;
+	char st = bestCol <= K ? 'M' : 'I';
+	int i = bestRow, j = bestCol <= K ? bestCol : K;
+	o.alnEnd = j; o.alnTo = bestRow;
+	const int R = rd.nRegions;
+	tr[n++] = 'E';
+	while(i >= 1 && j >= 0) {
+		tr[n++] = st;
+		if(st == 'M') {
+			double mD, iD, dD;
+			vit_lookup(ctx, R, i - 1, j - 1, mD, iD, dD);
+			const double* tp = db.T + (size_t)(j - 1) * 8;
+			const double pB = vit_bcol(ctx, i) + db.entryC[j];
+			double mn = INFINITY; char nx = 'B';
+			if(j > 1) {
+				const double pM = mD + tp[0], pI = iD + tp[3], pD = dD + tp[5];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pM < mn) { nx = 'M'; mn = pM; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+				if(pD < mn) { nx = 'D'; mn = pD; }
+			}
+			else {
+				const double pI = iD + tp[3];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			st = nx; i--; j--;
+		}
+		else if(st == 'I') {
+			double mU, iU, dU;
+			vit_lookup(ctx, R, i - 1, j, mU, iU, dU);
+			const double* tj = db.T + (size_t) j * 8;
+			double mn = INFINITY; char nx;
+			if(j > 0) {
+				nx = 'M';
+				const double pM = mU + tj[1], pI = iU + tj[4];
+				if(pM < mn) { nx = 'M'; mn = pM; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			else {
+				nx = 'B';
+				const double pB = vit_bcol(ctx, i) + db.T[1], pI = iU + tj[4];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			st = nx; i--;
+		}
+		else if(st == 'D') {
+			double mL, iL, dL;
+			vit_lookup(ctx, R, i, j - 1, mL, iL, dL);
+			const double* tp = db.T + (size_t)(j - 1) * 8;
+			double mn = INFINITY; char nx = 'M';
+			const double pM = mL + tp[2], pD = dL + tp[6];
+			if(pM < mn) { nx = 'M'; mn = pM; }
+			if(pD < mn) { nx = 'D'; mn = pD; }
+			st = nx; j--;
+		}
+		else break;
+	}
+	o.alnStart = j + 1; o.alnFrom = i + 1;
+	if(tr[n - 1] != 'B') tr[n++] = 'B';
+	for(int a = 0, b = n - 1; a < b; ++a, --b) { char t = tr[a]; tr[a] = tr[b]; tr[b] = t; }
+	o.traceLen = n;
+	o.status = (o.alnStart > 0 && o.alnFrom > 0) ? HU_READ_OK : HU_READ_INVALID;
+	outs[s] = o;
+}
+
+/* getPaddingSeq(..., JUSTIFIED) of a non-empty insert (src/BandedHMMP7.cpp:1168-1178) */
+__device__ inline void pad_justified(char* dst, int L, const char* ins, int n) {
+	if(n >= L) {
+		const int h0 = L / 2, h1 = L - L / 2; /* floor, ceil */
+		for(int a = 0; a < h0; ++a) dst[a] = (char)(ins[a] | 0x20);
+		for(int a = 0; a < h1; ++a) dst[h0 + a] = (char)(ins[n - h1 + a] | 0x20);
+	}
+	else { /* reference quirk: the tail repeats the FIRST ceil(n/2) characters */
+		const int h0 = n / 2, h1 = n - n / 2;
+		for(int a = 0; a < h0; ++a) dst[a] = (char)(ins[a] | 0x20);
+		for(int a = 0; a < L - n; ++a) dst[h0 + a] = '-';
+		for(int a = 0; a < h1; ++a) dst[h0 + L - n + a] = (char)(ins[a] | 0x20);
+	}
+}
+
+struct HuAlnDev { int32_t seqStart, seqEnd, hmmStart, hmmEnd, csStart, csEnd, status, usedFull; double cost; };
+
+/* one wave per sequence: row = '.' * csLen, then lane 0 replays the trace */
+__global__ __launch_bounds__(64) void k_align_rows(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		const char* __restrict__ traces, const HuVitOut* __restrict__ vit, char* __restrict__ rows, HuAlnDev* __restrict__ alns) {
+	const int s = blockIdx.x, lane = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const HuVitOut v = vit[s];
+	char* row = rows + (size_t) s * db.csLen;
+	for(int c = lane; c < db.csLen; c += 64) row[c] = '.';
+	__syncthreads();
+	if(lane != 0) return;
+	HuAlnDev a;
+	a.status = v.status; a.cost = v.minScore; a.usedFull = 0;
+	a.seqStart = v.alnFrom; a.seqEnd = v.alnTo; a.hmmStart = v.alnStart; a.hmmEnd = v.alnEnd;
+	a.csStart = a.csEnd = 0;
+	if(v.status != HU_READ_OK) { alns[s] = a; return; }
+	const char* __restrict__ x = bases + rd.baseOff;
+	const char* __restrict__ tr = traces + rd.traceOff;
+	const int Lr = rd.len, L = db.csLen;
+	const int csStart = db.p2cs[v.alnStart], csEnd = db.p2cs[v.alnEnd];
+	a.csStart = csStart; a.csEnd = csEnd;
+	int pos = 0, j = 0, k = 0, insFrom = 0, insLen = 0;
+	for(int t = 0; t < v.traceLen; ++t) {
+		const char st = tr[t];
+		if(st == 'B') {
+			const int nN = v.alnFrom - 1, room = csStart - 1;
+			const int cnt = nN < room ? nN : room;
+			for(int q = 0; q < cnt; ++q) row[room - cnt + q] = x[nN - cnt + q];
+			pos = room; j = v.alnFrom; k = v.alnStart;
+		}
+		else if(st == 'M') {
+			if(k > 1 && t > 1) {
+				const int gap = db.p2cs[k] - db.p2cs[k - 1] - 1;
+				if(gap > 0) {
+					if(insLen > 0) pad_justified(row + pos, gap, x + insFrom, insLen);
+					else for(int q = 0; q < gap; ++q) row[pos + q] = '-';
+					pos += gap;
+				}
+			}
+			insLen = 0;
+			row[pos++] = x[j - 1];
+			j++; k++;
+		}
+		else if(st == 'I') {
+			insFrom = j - 1; insLen = 0;
+			while(t < v.traceLen && tr[t] == 'I') { insLen++; j++; t++; }
+			t--;
+		}
+		else if(st == 'D') {
+			if(k > 1) {
+				const int gap = db.p2cs[k] - db.p2cs[k - 1] - 1;
+				for(int q = 0; q < gap; ++q) row[pos + q] = '-';
+				if(gap > 0) pos += gap;
+			}
+			row[pos++] = '-';
+			k++;
+		}
+		else if(st == 'E') {
+			const int nC = Lr - v.alnTo > 0 ? Lr - v.alnTo : 0, room = L - csEnd;
+			const int cnt = nC < room ? nC : room;
+			for(int q = 0; q < cnt; ++q) row[pos + q] = x[v.alnTo + q];
+		}
+	}
+	alns[s] = a;
+}
+
+/* PE: row r <- merge(row r, row n + r) unless the orientation check fails */
+__global__ __launch_bounds__(256) void k_merge_rows(HuDbDev db, int n, int ignoreOrient, char* __restrict__ rows, HuAlnDev* __restrict__ alns) {
+	const int r = blockIdx.x;
+	__shared__ int ok;
+	HuAlnDev a = alns[r];
+	const HuAlnDev b = alns[n + r];
+	if(threadIdx.x == 0) {
+		int st = a.status;
+		if(a.status == HU_READ_OK) {
+			if(b.status != HU_READ_OK) st = HU_READ_INVALID;
+			else if(!ignoreOrient && !(a.csStart <= b.csStart && a.csEnd <= b.csEnd)) st = HU_READ_CHIMERA;
+		}
+		ok = (st == HU_READ_OK);
+		if(ok) {
+			if(b.seqStart < a.seqStart) a.seqStart = b.seqStart;
+			if(b.seqEnd > a.seqEnd) a.seqEnd = b.seqEnd;
+			if(b.hmmStart < a.hmmStart) a.hmmStart = b.hmmStart;
+			if(b.hmmEnd > a.hmmEnd) a.hmmEnd = b.hmmEnd;
+			if(b.csStart < a.csStart) a.csStart = b.csStart;
+			if(b.csEnd > a.csEnd) a.csEnd = b.csEnd;
+			a.cost = a.cost + b.cost;
+			a.usedFull |= b.usedFull;
+		}
+		a.status = st;
+		alns[r] = a;
+	}
+	__syncthreads();
+	if(!ok) return;
+	char* ra = rows + (size_t) r * db.csLen;
+	const char* rb = rows + (size_t)(n + r) * db.csLen;
+	for(int c = threadIdx.x; c < db.csLen; c += 256) if(ra[c] == '.' && rb[c] != '.') ra[c] = rb[c];
+}
+
+/* DigitalSeq codes of the aligned row + region + bit-planes for the seed scan.
+ * rp layout: rp[((tile*WQ + q) * T + t) * 16 + p*4 + w], zero outside [csStart-1, csEnd-1]. */
+__global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, const HuAlnDev* __restrict__ alns,
+		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp) {
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const HuAlnDev a = alns[r];
+	const char* row = rows + (size_t) r * db.csLen;
+	int8_t* cd = codes + (size_t) r * db.csLen;
+	const bool ok = a.status == HU_READ_OK;
+	const int start = ok ? a.csStart - 1 : 0, end = ok ? a.csEnd - 1 : -1;
+	if(lane == 0) { rstart[r] = start; rend[r] = end; }
+	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
+	for(int base = 0; base < db.WQ * 128; base += 64) {
+		const int c = base + lane;
+		int8_t code = -2;
+		if(c < db.csLen) {
+			char ch = row[c];
+			if(ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+			code = c_sym_map[(int) ch & 127];
+			cd[c] = code;
+		}
+		const bool in = c >= start && c <= end && code >= 0;
+		const unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
+		if(lane == 0) {
+			const int q = base / 128, w = (base % 128) / 32;
+			uint32_t* dst = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
+			dst[0 + w] = (uint32_t) b0; dst[0 + w + 1] = (uint32_t)(b0 >> 32);
+			dst[4 + w] = (uint32_t) b1; dst[4 + w + 1] = (uint32_t)(b1 >> 32);
+			dst[8 + w] = (uint32_t) bv; dst[8 + w + 1] = (uint32_t)(bv >> 32);
+		}
+	}
+}
+
+/* same, when the caller supplies DigitalSeq codes directly (hu_batch_set_aligned) */
+__global__ __launch_bounds__(64) void k_planes_from_codes(HuDbDev db, const int8_t* __restrict__ codes,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, uint32_t* __restrict__ rp) {
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int8_t* cd = codes + (size_t) r * db.csLen;
+	const int start = rstart[r], end = rend[r];
+	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
+	for(int base = 0; base < db.WQ * 128; base += 64) {
+		const int c = base + lane;
+		const int8_t code = c < db.csLen ? cd[c] : (int8_t) -2;
+		const bool in = c >= start && c <= end && code >= 0;
+		const unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
+		if(lane == 0) {
+			const int q = base / 128, w = (base % 128) / 32;
+			uint32_t* dst = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
+			dst[0 + w] = (uint32_t) b0; dst[0 + w + 1] = (uint32_t)(b0 >> 32);
+			dst[4 + w] = (uint32_t) b1; dst[4 + w + 1] = (uint32_t)(b1 >> 32);
+			dst[8 + w] = (uint32_t) bv; dst[8 + w + 1] = (uint32_t)(bv >> 32);
+		}
+	}
+}

@@ -1,0 +1,422 @@
+// HIP kernels of the Seed-Estimate-Place stage (gfx950, wave64).  Included by hu_engine.hip.
+//
+//   k_seed_pdist  getSeed's node scan: SeqUtils::pDist of the read against every node sequence
+//                 (src/HmmUFOtu_main.cpp:131-137, src/SeqUtils.cpp:37-54)
+//   k_seed_topk   std::sort + truncation to max_nseed (src/HmmUFOtu_main.cpp:139,
+//                 src/hmmufotu.cpp:646-647) as an exact (dist, node id) selection
+//   k_estimate    PTUnrooted::estimateSeq (src/PhyloTreeUnrooted.cpp:849-877)
+//   k_place       PTUnrooted::placeSeq + joint optimizeBranchLength
+//                 (src/PhyloTreeUnrooted.cpp:879-954, 800-847, 749-798)
+#pragma once
+#include "hu_common.h"
+
+#define HU_TOPK_BINS 4097   /* bins 0..4096 = floor(4096 d/N); bin 4097 = N == 0 */
+#define HU_TOPK_CAP 4096
+
+/* ------------------------------------------------------------------------------------------
+ * Node sequences live in HBM as three bit-planes per 32 sites (b0, b1 = the 2-bit base code,
+ * v = "is a base"), 4 words (128 sites) per uint4, node index fastest:
+ *     planes[(q*3 + p) * nNodesPad + node]          q = site / 128
+ * so that one wave reads 64 consecutive nodes x 16 B = 1 KiB per plane per quad, coalesced.
+ * A lane owns one node and HU_READ_TILE reads; the reads' planes are wave-uniform and come in
+ * through the scalar cache:   rp[((tile*WQ + q) * T + t) * 16 + p*4 + w].
+ * Per (node, read, 32 sites): 2 xor + or + 2 and + 2 popcount-accumulate.
+ * Grid: x = read tile (fastest: consecutive workgroups re-use one node block from L2),
+ *       y = node block of 256. */
+template<int T>
+__global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* __restrict__ rp,
+		const int2* __restrict__ tileQ, uint32_t* __restrict__ pairs, int nReads) {
+	const int tile = blockIdx.x;
+	const int node = blockIdx.y * 256 + threadIdx.x;
+	const int2 qr = tileQ[tile];
+	uint32_t d[T], N[T];
+#pragma unroll
+	for(int t = 0; t < T; ++t) { d[t] = 0; N[t] = 0; }
+	const size_t np = (size_t) db.nNodesPad;
+	for(int q = qr.x; q <= qr.y; ++q) {
+		const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node];
+		const uint4 n1 = db.planes[((size_t) q * 3 + 1) * np + node];
+		const uint4 nv = db.planes[((size_t) q * 3 + 2) * np + node];
+		const uint32_t* __restrict__ r = rp + ((size_t) tile * db.WQ + q) * T * 16;
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const uint32_t* rt = r + t * 16;
+			uint32_t m, x;
+			m = nv.x & rt[8];  x = ((n0.x ^ rt[0]) | (n1.x ^ rt[4])) & m; d[t] += __popc(x); N[t] += __popc(m);
+			m = nv.y & rt[9];  x = ((n0.y ^ rt[1]) | (n1.y ^ rt[5])) & m; d[t] += __popc(x); N[t] += __popc(m);
+			m = nv.z & rt[10]; x = ((n0.z ^ rt[2]) | (n1.z ^ rt[6])) & m; d[t] += __popc(x); N[t] += __popc(m);
+			m = nv.w & rt[11]; x = ((n0.w ^ rt[3]) | (n1.w ^ rt[7])) & m; d[t] += __popc(x); N[t] += __popc(m);
+		}
+	}
+#pragma unroll
+	for(int t = 0; t < T; ++t) {
+		const int read = tile * T + t;
+		if(read < nReads) pairs[(size_t) read * np + node] = (d[t] << 16) | N[t];
+	}
+}
+
+/* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
+ * fractions differ by more than 2^-32, so floor(d * 2^39 / N) separates them; N == 0 (the
+ * reference's 0/0 = NaN) sorts last.  Ties are broken by node id in the low 24 bits. */
+__device__ inline unsigned long long seed_key(uint32_t d, uint32_t N, uint32_t node) {
+	unsigned long long q = N ? (((unsigned long long) d) << 39) / N : ((1ull << 40) - 1);
+	return (q << 24) | node;
+}
+
+__global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* __restrict__ pairs, double maxHeight,
+		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN) {
+	__shared__ uint32_t hist[HU_TOPK_BINS + 1];
+	__shared__ uint32_t chunk[256];
+	__shared__ unsigned long long keys[HU_TOPK_CAP];
+	__shared__ uint32_t sh[4];
+	const int read = blockIdx.x, tid = threadIdx.x;
+	const uint32_t* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
+	for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
+	__syncthreads();
+	for(int node = tid; node < db.nNodes; node += 256) {
+		if(node == db.root || !(db.height[node] <= maxHeight)) continue;
+		uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+		uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
+		atomicAdd(&hist[bin], 1u);
+	}
+	__syncthreads();
+	/* threshold bin: first bin whose cumulative count reaches the number of seeds wanted */
+	const int per = (HU_TOPK_BINS + 1 + 255) / 256;
+	{
+		uint32_t s = 0;
+		for(int i = tid * per; i < (tid + 1) * per && i <= HU_TOPK_BINS; ++i) s += hist[i];
+		chunk[tid] = s;
+	}
+	__syncthreads();
+	if(tid == 0) {
+		uint32_t total = 0;
+		for(int i = 0; i < 256; ++i) total += chunk[i];
+		uint32_t need = total < (uint32_t) maxNSeed ? total : (uint32_t) maxNSeed;
+		uint32_t cum = 0; int c = 0;
+		while(c < 255 && cum + chunk[c] < need) { cum += chunk[c]; ++c; }
+		int b = c * per;
+		while(b < HU_TOPK_BINS && cum + hist[b] < need) { cum += hist[b]; ++b; }
+		sh[0] = need; sh[1] = (uint32_t) b; sh[2] = cum + hist[b]; sh[3] = 0;
+	}
+	__syncthreads();
+	const uint32_t need = sh[0], thr = sh[1], cntLE = sh[2];
+	if(need == 0) { if(tid == 0) seedCnt[read] = 0; return; }
+	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
+	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
+	if(cntLE <= HU_TOPK_CAP) {
+		for(int node = tid; node < db.nNodes; node += 256) {
+			if(node == db.root || !(db.height[node] <= maxHeight)) continue;
+			uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+			uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
+			if(bin <= thr) { uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
+		}
+		__syncthreads();
+		uint32_t n2 = 1;
+		while(n2 < cntLE) n2 <<= 1;
+		for(uint32_t i = cntLE + tid; i < n2; i += 256) keys[i] = ~0ull;
+		__syncthreads();
+		for(uint32_t k = 2; k <= n2; k <<= 1)
+			for(uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for(uint32_t i = tid; i < n2; i += 256) {
+					uint32_t l = i ^ j;
+					if(l > i) {
+						unsigned long long a = keys[i], b = keys[l];
+						bool up = (i & k) == 0;
+						if((a > b) == up) { keys[i] = b; keys[l] = a; }
+					}
+				}
+				__syncthreads();
+			}
+		for(uint32_t i = tid; i < need; i += 256) {
+			uint32_t node = (uint32_t)(keys[i] & 0xffffffu);
+			outId[i] = (int32_t) node; outDN[i] = pr[node];
+		}
+	}
+	else { /* degenerate tie mass: one exact minimum per pass, bounded by max_nseed passes */
+		unsigned long long last = 0; bool first = true;
+		for(uint32_t s = 0; s < need; ++s) {
+			unsigned long long best = ~0ull;
+			for(int node = tid; node < db.nNodes; node += 256) {
+				if(node == db.root || !(db.height[node] <= maxHeight)) continue;
+				uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+				uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
+				if(bin > thr) continue;
+				unsigned long long k = seed_key(d, N, (uint32_t) node);
+				if((first || k > last) && k < best) best = k;
+			}
+			for(int m = 32; m > 0; m >>= 1) { unsigned long long o = __shfl_xor(best, m); best = o < best ? o : best; }
+			if((tid & 63) == 0) keys[tid >> 6] = best;
+			__syncthreads();
+			best = keys[0];
+			for(int wv = 1; wv < 4; ++wv) best = keys[wv] < best ? keys[wv] : best;
+			__syncthreads();
+			last = best; first = false;
+			if(tid == 0) { uint32_t node = (uint32_t)(best & 0xffffffu); outId[s] = (int32_t) node; outDN[s] = pr[node]; }
+		}
+	}
+	if(tid == 0) seedCnt[read] = (int32_t) need;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+__device__ inline double wave_sum(double x) {
+	for(int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m);
+	return x; /* butterfly: bitwise identical in every lane */
+}
+__device__ inline double max4d(const double* v) { return fmax(fmax(v[0], v[1]), fmax(v[2], v[3])); }
+__device__ inline int argmax4d(const double* v) { /* Eigen maxCoeff(&i): first strict maximum */
+	int b = 0;
+	if(v[1] > v[b]) b = 1;
+	if(v[2] > v[b]) b = 2;
+	if(v[3] > v[b]) b = 3;
+	return b;
+}
+__device__ inline double sel4(const double* v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+
+/* e = exp(M - max M), returns max M (the log scale); all -inf -> zeros */
+__device__ inline double lin_msg(const double* M, double* e) {
+	double mx = max4d(M);
+	if(mx == -INFINITY) { e[0] = e[1] = e[2] = e[3] = 0; return mx; }
+#pragma unroll
+	for(int i = 0; i < 4; ++i) e[i] = exp(M[i] - mx);
+	return mx;
+}
+/* a = U1 . e  (message in the eigenbasis) */
+__device__ inline void to_eig(const HuModelDev& m, const double* e, double* a) {
+#pragma unroll
+	for(int k = 0; k < 4; ++k) a[k] = (m.U1[k*4+0] * e[0] + m.U1[k*4+1] * e[1]) + (m.U1[k*4+2] * e[2] + m.U1[k*4+3] * e[3]);
+}
+/* c = P(t) . e = U . (E (.) a), E = exp(lam t); clamped at 0 against spectral cancellation */
+__device__ inline void conv_eig(const HuModelDev& m, const double* E, const double* a, double* c) {
+	double s[4];
+#pragma unroll
+	for(int k = 0; k < 4; ++k) s[k] = E[k] * a[k];
+#pragma unroll
+	for(int i = 0; i < 4; ++i)
+		c[i] = fmax((m.U[i*4+0] * s[0] + m.U[i*4+1] * s[1]) + (m.U[i*4+2] * s[2] + m.U[i*4+3] * s[3]), 0.0);
+}
+__device__ inline void load4(const double* p, double* v) {
+	const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+struct HuEstOut { double ratio, wnr, loglik; };
+
+/* one wave per (read, seed); lanes stride the sites of [start, end] */
+__global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
+		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
+		int weighted, HuEstOut* __restrict__ out) {
+	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, lane = threadIdx.x;
+	if(s >= seedCnt[read]) return;
+	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
+	const int v = db.parent[u];
+	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
+	const uint32_t pv = pairs[(size_t) read * db.nNodesPad + v];
+	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
+	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
+	double ratio = cDist / (cDist + pDist);
+	if(isnan(ratio)) ratio = 0.5;
+	const double w0 = db.blen[u];
+	const double wur = w0 * ratio, wvr = w0 - wur;
+	double Eu[4], Ev[4];
+#pragma unroll
+	for(int k = 0; k < 4; ++k) { Eu[k] = exp(mdl.lam[k] * wur); Ev[k] = exp(mdl.lam[k] * wvr); }
+	const int start = rstart[read], end = rend[read];
+	const int8_t* __restrict__ cd = codes + (size_t) read * db.csLen;
+	const int64_t mOff = ((int64_t) u * db.winLen - db.winStart) * 4; /* + 4 j, j >= winStart */
+	const double* __restrict__ Ub = db.up;
+	const double* __restrict__ Vb = db.down;
+	const int piMax = argmax4d(mdl.logpi);
+	double piw[4]; /* inferWeight(log pi) */
+	{ double mx = max4d(mdl.logpi), sm; for(int i = 0; i < 4; ++i) piw[i] = exp(mdl.logpi[i] - mx); sm = (piw[0] + piw[2]) + (piw[1] + piw[3]); for(int i = 0; i < 4; ++i) piw[i] /= sm; }
+
+	auto siteR = [&](int j, double* R) {
+		double M[4], e[4], a[4], c[4];
+		load4(Ub + (mOff + (int64_t) j * 4), M);
+		double ls = lin_msg(M, e);
+		if(wur == 0) { for(int i = 0; i < 4; ++i) c[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Eu, a, c); }
+		for(int i = 0; i < 4; ++i) R[i] = log(c[i]) + ls;
+		load4(Vb + (mOff + (int64_t) j * 4), M);
+		ls = lin_msg(M, e);
+		if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Ev, a, c); }
+		for(int i = 0; i < 4; ++i) R[i] += log(c[i]) + ls;
+	};
+	double dsum = 0, nsum = 0;
+	for(int j = start + lane; j <= end; j += 64) {
+		double R[4];
+		siteR(j, R);
+		const int b = cd[j];
+		const int b1 = argmax4d(R), b2 = b >= 0 ? b : piMax;
+		if(!weighted) { if(b1 != b2) dsum += 1; }
+		else {
+			double mx = max4d(R), w[4];
+			for(int i = 0; i < 4; ++i) w[i] = exp(R[i] - mx);
+			double w1 = sel4(w, b1) / ((w[0] + w[2]) + (w[1] + w[3]));
+			double w2 = b >= 0 ? 1.0 : piw[b2];
+			if(b1 != b2) dsum += w1 * w2;
+			nsum += w1 * w2;
+		}
+	}
+	dsum = wave_sum(dsum);
+	double wnr;
+	if(!weighted) wnr = dsum / (double)(end - start + 1);
+	else { nsum = wave_sum(nsum); wnr = dsum / nsum; }
+	/* N*P(wnr): column b of P(wnr) for a base, P(wnr).pi for a gap */
+	double En[4], Ppi[4];
+#pragma unroll
+	for(int k = 0; k < 4; ++k) En[k] = exp(mdl.lam[k] * wnr);
+	{ double a[4]; to_eig(mdl, mdl.pi, a); if(wnr == 0) { for(int i = 0; i < 4; ++i) Ppi[i] = mdl.pi[i]; } else conv_eig(mdl, En, a, Ppi); }
+	double ll = 0;
+	for(int j = start + lane; j <= end; j += 64) {
+		double R[4], c[4];
+		siteR(j, R);
+		const int b = cd[j];
+		if(b >= 0) {
+			if(wnr == 0) { for(int i = 0; i < 4; ++i) c[i] = i == b ? 1.0 : 0.0; }
+			else { double a[4]; for(int k = 0; k < 4; ++k) a[k] = mdl.U1[k*4+b]; conv_eig(mdl, En, a, c); }
+		}
+		else for(int i = 0; i < 4; ++i) c[i] = Ppi[i];
+		double X[4];
+		for(int i = 0; i < 4; ++i) X[i] = R[i] + log(c[i]);
+		double mx = max4d(X);
+		if(mx == -INFINITY) { ll += -INFINITY; continue; }
+		double e[4];
+		for(int i = 0; i < 4; ++i) e[i] = exp(X[i] - mx);
+		ll += log((mdl.pi[0] * e[0] + mdl.pi[2] * e[2]) + (mdl.pi[1] * e[1] + mdl.pi[3] * e[3])) + mx;
+	}
+	ll = wave_sum(ll);
+	if(lane == 0) { HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = ll; out[(size_t) read * HU_MAX_SEEDS + s] = o; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+struct HuCand { int32_t read, node; double ratio0, wnr0; };
+struct HuPlaceOut { double wnr, wur; int32_t iters, pad; };
+
+/* Felsenstein's EM for one branch (src/PhyloTreeUnrooted.cpp:749-798) on the per-site ratios
+ * rho_j = A_j / B_j kept in LDS: p <- mean_j p0 / (rho_j q0 + p0); NaN sites are skipped. */
+__device__ inline double em_branch(const double* rho, int n, double w0, double maxL, int lane) {
+	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0;
+	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
+		double s = 0, c = 0;
+		for(int j = lane; j < n; j += 64) {
+			double r = rho[j];
+			if(!isnan(r)) { s += p0 / (r * q0 + p0); c += 1; }
+		}
+		s = wave_sum(s); c = wave_sum(c);
+		p = s / c; q = 1 - p;
+		if(fabs(log(q) - log(q0)) < HU_BRANCH_EPS) break;
+		p0 = p; q0 = q;
+	}
+	double w = -log(q);
+	if(w > maxL) w = maxL;
+	return w;
+}
+
+/* One wave per candidate placement.  Messages stay in linear space, scaled by their own
+ * maximum; P(t r_k) acts in the eigenbasis so a category costs 4 mul + 16 fma per message.
+ * The r->v message of the reference's outer iteration is never read by anything and is not
+ * evaluated.  LDS: rho[n] + E tables + leaf-conv table. */
+__global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
+		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out) {
+	extern __shared__ double lds[];
+	const int lane = threadIdx.x;
+	const HuCand cd = cands[blockIdx.x];
+	const int read = cd.read, u = cd.node;
+	const int start = rstart[read], end = rend[read], n = end - start + 1;
+	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
+	double* Etab = lds;                    /* [3][Kc][4]: u, v, n branches          */
+	double* Ltab = Etab + 3 * HU_MAX_DGK * 4; /* [Kc][5][4] leaf convolutions          */
+	double* rho = Ltab + HU_MAX_DGK * 5 * 4;
+	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;
+	const int64_t mOff = ((int64_t) u * db.winLen + (start - db.winStart)) * 4;
+	const double* __restrict__ Ub = db.up + mOff;
+	const double* __restrict__ Vb = db.down + mOff;
+	const double w0 = db.blen[u];
+	double lenUR = w0 * cd.ratio0, lenVR = w0 * (1 - cd.ratio0), lenNR = cd.wnr0;
+	double wur0 = lenUR, wnr0 = lenNR;
+	const double w0j = lenUR + lenVR;
+	double wur = wur0, wnr = wnr0;
+	double pi2 = 0;
+	for(int i = 0; i < 4; ++i) pi2 += mdl.pi[i] * mdl.pi[i];
+	double api[4];
+	to_eig(mdl, mdl.pi, api);
+	int iter = 0;
+	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
+		/* E tables for the u and v branches */
+		for(int i = lane; i < Kc * 4; i += 64) {
+			double r = mdl.rate[i >> 2], l = mdl.lam[i & 3];
+			Etab[0 * HU_MAX_DGK * 4 + i] = exp(l * (lenUR * r));
+			Etab[1 * HU_MAX_DGK * 4 + i] = exp(l * (lenVR * r));
+		}
+		__syncthreads();
+		/* (i) message r->n from children u, v; EM on the n-r branch against the read's leaf message */
+		for(int j = lane; j < n; j += 64) {
+			double M[4], eU[4], eV[4], aU[4], aV[4];
+			load4(Ub + (size_t) j * 4, M); lin_msg(M, eU); to_eig(mdl, eU, aU);
+			load4(Vb + (size_t) j * 4, M); lin_msg(M, eV); to_eig(mdl, eV, aV);
+			double X[4] = {0, 0, 0, 0};
+			for(int k = 0; k < Kc; ++k) {
+				double cu[4], cv[4];
+				if(lenUR == 0) { for(int i = 0; i < 4; ++i) cu[i] = eU[i]; } else conv_eig(mdl, Etab + k * 4, aU, cu);
+				if(lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
+				for(int i = 0; i < 4; ++i) X[i] += cu[i] * cv[i];
+			}
+			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
+			const int b = cdr[j];
+			double r;
+			if(b >= 0) r = sel4(X, b) / piX;
+			else r = ((mdl.pi[0] * mdl.pi[0] * X[0] + mdl.pi[2] * mdl.pi[2] * X[2]) + (mdl.pi[1] * mdl.pi[1] * X[1] + mdl.pi[3] * mdl.pi[3] * X[3])) / (piX * pi2);
+			rho[j] = r;
+		}
+		__syncthreads();
+		wnr = em_branch(rho, n, lenNR, 1.0, lane);
+		lenNR = wnr;
+		__syncthreads();
+		/* tables for the n branch: E, and P(wnr r_k) applied to each possible leaf vector */
+		for(int i = lane; i < Kc * 4; i += 64)
+			Etab[2 * HU_MAX_DGK * 4 + i] = exp(mdl.lam[i & 3] * (lenNR * mdl.rate[i >> 2]));
+		__syncthreads();
+		for(int i = lane; i < Kc * 5; i += 64) {
+			const int k = i / 5, b = i % 5;
+			double c[4];
+			if(b < 4) {
+				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = x == b ? 1.0 : 0.0; }
+				else { double a[4]; for(int m = 0; m < 4; ++m) a[m] = mdl.U1[m*4+b]; conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, a, c); }
+			}
+			else {
+				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = mdl.pi[x]; }
+				else conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, api, c);
+			}
+			for(int x = 0; x < 4; ++x) Ltab[(k * 5 + b) * 4 + x] = c[x];
+		}
+		__syncthreads();
+		/* (ii) message r->u from children v, n; EM on the u-r branch against u's own message */
+		for(int j = lane; j < n; j += 64) {
+			double M[4], eU[4], eV[4], aV[4];
+			load4(Ub + (size_t) j * 4, M); lin_msg(M, eU);
+			load4(Vb + (size_t) j * 4, M); lin_msg(M, eV); to_eig(mdl, eV, aV);
+			const int b = cdr[j];
+			const int bi = b >= 0 ? b : 4;
+			double X[4] = {0, 0, 0, 0};
+			for(int k = 0; k < Kc; ++k) {
+				double cv[4];
+				if(lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
+				const double* cn = Ltab + (k * 5 + bi) * 4;
+				for(int i = 0; i < 4; ++i) X[i] += cv[i] * cn[i];
+			}
+			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
+			const double piU = (mdl.pi[0] * eU[0] + mdl.pi[2] * eU[2]) + (mdl.pi[1] * eU[1] + mdl.pi[3] * eU[3]);
+			const double A = (mdl.pi[0] * X[0] * eU[0] + mdl.pi[2] * X[2] * eU[2]) + (mdl.pi[1] * X[1] * eU[1] + mdl.pi[3] * X[3] * eU[3]);
+			rho[j] = A / (piX * piU);
+		}
+		__syncthreads();
+		wur = em_branch(rho, n, lenUR, w0j, lane);
+		lenUR = wur;
+		lenVR = w0j - wur;
+		__syncthreads();
+		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
+		wur0 = wur; wnr0 = wnr;
+	}
+	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = 0; out[blockIdx.x] = o; }
+}

@@ -1,0 +1,344 @@
+"""ctypes host binding of libhmmufotu_amd.so (include/hmmufotu_amd.h).
+
+The Python side mirrors the per-read surface of the reference (src/HmmUFOtu_main.h:70-113):
+`Batch.align / get_seed / estimate_seq / filter_placements / place_seq / calc_q_values`
+operate on a whole batch of reads.  There is no CPU fallback: `load_library()` raises if the
+HIP extension is missing and every compute call raises `EngineError` without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmmufotu_amd.so")
+_LIB = None
+
+HU_MAX_SEEDS = 64
+T_NAMES = ["viterbi", "align_build", "seed_pdist", "seed_topk", "estimate", "place", "_6", "_7"]
+MODE = {"global": 0, "local": 1, "ngcl": 2, "cgnl": 3}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class ProfileDesc(C.Structure):
+    _fields_ = [("K", C.c_int32), ("L", C.c_int32), ("EM", C.POINTER(C.c_double)), ("EI", C.POINTER(C.c_double)),
+                ("T", C.POINTER(C.c_double)), ("p2cs", C.POINTER(C.c_int32))]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pi", C.c_double * 4), ("par", C.c_double * 16), ("dg_k", C.c_int32),
+                ("dg_rate", C.c_double * 16)]
+
+
+class TreeDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("cs_len", C.c_int32), ("parent", C.POINTER(C.c_int32)), ("blen", C.POINTER(C.c_double)),
+                ("seq", C.POINTER(C.c_int8)), ("up", C.c_void_p), ("down", C.c_void_p), ("height", C.POINTER(C.c_double)),
+                ("anno_id", C.POINTER(C.c_int32)), ("anno_dist", C.POINTER(C.c_double)), ("win_start", C.c_int64),
+                ("win_len", C.c_int64), ("msgs_on_device", C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("align_mode", C.c_int32), ("max_nseed", C.c_int32), ("max_diff", C.c_double), ("max_height", C.c_double),
+                ("max_error", C.c_double), ("weighted", C.c_int32), ("only_ml", C.c_int32), ("prior", C.c_int32),
+                ("ignore_orient", C.c_int32)]
+
+
+class AlignRec(C.Structure):
+    _fields_ = [("seq_start", C.c_int32), ("seq_end", C.c_int32), ("hmm_start", C.c_int32), ("hmm_end", C.c_int32),
+                ("cs_start", C.c_int32), ("cs_end", C.c_int32), ("status", C.c_int32), ("used_full", C.c_int32), ("cost", C.c_double)]
+
+
+class PlaceRec(C.Structure):
+    _fields_ = [("c_node", C.c_int32), ("p_node", C.c_int32), ("a_node", C.c_int32), ("n_cand", C.c_int32),
+                ("wuv", C.c_double), ("ratio", C.c_double), ("wnr", C.c_double), ("loglik", C.c_double), ("height", C.c_double),
+                ("q_place", C.c_double), ("q_taxon", C.c_double), ("anno_dist", C.c_double), ("est_loglik", C.c_double)]
+
+
+ALIGN_DTYPE = np.dtype([("seq_start", "i4"), ("seq_end", "i4"), ("hmm_start", "i4"), ("hmm_end", "i4"), ("cs_start", "i4"),
+                        ("cs_end", "i4"), ("status", "i4"), ("used_full", "i4"), ("cost", "f8")])
+PLACE_DTYPE = np.dtype([("c_node", "i4"), ("p_node", "i4"), ("a_node", "i4"), ("n_cand", "i4"), ("wuv", "f8"), ("ratio", "f8"),
+                        ("wnr", "f8"), ("loglik", "f8"), ("height", "f8"), ("q_place", "f8"), ("q_taxon", "f8"),
+                        ("anno_dist", "f8"), ("est_loglik", "f8")])
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".cpp", ".h"))]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "hmmufotu_amd.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps):
+        subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.hu_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise EngineError("hmmufotu_amd error %d: %s" % (rc, load_library().hu_last_error().decode()))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def device_count() -> int:
+    return int(load_library().hu_device_count())
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    load_library().hu_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if k == "align_mode" and isinstance(v, str):
+            v = MODE[v]
+        setattr(o, k, v)
+    return o
+
+
+def model_desc(type_id: int, pi, par, dg_rates=None) -> ModelDesc:
+    m = ModelDesc()
+    m.type = int(type_id)
+    for i in range(4):
+        m.pi[i] = float(pi[i])
+    par = np.asarray(par, np.float64).ravel()
+    for i in range(min(16, len(par))):
+        m.par[i] = float(par[i])
+    dg = np.asarray(dg_rates if dg_rates is not None else [], np.float64)
+    m.dg_k = len(dg)
+    for i in range(len(dg)):
+        m.dg_rate[i] = float(dg[i])
+    return m
+
+
+def model_spectral(md: ModelDesc):
+    """Host-only: (U, lam, U1) with P(t) = U diag(exp(lam t)) U1 as the kernels use it."""
+    U = np.zeros(16); lam = np.zeros(4); U1 = np.zeros(16)
+    _chk(load_library().hu_model_spectral(C.byref(md), _p(U, C.c_double), _p(lam, C.c_double), _p(U1, C.c_double)))
+    return U.reshape(4, 4), lam, U1.reshape(4, 4)
+
+
+def parse_files(hmm_path=None, ptu_path=None):
+    """Host-only parse of the reference's .hmm / .ptu formats (no device needed)."""
+    L_ = load_library()
+    K = C.c_int32(0); L = C.c_int32(0); n = C.c_int32(0); root = C.c_int32(0); md = ModelDesc()
+    hp = hmm_path.encode() if hmm_path else None
+    pp = ptu_path.encode() if ptu_path else None
+    _chk(L_.hu_files_parse(hp, pp, C.byref(K), C.byref(L), C.byref(n), C.byref(root), *([None] * 12), C.byref(md), 0))
+    out = dict(K=K.value, L=L.value, n_nodes=n.value, root=root.value, model=md)
+    args = [None] * 12
+    if hmm_path:
+        out.update(EM=np.zeros((K.value + 1, 4)), EI=np.zeros((K.value + 1, 4)), T=np.zeros((K.value + 1, 7)),
+                   p2cs=np.zeros(K.value + 1, np.int32), entry_cost=np.zeros(K.value + 1), exit_cost=np.zeros(K.value + 1))
+        args[0:6] = [_p(out["EM"], C.c_double), _p(out["EI"], C.c_double), _p(out["T"], C.c_double), _p(out["p2cs"], C.c_int32),
+                     _p(out["entry_cost"], C.c_double), _p(out["exit_cost"], C.c_double)]
+    if ptu_path:
+        nn, ll = n.value, L.value
+        out.update(parent=np.zeros(nn, np.int32), blen=np.zeros(nn), seq=np.zeros((nn, ll), np.int8), height=np.zeros(nn),
+                   up=np.zeros((nn, ll, 4)), down=np.zeros((nn, ll, 4)))
+        args[6:12] = [_p(out["parent"], C.c_int32), _p(out["blen"], C.c_double), _p(out["seq"], C.c_int8), _p(out["height"], C.c_double),
+                      _p(out["up"], C.c_double), _p(out["down"], C.c_double)]
+    _chk(L_.hu_files_parse(hp, pp, C.byref(K), C.byref(L), C.byref(n), C.byref(root), *args, C.byref(md), 1))
+    return out
+
+
+class Database:
+    """Profile + pre-evaluated tree packed once into HBM (hu_db)."""
+
+    def __init__(self, handle, keep=None):
+        self.h = handle
+        self._keep = keep
+        K = C.c_int32(); L = C.c_int32(); n = C.c_int32(); r = C.c_int32(); hb = C.c_int64()
+        _chk(load_library().hu_db_info(self.h, C.byref(K), C.byref(L), C.byref(n), C.byref(r), C.byref(hb)))
+        self.K, self.cs_len, self.n_nodes, self.root, self.hbm_bytes = K.value, L.value, n.value, r.value, hb.value
+
+    @classmethod
+    def from_arrays(cls, hmm, parent, blen, seq, up, down, height, model: ModelDesc, anno_id=None, anno_dist=None,
+                    win_start=0, win_len=0, device=0, msgs_on_device=False):
+        lib = load_library()
+        keep = dict(EM=np.ascontiguousarray(hmm.EM, np.float64), EI=np.ascontiguousarray(hmm.EI, np.float64),
+                    T=np.ascontiguousarray(hmm.T, np.float64), p2cs=np.ascontiguousarray(hmm.p2cs, np.int32),
+                    parent=np.ascontiguousarray(parent, np.int32), blen=np.ascontiguousarray(blen, np.float64),
+                    seq=np.ascontiguousarray(seq, np.int8), height=np.ascontiguousarray(height, np.float64))
+        pd = ProfileDesc(int(hmm.K), int(hmm.L), _p(keep["EM"], C.c_double), _p(keep["EI"], C.c_double), _p(keep["T"], C.c_double),
+                         _p(keep["p2cs"], C.c_int32))
+        td = TreeDesc()
+        td.n_nodes, td.cs_len = keep["seq"].shape
+        td.parent = _p(keep["parent"], C.c_int32); td.blen = _p(keep["blen"], C.c_double); td.seq = _p(keep["seq"], C.c_int8)
+        td.height = _p(keep["height"], C.c_double)
+        if msgs_on_device:
+            td.up = C.c_void_p(int(up)); td.down = C.c_void_p(int(down)); td.msgs_on_device = 1
+        else:
+            keep["up"] = np.ascontiguousarray(up, np.float64); keep["down"] = np.ascontiguousarray(down, np.float64)
+            td.up = keep["up"].ctypes.data_as(C.c_void_p); td.down = keep["down"].ctypes.data_as(C.c_void_p)
+        if anno_id is not None:
+            keep["anno"] = np.ascontiguousarray(anno_id, np.int32); td.anno_id = _p(keep["anno"], C.c_int32)
+        if anno_dist is not None:
+            keep["annod"] = np.ascontiguousarray(anno_dist, np.float64); td.anno_dist = _p(keep["annod"], C.c_double)
+        td.win_start = int(win_start); td.win_len = int(win_len)
+        h = C.c_void_p()
+        _chk(lib.hu_db_create(C.byref(pd), C.byref(td), C.byref(model), C.c_int(device), C.byref(h)))
+        return cls(h, keep if msgs_on_device else None)
+
+    @classmethod
+    def from_synth(cls, db, device=0):
+        md = model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if db.dg_k > 0 else None)
+        return cls.from_arrays(db.hmm, db.parent, db.blen, db.seq, db.up, db.down, db.height, md, db.anno_id, db.anno_dist, device=device)
+
+    @classmethod
+    def load(cls, hmm_path: str, ptu_path: str, device=0):
+        h = C.c_void_p()
+        _chk(load_library().hu_db_load(hmm_path.encode(), ptu_path.encode(), C.c_int(device), C.byref(h)))
+        return cls(h)
+
+    def model_pr(self, t):
+        t = np.ascontiguousarray(t, np.float64).ravel()
+        P = np.zeros((len(t), 4, 4))
+        _chk(load_library().hu_db_model_pr(self.h, C.c_int(len(t)), _p(t, C.c_double), _p(P, C.c_double)))
+        return P
+
+    def profile(self):
+        K = self.K
+        out = dict(EM=np.zeros((K + 1, 4)), EI=np.zeros((K + 1, 4)), T=np.zeros((K + 1, 7)), p2cs=np.zeros(K + 1, np.int32),
+                   entry_cost=np.zeros(K + 1), exit_cost=np.zeros(K + 1))
+        _chk(load_library().hu_db_get_profile(self.h, _p(out["EM"], C.c_double), _p(out["EI"], C.c_double), _p(out["T"], C.c_double),
+                                              _p(out["p2cs"], C.c_int32), _p(out["entry_cost"], C.c_double), _p(out["exit_cost"], C.c_double)))
+        return out
+
+    def close(self):
+        if self.h:
+            load_library().hu_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """One batch of reads in flight on one HIP stream (hu_batch)."""
+
+    def __init__(self, db: Database, max_reads: int):
+        self.db = db
+        self.h = C.c_void_p()
+        self.n = 0
+        _chk(load_library().hu_batch_create(db.h, C.c_int(max_reads), C.byref(self.h)))
+
+    # ---- inputs
+    def set_reads(self, reads, vpaths, mates=None, mvpaths=None):
+        n = len(reads)
+        self.n = n
+        cat = "".join(reads).encode("latin1")
+        offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
+        vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 2, 6) if vpaths is not None else None
+        if mates is not None:
+            mcat = "".join(mates).encode("latin1")
+            moffs = np.zeros(n + 1, np.int64); moffs[1:] = np.cumsum([len(r) for r in mates])
+            mvp = np.ascontiguousarray(mvpaths, np.int32).reshape(n, 2, 6) if mvpaths is not None else None
+        _chk(load_library().hu_batch_set_reads(self.h, C.c_int(n), cat, _p(offs, C.c_int64), _p(vp, C.c_int32) if vp is not None else None,
+                                               mcat if mates is not None else None, _p(moffs, C.c_int64) if mates is not None else None,
+                                               _p(mvp, C.c_int32) if mates is not None and mvp is not None else None))
+
+    def set_aligned(self, codes, start, end):
+        codes = np.ascontiguousarray(codes, np.int8)
+        n = codes.shape[0]
+        self.n = n
+        s = np.ascontiguousarray(start, np.int32); e = np.ascontiguousarray(end, np.int32)
+        _chk(load_library().hu_batch_set_aligned(self.h, C.c_int(n), _p(codes, C.c_int8), _p(s, C.c_int32), _p(e, C.c_int32)))
+
+    # ---- stages (reference names in the docstrings of include/hmmufotu_amd.h)
+    def align(self, opts): _chk(load_library().hu_align_batch(self.h, C.byref(opts)))
+    def get_seed(self, opts): _chk(load_library().hu_seed_batch(self.h, C.byref(opts)))
+    def estimate_seq(self, opts): _chk(load_library().hu_estimate_batch(self.h, C.byref(opts)))
+    def filter_placements(self, opts): _chk(load_library().hu_filter_batch(self.h, C.byref(opts)))
+    def place_seq(self, opts): _chk(load_library().hu_place_batch(self.h, C.byref(opts)))
+    def calc_q_values(self, opts): _chk(load_library().hu_finish_batch(self.h, C.byref(opts)))
+    def assign(self, opts): _chk(load_library().hu_assign_batch(self.h, C.byref(opts)))
+    def sync(self): _chk(load_library().hu_batch_sync(self.h))
+    def profile(self, enable=True): _chk(load_library().hu_batch_profile(self.h, C.c_int(int(enable))))
+
+    def timings(self):
+        ms = np.zeros(8, np.float32)
+        _chk(load_library().hu_batch_timings(self.h, _p(ms, C.c_float)))
+        return {T_NAMES[i]: float(ms[i]) for i in range(6)}
+
+    # ---- results
+    def alignments(self, want_align=True, want_trace=False, trace_stride=0):
+        n, L = self.n, self.db.cs_len
+        recs = np.zeros(n, ALIGN_DTYPE)
+        rows = np.zeros((n, L), np.uint8) if want_align else None
+        tr = np.zeros((n, trace_stride), np.uint8) if want_trace else None
+        _chk(load_library().hu_batch_get_alignments(self.h, recs.ctypes.data_as(C.c_void_p),
+                                                    rows.ctypes.data_as(C.c_char_p) if rows is not None else None,
+                                                    tr.ctypes.data_as(C.c_char_p) if tr is not None else None, C.c_int(trace_stride)))
+        out = dict(recs=recs)
+        if rows is not None:
+            out["align"] = [rows[i].tobytes().decode("latin1") for i in range(n)]
+        if tr is not None:
+            out["trace"] = [tr[i].tobytes().split(b"\0")[0].decode() for i in range(n)]
+        return out
+
+    def codes(self):
+        n, L = self.n, self.db.cs_len
+        cd = np.zeros((n, L), np.int8); s = np.zeros(n, np.int32); e = np.zeros(n, np.int32)
+        _chk(load_library().hu_batch_get_codes(self.h, _p(cd, C.c_int8), _p(s, C.c_int32), _p(e, C.c_int32)))
+        return cd, s, e
+
+    def pdist(self, read: int):
+        d = np.zeros(self.db.n_nodes, np.int32); N = np.zeros(self.db.n_nodes, np.int32)
+        _chk(load_library().hu_batch_get_pdist(self.h, C.c_int(read), _p(d, C.c_int32), _p(N, C.c_int32)))
+        return d, N
+
+    def seeds(self):
+        n = self.n
+        cnt = np.zeros(n, np.int32); ids = np.zeros((n, HU_MAX_SEEDS), np.int32); d = np.zeros_like(ids); N = np.zeros_like(ids)
+        _chk(load_library().hu_batch_get_seeds(self.h, _p(cnt, C.c_int32), _p(ids, C.c_int32), _p(d, C.c_int32), _p(N, C.c_int32)))
+        return cnt, ids, d, N
+
+    def estimates(self):
+        n = self.n
+        r = np.zeros((n, HU_MAX_SEEDS)); w = np.zeros_like(r); ll = np.zeros_like(r)
+        _chk(load_library().hu_batch_get_estimates(self.h, _p(r, C.c_double), _p(w, C.c_double), _p(ll, C.c_double)))
+        return r, w, ll
+
+    def candidates(self):
+        offs = np.zeros(self.n + 1, np.int64)
+        _chk(load_library().hu_batch_get_candidates(self.h, _p(offs, C.c_int64), None, None, None, None, None))
+        m = int(offs[-1])
+        c = np.zeros(m, np.int32); r = np.zeros(m); w = np.zeros(m); e = np.zeros(m); it = np.zeros(m, np.int32)
+        _chk(load_library().hu_batch_get_candidates(self.h, _p(offs, C.c_int64), _p(c, C.c_int32), _p(r, C.c_double), _p(w, C.c_double),
+                                                    _p(e, C.c_double), _p(it, C.c_int32)))
+        return dict(offs=offs, c_node=c, ratio=r, wnr=w, est_loglik=e, iters=it)
+
+    def placements(self):
+        out = np.zeros(self.n, PLACE_DTYPE)
+        _chk(load_library().hu_batch_get_placements(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.h:
+            load_library().hu_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

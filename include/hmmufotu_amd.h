@@ -1,0 +1,201 @@
+/*
+ * hmmufotu_amd — C ABI of the MI355X-native per-read assignment engine.
+ *
+ * The reference (HmmUFOtu v1.5.1) has no plugin/FFI layer; its seam for this path is the C++
+ * free-function API of src/HmmUFOtu_main.h:70-113 called once per read from the OpenMP task in
+ * src/hmmufotu.cpp:603-751.  This header is the batched, POD-only replacement of that seam:
+ * every entry point names the reference function(s) it stands in for.  Host code that keeps
+ * the per-read reference signatures lives in hmmufotu_amd/csrc/hu_reference_api.hpp.
+ *
+ * Conventions: all pointers are HOST pointers unless a field says "device"; the caller owns
+ * every in/out buffer; functions return HU_OK (0) or a negative hu_status and never abort;
+ * hu_last_error() returns a thread-local message.  One hu_batch is driven by one host thread
+ * (it owns a HIP stream); several batches may share one hu_db concurrently (the DB is
+ * immutable after creation, like the const BandedHMMP7 / PTUnrooted objects of the reference).
+ */
+#ifndef HMMUFOTU_AMD_H_
+#define HMMUFOTU_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	HU_OK = 0,
+	HU_ERR_ARG = -1,      /* invalid argument (reference: assert / invalid_argument)            */
+	HU_ERR_DEVICE = -2,   /* no gfx950 device / HIP failure: the engine has NO CPU fallback      */
+	HU_ERR_IO = -3,       /* unreadable or malformed database file                                */
+	HU_ERR_NOMEM = -4,
+	HU_ERR_STATE = -5     /* stage called out of order                                            */
+} hu_status;
+
+/* align_mode of src/BandedHMMP7.h:168-173 */
+enum { HU_MODE_GLOBAL = 0, HU_MODE_LOCAL = 1, HU_MODE_NGCL = 2, HU_MODE_CGNL = 3 };
+/* DNA substitution models of src/DNASubModelFactory.cpp:38-53 */
+enum { HU_GTR = 0, HU_TN93 = 1, HU_HKY85 = 2, HU_F81 = 3, HU_K80 = 4, HU_JC69 = 5 };
+/* PTUnrooted::PRIOR_TYPE */
+enum { HU_PRIOR_UNIFORM = 0, HU_PRIOR_HEIGHT = 1 };
+
+/* per-read status flags (replace the reference's assert(aln.isValid()) aborts, src/hmmufotu.cpp:622) */
+enum {
+	HU_READ_OK = 1,
+	HU_READ_INVALID = 0,      /* bad base code or no finite Viterbi path                            */
+	HU_READ_CHIMERA = 2,      /* PE orientation check failed (src/hmmufotu.cpp:629-637)             */
+	HU_READ_NEEDS_FULL = 4    /* internal: banded DP found no path, full DP scheduled              */
+};
+
+typedef struct hu_db hu_db;        /* profile + pre-evaluated tree packed once into HBM             */
+typedef struct hu_batch hu_batch;  /* device workspace + stream for one batch of reads in flight    */
+
+/* BandedHMMP7 profile fields as operator>> leaves them (src/BandedHMMP7.cpp:100-246,
+ * src/BandedHMMP7.h:499-548): costs are -ln p, '*' == +inf.  hu_db_create runs the post-load
+ * chain itself (extend_index, adjustProfileLocalMode, wingRetract; :104-109, :1083-1120). */
+typedef struct {
+	int32_t K;                /* profile length (LENG)                                             */
+	int32_t L;                /* consensus length (MAXL)                                           */
+	const double* EM;         /* [K+1][4] match emission costs, row 0 = COMPO                      */
+	const double* EI;         /* [K+1][4] insert emission costs                                    */
+	const double* T;          /* [K+1][7] transition costs m->m m->i m->d i->m i->i d->m d->d      */
+	const int32_t* p2cs;      /* [K+1] MAP: 1-based CS column of profile column k; [0] ignored     */
+} hu_profile_desc;
+
+/* DNASubModel + DiscreteGammaModel parameters (src/GTR.cpp:43-81, src/TN93.cpp:40-77, ...;
+ * src/DiscreteGammaModel.cpp:57-72).  par: GTR R[16] row-major | TN93 kr,ky,beta |
+ * HKY85 kappa,beta | F81 beta | K80 kappa | JC69 -.  pi is ignored for K80/JC69. */
+typedef struct {
+	int32_t type;
+	double pi[4];
+	double par[16];
+	int32_t dg_k;             /* 0 = no discrete Gamma                                             */
+	double dg_rate[16];       /* r[k] exactly as stored in the .ptu (NOT multiplied by K)          */
+} hu_model_desc;
+
+/* PTUnrooted as loaded from a .ptu (src/PhyloTreeUnrooted.cpp:496-535): node i is id2node[i].
+ * up[i] is the cached message of branch i -> parent(i), down[i] that of parent(i) -> i
+ * (Matrix4Xd 4 x csLen, column-major == [site][4]); for the root, up[root] holds the root
+ * message.  Messages may be given for a column window only (win_len < cs_len). */
+typedef struct {
+	int32_t n_nodes;
+	int32_t cs_len;
+	const int32_t* parent;    /* [n] -1 for the root                                               */
+	const double* blen;       /* [n] length of the branch to the parent                            */
+	const int8_t* seq;        /* [n][cs_len] DigitalSeq codes: 0..3, gap -2                        */
+	const double* up;         /* [n][win_len][4]                                                   */
+	const double* down;       /* [n][win_len][4]                                                   */
+	const double* height;     /* [n] node2height                                                   */
+	const int32_t* anno_id;   /* [n] class of the node's taxon annotation string (may be NULL)     */
+	const double* anno_dist;  /* [n] annoDist (may be NULL)                                        */
+	int64_t win_start;        /* first CS column (0-based) covered by up/down                      */
+	int64_t win_len;          /* 0 = all cs_len columns                                            */
+	int32_t msgs_on_device;   /* up/down are DEVICE pointers the DB adopts (not copied, not freed) */
+} hu_tree_desc;
+
+/* CLI defaults of src/hmmufotu.cpp:37-57 */
+typedef struct {
+	int32_t align_mode;       /* HU_MODE_GLOBAL for assembled/PE reads, HU_MODE_NGCL for --single  */
+	int32_t max_nseed;        /* -N  [50]                                                          */
+	double max_diff;          /* -d  [inf]                                                         */
+	double max_height;        /* -H  [inf]                                                         */
+	double max_error;         /* -e  [20]                                                          */
+	int32_t weighted;         /* -m  0 'unweighted' [default], 1 'weighted'                        */
+	int32_t only_ml;          /* --ML                                                              */
+	int32_t prior;            /* --prior                                                           */
+	int32_t ignore_orient;    /* -i                                                                */
+} hu_opts;
+
+/* BandedHMMP7::HmmAlignment minus the string (src/BandedHMMP7.h:74-130) */
+typedef struct {
+	int32_t seq_start, seq_end, hmm_start, hmm_end, cs_start, cs_end; /* all 1-based */
+	int32_t status;           /* HU_READ_*                                                          */
+	int32_t used_full;        /* 1 if the full-DP fallback ran (src/HmmUFOtu_main.cpp:89-93)        */
+	double cost;
+} hu_align_rec;
+
+/* PTUnrooted::PTPlacement (src/PhyloTreeUnrooted.h:410-510) with node ids instead of pointers */
+typedef struct {
+	int32_t c_node, p_node, a_node;
+	int32_t n_cand;           /* candidates that survived filterPlacements                          */
+	double wuv, ratio, wnr, loglik, height, q_place, q_taxon, anno_dist, est_loglik;
+} hu_place_rec;
+
+void hu_default_opts(hu_opts* o);
+const char* hu_last_error(void);
+/* number of usable gfx950 devices (0 => every compute entry point fails with HU_ERR_DEVICE) */
+int hu_device_count(void);
+
+/* ---- database ---------------------------------------------------------------------------
+ * replaces: hmmIn >> hmm, ptu.load(ptuIn), hmm.setSequenceMode/wingRetract
+ * (src/hmmufotu.cpp:457-498) */
+int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu_model_desc* model,
+		int device, hu_db** out);
+/* same from the reference's on-disk formats (.hmm text, .ptu binary) */
+int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out);
+void hu_db_destroy(hu_db* db);
+int hu_db_info(const hu_db* db, int32_t* K, int32_t* cs_len, int32_t* n_nodes, int32_t* root, int64_t* hbm_bytes);
+/* host copies of what the readers parsed (for format tests); any pointer may be NULL */
+int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double* T, int32_t* p2cs,
+		double* entry_cost, double* exit_cost);
+int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, int8_t* seq, double* height);
+int hu_db_get_model(const hu_db* db, hu_model_desc* out);
+/* device-side DNASubModel::Pr(t) (src/GTR.h:116-121 and friends), for parity tests */
+int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P /* [n][16] row-major */);
+
+/* ---- batch ------------------------------------------------------------------------------ */
+int hu_batch_create(hu_db* db, int max_reads, hu_batch** out);
+void hu_batch_destroy(hu_batch* b);
+
+/* reads after the host seed lookup (the boundary of SURVEY.md F7): bases are the read
+ * characters (upper-case IUPAC; anything PrimarySeq::encodeAt maps to <0 marks the read
+ * invalid), vpaths the ViterbiAlignPath {start,end,from,to,nIns,nDel} of the <=2 CSFM seeds
+ * (src/HmmUFOtu_main.cpp:52-84, src/BandedHMMP7.cpp:894-941), rows with start==0 unused.
+ * mates (already reverse-complemented, src/hmmufotu.cpp:609) may be NULL for SE. */
+int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const int64_t* offs, const int32_t* vpaths,
+		const char* mates, const int64_t* moffs, const int32_t* mvpaths);
+/* alternative entry after alignment: DigitalSeq codes [n][cs_len] and 0-based inclusive
+ * regions, as getSeed/estimateSeq/placeSeq receive them (src/hmmufotu.cpp:641-645) */
+int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end);
+
+/* alignSeq(hmm, csfm, read, ...) minus the CSFM lookup, + PE merge + DigitalSeq encoding
+ * (src/HmmUFOtu_main.cpp:86-104, src/hmmufotu.cpp:621-641) */
+int hu_align_batch(hu_batch* b, const hu_opts* o);
+/* getSeed + truncation to max_nseed (src/HmmUFOtu_main.cpp:127-152, src/hmmufotu.cpp:645-647);
+ * order is (dist, node id) — the reference's std::sort order is unspecified among ties */
+int hu_seed_batch(hu_batch* b, const hu_opts* o);
+/* estimateSeq over the seeds (src/HmmUFOtu_main.cpp:154-160, src/PhyloTreeUnrooted.cpp:849-877) */
+int hu_estimate_batch(hu_batch* b, const hu_opts* o);
+/* filterPlacements (src/HmmUFOtu_main.cpp:162-173) — host, literally std::sort */
+int hu_filter_batch(hu_batch* b, const hu_opts* o);
+/* placeSeq over the survivors (src/HmmUFOtu_main.cpp:175-180, src/PhyloTreeUnrooted.cpp:879-954) */
+int hu_place_batch(hu_batch* b, const hu_opts* o);
+/* calcQValues + final sort + bestPlace (src/HmmUFOtu_main.cpp:182-216, src/hmmufotu.cpp:725-733) */
+int hu_finish_batch(hu_batch* b, const hu_opts* o);
+/* the whole per-read task body for the batch (src/hmmufotu.cpp:621-733) */
+int hu_assign_batch(hu_batch* b, const hu_opts* o);
+/* wait for everything queued on the batch's stream */
+int hu_batch_sync(hu_batch* b);
+
+/* ---- results (device -> caller's host buffers; any pointer may be NULL) ----------------- */
+int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align /* [n][cs_len] */, char* trace, int trace_stride);
+int hu_batch_get_codes(hu_batch* b, int8_t* codes /* [n][cs_len] */, int32_t* start, int32_t* end);
+int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d /* [n_nodes] */, int32_t* N);
+int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N /* [n][max_nseed] */);
+int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik /* [n][max_nseed] */);
+/* all candidates after placement, in filterPlacements order: offs [n+1]; arrays sized offs[n] */
+int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters);
+int hu_batch_get_placements(hu_batch* b, hu_place_rec* best /* [n] */);
+
+/* ---- measurement ------------------------------------------------------------------------
+ * per-kernel device time of the LAST call of each stage, measured with HIP events on the
+ * batch's stream: ms[HU_T_*]; and the algorithmic work it covered */
+enum { HU_T_VITERBI = 0, HU_T_ALIGN_BUILD = 1, HU_T_SEED_PDIST = 2, HU_T_SEED_TOPK = 3,
+	HU_T_ESTIMATE = 4, HU_T_PLACE = 5, HU_T_COUNT = 8 };
+int hu_batch_timings(hu_batch* b, float* ms /* [HU_T_COUNT] */);
+/* enable/disable event recording around kernels (off by default: zero overhead) */
+int hu_batch_profile(hu_batch* b, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMMUFOTU_AMD_H_ */

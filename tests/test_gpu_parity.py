@@ -1,0 +1,258 @@
+"""GPU parity tests: every stage of the HIP path against the CPU oracle, through the C ABI.
+
+Tolerances: integer / index / string results bit-exact; Viterbi cost bit-exact (same additions
+and minima); floating-point SEP quantities within 1e-6 relative as BASELINE.json's north_star
+states (the kernels work in linear space with their own scaling and device exp/log, so they are
+not expected to be bitwise equal to the log-space CPU arithmetic).
+"""
+import numpy as np
+import pytest
+
+from conftest import get_db, oracle_objects, sim_reads
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+def _engine():
+    from hmmufotu_amd import engine as E
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device: GPU tests must run on the MI355X box (no CPU fallback exists)")
+    return E
+
+
+def _rel(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    return np.abs(a - b) / np.maximum(1e-300, np.maximum(np.abs(a), np.abs(b)))
+
+
+@pytest.mark.parametrize("model", ["GTR", "TN93", "HKY85", "F81", "K80", "JC69"])
+def test_model_pr(model):
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(20, 200, model, dg_k=0, seed=3)
+    D = E.Database.from_synth(db)
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    ts = np.array([0.0, 1e-8, 1e-5, 1e-3, 0.05, 0.3, 1.0, 5.0, 50.0])
+    P = D.model_pr(ts)
+    for i, t in enumerate(ts):
+        assert np.abs(P[i] - m.P(float(t))).max() < 1e-12, (model, t)
+    D.close()
+
+
+def _run_stages(E, db, reads, vps, opts, mode=0, mates=None, mvps=None):
+    D = E.Database.from_synth(db)
+    B = E.Batch(D, max(len(reads), 1))
+    B.set_reads([r if isinstance(r, str) else r.seq for r in reads], vps, mates, mvps)
+    B.align(opts)
+    return D, B
+
+
+@pytest.mark.parametrize("cfg", [dict(model="GTR", dg_k=4, read_len=150), dict(model="JC69", dg_k=0, read_len=100),
+                                 dict(model="TN93", dg_k=4, read_len=250)])
+def test_align_parity(cfg):
+    E = _engine()
+    db = get_db(120, 700 if cfg["read_len"] < 200 else 1400, cfg["model"], dg_k=cfg["dg_k"])
+    _, H, _ = oracle_objects(db)
+    reads, vps = sim_reads(db, 48, cfg["read_len"])
+    # exercise: no seed at all (full DP), one seed only, both seeds
+    vps = vps.copy(); vps[0] = 0; vps[1, 1] = 0; vps[2, 0] = vps[2, 1]; vps[2, 1] = 0
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    out = B.alignments(want_align=True, want_trace=True, trace_stride=db.hmm.K + 400)
+    cd, st, en = B.codes()
+    from oracle import oracle_py as O
+    for i, r in enumerate(reads):
+        a = H.align(r.seq, vps[i])
+        rec = out["recs"][i]
+        assert a["ok"] and rec["status"] == 1, i
+        assert (rec["seq_start"], rec["seq_end"], rec["hmm_start"], rec["hmm_end"], rec["cs_start"], rec["cs_end"]) == \
+               (a["seqStart"], a["seqEnd"], a["hmmStart"], a["hmmEnd"], a["csStart"], a["csEnd"]), i
+        assert rec["cost"] == a["cost"], (i, rec["cost"], a["cost"])          # bit-exact
+        assert out["trace"][i] == a["trace"], i
+        assert out["align"][i] == a["align"], i
+        assert bool(rec["used_full"]) == a["usedFull"], i
+        ds = O.digitize(a["align"])
+        assert (cd[i] == ds).all(), i
+        assert st[i] == a["csStart"] - 1 and en[i] == a["csEnd"] - 1
+    B.close(); D.close()
+
+
+def test_align_modes_and_bad_reads():
+    E = _engine()
+    db = get_db(120, 700, "GTR", dg_k=4)
+    reads, vps = sim_reads(db, 16, 120)
+    seqs = [r.seq for r in reads]
+    seqs[3] = seqs[3][:10] + "x" + seqs[3][11:]       # invalid character -> invalid read, not an abort
+    seqs[4] = seqs[4][:20] + "N" + seqs[4][21:]       # degenerate base scores as its first expansion
+    for mode in (0, 2):
+        _, H, _ = oracle_objects(db, mode)
+        opts = E.default_opts(align_mode=mode)
+        D, B = _run_stages(E, db, seqs, vps, opts)
+        out = B.alignments(want_align=True)
+        for i, s in enumerate(seqs):
+            a = H.align(s, vps[i])
+            rec = out["recs"][i]
+            if i == 3:
+                assert rec["status"] == 0 and not a["ok"]
+                continue
+            assert rec["status"] == 1 and a["ok"], (mode, i)
+            assert rec["cost"] == a["cost"] and out["align"][i] == a["align"], (mode, i)
+        B.close(); D.close()
+
+
+def test_pe_merge_parity():
+    E = _engine()
+    from hmmufotu_amd import synth
+    from oracle import oracle_py as O
+    db = get_db(120, 1400, "GTR", dg_k=4)
+    _, H, _ = oracle_objects(db)
+    rng = np.random.default_rng(5)
+    ins = synth.simulate_reads(db, 24, 100000, rng, amplicon_start=60, amplicon_cols=1200, jitter=20)
+    fw, rv, vf, vr = [], [], [], []
+    for r in ins:
+        n = len(r.seq)
+        f = synth.SimRead(r.seq[:120], r.cols[:120], r.node, r.rc, r.cs_start, r.cs_end)
+        m = synth.SimRead(r.seq[n - 120:], r.cols[n - 120:], r.node, r.rc, r.cs_start, r.cs_end)  # mate after revcom
+        fw.append(f.seq); rv.append(m.seq); vf.append(synth.read_vpaths(db.hmm, f)); vr.append(synth.read_vpaths(db.hmm, m))
+    fw[0], rv[0] = rv[0], fw[0]; vf[0], vr[0] = vr[0], vf[0]          # wrong orientation -> chimera status
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, fw, np.stack(vf), opts, mates=rv, mvps=np.stack(vr))
+    out = B.alignments(want_align=True)
+    for i in range(len(fw)):
+        a = H.align(fw[i], vf[i]); b = H.align(rv[i], vr[i])
+        ia = [a[k] for k in ("seqStart", "seqEnd", "hmmStart", "hmmEnd", "csStart", "csEnd")]
+        ib = [b[k] for k in ("seqStart", "seqEnd", "hmmStart", "hmmEnd", "csStart", "csEnd")]
+        ok, im, cm, am = O.merge(db.cs_len, ia, a["cost"], a["align"].encode("latin1"), ib, b["cost"], b["align"].encode("latin1"))
+        rec = out["recs"][i]
+        if i == 0:
+            assert not ok and rec["status"] == 2
+            continue
+        assert ok and rec["status"] == 1, i
+        assert [rec[k] for k in ("seq_start", "seq_end", "hmm_start", "hmm_end", "cs_start", "cs_end")] == list(im[:6]), i
+        assert rec["cost"] == cm and out["align"][i] == am.decode("latin1"), i
+    B.close(); D.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(model="GTR", dg_k=4, n_leaves=300, cs_len=1400, read_len=250),
+                                 dict(model="GTR", dg_k=0, n_leaves=150, cs_len=700, read_len=150),
+                                 dict(model="JC69", dg_k=0, n_leaves=100, cs_len=700, read_len=150),
+                                 dict(model="HKY85", dg_k=4, n_leaves=100, cs_len=700, read_len=100),
+                                 dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100)])
+def test_sep_parity(cfg):
+    """seed scan, top-k, estimate, filter, place, q-values vs the oracle, stage by stage."""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(cfg["n_leaves"], cfg["cs_len"], cfg["model"], dg_k=cfg["dg_k"])
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 40, cfg["read_len"])
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+    cd, st, en = B.codes()
+    cnt, ids, sd, sN = B.seeds()
+    er, ew, el = B.estimates()
+    cand = B.candidates()
+    best = B.placements()
+    oo = O.default_opts()
+    worst = dict(est=0.0, ratio=0.0, wnr=0.0)
+    for i in range(len(reads)):
+        d, N = B.pdist(i)
+        od, oN = T.pdist_all(cd[i], int(st[i]), int(en[i]))
+        assert (d == od).all() and (N == oN).all(), i                      # bit-exact counts for every node
+        res = T.assign(cd[i], int(st[i]), int(en[i]), oo)
+        k = len(res["seed_ids"])
+        assert cnt[i] == k and (ids[i, :k] == res["seed_ids"]).all(), i     # bit-exact seed ids and order
+        assert (sd[i, :k] == res["seed_d"]).all() and (sN[i, :k] == res["seed_N"]).all()
+        assert np.array_equal(er[i, :k], res["est"][:, 0]), i               # ratio: same integer quotients
+        assert np.array_equal(ew[i, :k], res["est"][:, 1]), i               # unweighted wnr = count / n
+        worst["est"] = max(worst["est"], _rel(el[i, :k], res["est"][:, 2]).max())
+        lo, hi = cand["offs"][i], cand["offs"][i + 1]
+        assert hi - lo == res["n"], i
+        # candidates are reported in filterPlacements order; the oracle's list is in final output order
+        oc = {int(n_[0]): (v[0], v[1], int(n_[3])) for n_, v in zip(res["nodes"], res["vals"])}
+        for c in range(lo, hi):
+            r0, w0_, it = oc[int(cand["c_node"][c])]
+            worst["ratio"] = max(worst["ratio"], abs(cand["ratio"][c] - r0) / max(abs(r0), 1e-3))
+            worst["wnr"] = max(worst["wnr"], abs(cand["wnr"][c] - w0_) / max(abs(w0_), 1e-3))
+        b = best[i]
+        assert (b["c_node"], b["p_node"], b["a_node"]) == tuple(int(x) for x in res["nodes"][0][:3]), i   # bit-exact ids
+        assert b["n_cand"] == res["n"]
+        assert _rel(b["loglik"], res["vals"][0][2]) < 1e-12
+        assert _rel(b["q_place"], res["vals"][0][4]) < 1e-9 and _rel(b["q_taxon"], res["vals"][0][5]) < 1e-9
+    assert worst["est"] < REL and worst["ratio"] < REL and worst["wnr"] < REL, worst
+    B.close(); D.close()
+
+
+def test_sep_weighted_and_maxheight():
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(150, 700, "GTR", dg_k=0)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 16, 150)
+    mh = float(np.median(db.height))
+    opts = E.default_opts(weighted=1, max_height=mh, max_nseed=20, prior=1)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.assign(opts) if False else (B.get_seed(opts), B.estimate_seq(opts), B.filter_placements(opts), B.place_seq(opts), B.calc_q_values(opts))
+    cd, st, en = B.codes()
+    cnt, ids, _, _ = B.seeds()
+    er, ew, el = B.estimates()
+    best = B.placements()
+    oo = O.default_opts(weighted=1, maxHeight=mh, maxNSeed=20, prior=1)
+    for i in range(len(reads)):
+        res = T.assign(cd[i], int(st[i]), int(en[i]), oo)
+        k = len(res["seed_ids"])
+        assert cnt[i] == k and (ids[i, :k] == res["seed_ids"]).all()
+        assert _rel(ew[i, :k], res["est"][:, 1]).max() < REL and _rel(el[i, :k], res["est"][:, 2]).max() < REL
+        b = best[i]
+        assert (b["c_node"], b["a_node"]) == (int(res["nodes"][0][0]), int(res["nodes"][0][2]))
+        assert _rel(b["q_place"], res["vals"][0][4]) < 1e-5
+    B.close(); D.close()
+
+
+def test_set_aligned_entry_and_empty_batch():
+    E = _engine()
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    from oracle import oracle_py as O
+    reads, vps = sim_reads(db, 8, 120)
+    codes, s, e = [], [], []
+    for r, vp in zip(reads, vps):
+        a = H.align(r.seq, vp)
+        codes.append(O.digitize(a["align"])); s.append(a["csStart"] - 1); e.append(a["csEnd"] - 1)
+    D = E.Database.from_synth(db)
+    B = E.Batch(D, 16)
+    opts = E.default_opts()
+    B.set_aligned(np.stack(codes), s, e)
+    B.assign(opts)
+    best = B.placements()
+    for i in range(len(reads)):
+        res = T.assign(codes[i], s[i], e[i], O.default_opts())
+        assert best[i]["c_node"] == int(res["nodes"][0][0])
+    B.set_reads([], np.zeros((0, 2, 6), np.int32))
+    B.assign(opts)
+    assert len(B.placements()) == 0
+    B.close(); D.close()
+
+
+def test_db_load_from_reference_formats(tmp_path):
+    E = _engine()
+    from hmmufotu_amd import synth
+    db = get_db(60, 400, "GTR", dg_k=4, seed=3)
+    hp, pp = str(tmp_path / "t.hmm"), str(tmp_path / "t.ptu")
+    synth.write_hmm(db.hmm, hp); synth.write_ptu(db, pp)
+    D1 = E.Database.load(hp, pp)
+    D2 = E.Database.from_synth(db)
+    reads, vps = sim_reads(db, 8, 100)
+    outs = []
+    for D in (D1, D2):
+        B = E.Batch(D, 8)
+        B.set_reads([r.seq for r in reads], vps)
+        B.assign(E.default_opts())
+        outs.append((B.placements().copy(), B.alignments()["align"]))
+        B.close()
+    assert outs[0][1] == outs[1][1]
+    for k in ("c_node", "a_node", "ratio", "wnr", "q_place"):
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    D1.close(); D2.close()
