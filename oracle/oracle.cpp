@@ -139,9 +139,10 @@ static void export_place(const Placement& p, int* ni, double* nd) {
 /* full SEP for one aligned read; outputs all final placements in output order (ints [n][4], dbl [n][8]),
  * seeds (ids/d/N) and per-seed estimates (est [nSeeds][3] = ratio,wnr,loglik).  Returns #placements. */
 int orc_assign(void* tr, const int8_t* seq, int start, int end, const OrcOpts* o,
-		int* ni, double* nd, int* nSeeds, long* seedIds, long* seedD, long* seedN, double* est) {
-	std::vector<PTLoc> seeds; std::vector<Placement> ests;
-	std::vector<Placement> pl = assignSeq(*(Tree*) tr, seq, start, end, to_opts(o), &seeds, &ests);
+		int* ni, double* nd, int* nSeeds, long* seedIds, long* seedD, long* seedN, double* est, int* filtOrder) {
+	std::vector<PTLoc> seeds; std::vector<Placement> ests; std::vector<int> filt;
+	std::vector<Placement> pl = assignSeq(*(Tree*) tr, seq, start, end, to_opts(o), &seeds, &ests, &filt);
+	if(filtOrder) for(size_t i = 0; i < filt.size(); ++i) filtOrder[i] = filt[i];
 	for(size_t i = 0; i < pl.size(); ++i) export_place(pl[i], ni + 4 * i, nd + 8 * i);
 	if(nSeeds) *nSeeds = (int) seeds.size();
 	for(size_t i = 0; i < seeds.size(); ++i) {

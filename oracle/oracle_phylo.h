@@ -378,13 +378,14 @@ struct AssignOpts {
 /* the SEP part of the per-read task (src/hmmufotu.cpp:641-647,720-733); seq = DigitalSeq of
  * the alignment, [start,end] 0-based inclusive */
 inline std::vector<Placement> assignSeq(const Tree& t, const int8_t* seq, int start, int end, const AssignOpts& o,
-		std::vector<PTLoc>* seedsOut = nullptr, std::vector<Placement>* estOut = nullptr) {
+		std::vector<PTLoc>* seedsOut = nullptr, std::vector<Placement>* estOut = nullptr, std::vector<int>* filtOut = nullptr) {
 	std::vector<PTLoc> seeds = getSeed(t, seq, start, end, o.maxDiff, o.maxHeight, o.tieMode, (size_t) o.maxNSeed);
 	if(seedsOut) *seedsOut = seeds;
 	std::vector<Placement> places;
 	for(const PTLoc& l : seeds) places.push_back(estimateSeq(t, seq, l, o.weighted != 0));
 	if(estOut) *estOut = places;
 	filterPlacements(places, o.maxError);
+	if(filtOut) { filtOut->clear(); for(const Placement& p : places) filtOut->push_back(p.cNode); }
 	for(Placement& p : places) placeSeq(t, seq, p, o.maxHeight);
 	if(o.onlyML)
 		std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; });

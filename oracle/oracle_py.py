@@ -169,10 +169,11 @@ class Tree:
         m = max(opts.maxNSeed, 1)
         ni = np.zeros((m, 4), np.int32); nd = np.zeros((m, 8)); ns = C.c_int(0)
         sid = np.zeros(m, np.int64); sd = np.zeros(m, np.int64); sn = np.zeros(m, np.int64); est = np.zeros((m, 3))
+        fo = np.zeros(m, np.int32)
         n = lib().orc_assign(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.byref(opts), _p(ni, C.c_int), _p(nd, C.c_double),
-                             C.byref(ns), _p(sid, C.c_long), _p(sd, C.c_long), _p(sn, C.c_long), _p(est, C.c_double))
+                             C.byref(ns), _p(sid, C.c_long), _p(sd, C.c_long), _p(sn, C.c_long), _p(est, C.c_double), _p(fo, C.c_int))
         k = ns.value
-        return dict(n=n, nodes=ni[:n], vals=nd[:n], seed_ids=sid[:k], seed_d=sd[:k], seed_N=sn[:k], est=est[:k])
+        return dict(n=n, nodes=ni[:n], vals=nd[:n], seed_ids=sid[:k], seed_d=sd[:k], seed_N=sn[:k], est=est[:k], filt_order=fo[:n])
 
     def __del__(self):
         try:

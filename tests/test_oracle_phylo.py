@@ -1,0 +1,131 @@
+"""Pins of the oracle's SEP placement (CPU): independent recounts and likelihood invariants."""
+import numpy as np
+import pytest
+
+from conftest import get_db, oracle_objects, sim_reads
+from hmmufotu_amd import synth
+from oracle import oracle_py as O
+
+
+def _aligned(db, H, n=12, read_len=150):
+    reads, vps = sim_reads(db, n, read_len)
+    out = []
+    for r, vp in zip(reads, vps):
+        a = H.align(r.seq, vp)
+        out.append((r, O.digitize(a["align"]), a["csStart"] - 1, a["csEnd"] - 1))
+    return out
+
+
+def test_pdist_counts_against_numpy_recount():
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    for r, ds, s, e in _aligned(db, H, 6):
+        d, N = T.pdist_all(ds, s, e)
+        both = (db.seq[:, s:e + 1] >= 0) & (ds[None, s:e + 1] >= 0)
+        assert (N == both.sum(1)).all()
+        assert (d == (both & (db.seq[:, s:e + 1] != ds[None, s:e + 1])).sum(1)).all()
+        ids, sd, sN, dist = T.get_seed(ds, s, e, tie=0)
+        key = np.where(N > 0, d / np.maximum(N, 1), np.inf)
+        key[0] = np.inf                                      # root is never a seed
+        order = np.lexsort((np.arange(len(key)), key))[:50]
+        assert (ids == order).all()
+        ids2, _, _, dist2 = T.get_seed(ds, s, e, tie=1)      # reference's std::sort: same multiset of distances
+        assert np.array_equal(np.sort(dist), np.sort(dist2))
+
+
+@pytest.mark.parametrize("model,dg_k", [("GTR", 0), ("GTR", 4), ("JC69", 0), ("TN93", 4)])
+def test_tree_loglik_root_invariance(model, dg_k):
+    """the design claim of the unrooted tree (src/PhyloTreeUnrooted.h:23-24): with messages on
+    every directed edge, the site likelihood evaluated across ANY branch is the same number."""
+    db = get_db(40, 120, model, dg_k=dg_k, seed=7)
+    m, _, _ = oracle_objects(db)
+    pi = np.full(4, 0.25) if model in ("JC69",) else db.model.pi
+    if dg_k:
+        return _root_invariance_dg(db, pi)
+    ref = None
+    for u in range(1, db.n_nodes, 7):
+        P = synth.model_P(db.model, db.blen[u])
+        conv = np.log(np.einsum("ij,sj->si", P, np.exp(db.up[u])))
+        ll = np.log((pi[None, :] * np.exp(conv + db.down[u])).sum(1))
+        ref = ll if ref is None else ref
+        assert np.abs(ll - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    root = np.log((pi[None, :] * np.exp(db.up[0])).sum(1))
+    assert np.abs(root - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+
+
+def _root_invariance_dg(db, pi):
+    # with discrete Gamma the reference averages categories at every inner node, so strict root
+    # invariance does not hold; check instead that the oracle's evaluate reproduces the stored messages
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    up, down, seq, h = O.tree_evaluate(db.parent, db.blen, np.where(db.is_leaf[:, None], db.seq, 0), m, db.dg_r)
+    fin = np.isfinite(db.up)
+    assert np.abs(up[fin] - db.up[fin]).max() < 1e-9 * max(1.0, np.abs(db.up[fin]).max())
+    assert (np.isfinite(up) == fin).all()
+    assert np.abs(down[1:] - db.down[1:]).max() < 1e-9 * max(1.0, np.abs(db.down[1:]).max())
+    assert (seq == db.seq).all() and np.abs(h - db.height).max() < 1e-12
+
+
+def test_oracle_evaluate_matches_generator_no_dg():
+    db = get_db(40, 120, "HKY85", dg_k=0, seed=7)
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    up, down, seq, h = O.tree_evaluate(db.parent, db.blen, np.where(db.is_leaf[:, None], db.seq, 0), m, None)
+    fin = np.isfinite(db.up)
+    assert np.abs(up[fin] - db.up[fin]).max() < 1e-9 * np.abs(db.up[fin]).max()
+    assert np.abs(down[1:] - db.down[1:]).max() < 1e-9 * np.abs(db.down[1:]).max()
+    assert (seq == db.seq).all() and np.abs(h - db.height).max() < 1e-12
+
+
+def test_estimate_equals_grafted_tree_loglik():
+    """estimateSeq's loglik is the tree log-likelihood with the read grafted at the branch point:
+    recomputed here from scratch in probability space with numpy."""
+    db = get_db(120, 700, "GTR", dg_k=0)
+    _, H, T = oracle_objects(db)
+    pi = db.model.pi
+    for r, ds, s, e in _aligned(db, H, 4):
+        ids, d, N, dist = T.get_seed(ds, s, e)
+        for k in (0, 3, 17):
+            u = int(ids[k])
+            est = T.estimate(ds, s, e, u, float(dist[k]))
+            w0 = db.blen[u]; wur = w0 * est["ratio"]; wvr = w0 - wur
+            Pu, Pv, Pn = (synth.model_P(db.model, t) for t in (wur, wvr, est["wnr"]))
+            U = np.exp(db.up[u, s:e + 1]); V = np.exp(db.down[u, s:e + 1])
+            leaf = np.where(ds[s:e + 1, None] >= 0, np.eye(4)[np.maximum(ds[s:e + 1], 0)], pi[None, :])
+            site = (pi[None, :] * (U @ Pu.T) * (V @ Pv.T) * (leaf @ Pn.T)).sum(1)
+            assert abs(np.log(site).sum() - est["loglik"]) < 1e-7 * abs(est["loglik"])
+            par = db.parent[u]
+            pd = (db.seq[par, s:e + 1] != ds[s:e + 1])[(db.seq[par, s:e + 1] >= 0) & (ds[s:e + 1] >= 0)].mean()
+            want = dist[k] / (dist[k] + pd) if dist[k] + pd > 0 else 0.5
+            assert abs(est["ratio"] - want) < 1e-15
+            assert est["aNode"] == (u if est["ratio"] <= 0.5 else par)
+
+
+def test_place_constant_loglik_and_fixed_point():
+    """F4: the final loglik is (end-start+1) * log(sum_i pi_i e); and the joint optimisation ends at
+    a fixed point of the two EM updates (re-running from its output changes nothing > 1e-5)."""
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    pi = db.model.pi
+    for r, ds, s, e in _aligned(db, H, 4):
+        res = T.assign(ds, s, e)
+        const = (e - s + 1) * np.log((pi * np.e).sum())
+        assert np.allclose(res["vals"][:, 2], const, rtol=1e-13)
+        assert len(set(res["vals"][:, 2])) == 1                          # exact ties (decides the final sort)
+        u = int(res["nodes"][0][0])
+        p1 = T.place(ds, s, e, u, res["vals"][0][0], res["vals"][0][1])
+        w0 = db.blen[u]                                                  # the EM stops on |d wur| < 1e-5, wur = ratio * w0
+        assert abs(p1["ratio"] - res["vals"][0][0]) * w0 < 5e-5 and abs(p1["wnr"] - res["vals"][0][1]) < 5e-5
+        assert p1["iters"] <= 3
+
+
+def test_simulated_reads_place_near_truth():
+    """sanity of the whole oracle: the estimate stage ranks the true branch (or a neighbour) high."""
+    db = get_db(120, 700, "GTR", dg_k=0)
+    _, H, T = oracle_objects(db)
+    hit = 0
+    al = _aligned(db, H, 20)
+    for r, ds, s, e in al:
+        res = T.assign(ds, s, e)
+        top = res["seed_ids"][np.argsort(-res["est"][:, 2])[:5]]
+        near = {r.node, int(db.parent[r.node])} | {int(c) for c in np.nonzero(db.parent == r.node)[0]}
+        hit += bool(near & set(int(x) for x in top))
+    assert hit >= 14
