@@ -267,6 +267,7 @@ extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P
 	double *dt, *dP;
 	HIPCHK(hipMalloc((void**) &dt, std::max(n, 1) * 8)); HIPCHK(hipMalloc((void**) &dP, std::max(n, 1) * 128));
 	HIPCHK(hipMemcpy(dt, t, n * 8, hipMemcpyHostToDevice));
+	(void) hipGetLastError();
 	if(n) k_model_pr<<<(n + 63) / 64, 64>>>(db->mdl, n, dt, dP);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpy(P, dP, (size_t) n * 128, hipMemcpyDeviceToHost));
@@ -304,6 +305,7 @@ struct hu_batch {
 	bool paired = false, fromCodes = false, profile = false;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[2 * HU_T_COUNT];
+	bool evSet[HU_T_COUNT] = {false};
 	float ms[HU_T_COUNT];
 	/* device */
 	DBuf<char> dBases, dTraces, dRows;
@@ -337,7 +339,7 @@ struct hu_batch {
 struct Timer {
 	hu_batch* b; int id;
 	Timer(hu_batch* b, int id) : b(b), id(id) { if(b->profile) (void) hipEventRecord(b->ev[2 * id], b->stream); }
-	~Timer() { if(b->profile) (void) hipEventRecord(b->ev[2 * id + 1], b->stream); }
+	~Timer() { if(b->profile) { (void) hipEventRecord(b->ev[2 * id + 1], b->stream); b->evSet[id] = true; } }
 };
 
 extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) {
@@ -369,7 +371,7 @@ extern "C" int hu_batch_timings(hu_batch* b, float* ms) {
 	HIPCHK(hipStreamSynchronize(b->stream));
 	for(int i = 0; i < HU_T_COUNT; ++i) {
 		float t = 0;
-		if(b->profile && hipEventElapsedTime(&t, b->ev[2 * i], b->ev[2 * i + 1]) == hipSuccess) b->ms[i] = t;
+		if(b->profile && b->evSet[i] && hipEventElapsedTime(&t, b->ev[2 * i], b->ev[2 * i + 1]) == hipSuccess) b->ms[i] = t;
 		ms[i] = b->ms[i];
 	}
 	return HU_OK;
@@ -511,6 +513,7 @@ extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, con
 		a.csStart = start[r] + 1; a.csEnd = end[r] + 1;
 		if(!ok) { b->hStart[r] = 0; b->hEnd[r] = -1; }
 	}
+	(void) hipGetLastError();
 	if(n) {
 		HIPCHK(hipMemcpyAsync(b->dCodes.p, codes, (size_t) n * d.csLen, hipMemcpyHostToDevice, b->stream));
 		HIPCHK(hipMemcpyAsync(b->dStart.p, b->hStart.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
@@ -537,6 +540,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	if((rc = b->dRows.ensure((size_t) b->nSeq * d.csLen)) != HU_OK) return rc;
 	if((rc = b->dAlns.ensure(b->nSeq)) != HU_OK) return rc;
 	b->hVit.resize(b->nSeq);
+	(void) hipGetLastError(); /* the HIP runtime is shared with torch: drop stale sticky errors that are not ours */
 	if(b->nSeq) {
 		{
 			Timer t(b, HU_T_VITERBI);
@@ -608,6 +612,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	(void) hipGetLastError();
 	if(n) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
@@ -631,6 +636,7 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 	const size_t n = (size_t) b->n;
 	int rc;
 	if((rc = b->dEst.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	(void) hipGetLastError();
 	if(n) {
 		Timer t(b, HU_T_ESTIMATE);
 		k_estimate<<<b->n * HU_MAX_SEEDS, 64, 0, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p,
@@ -701,6 +707,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 	if((rc = b->dCands.ensure(nc)) != HU_OK) return rc;
 	if((rc = b->dPlaceOut.ensure(nc)) != HU_OK) return rc;
 	b->hPlaceOut.resize(nc);
+	(void) hipGetLastError();
 	if(nc) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);

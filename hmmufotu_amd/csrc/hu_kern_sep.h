@@ -170,6 +170,17 @@ __device__ inline int argmax4d(const double* v) { /* Eigen maxCoeff(&i): first s
 	if(v[3] > v[b]) b = 3;
 	return b;
 }
+/* inferState on a computed message: components that are equal in exact arithmetic (all-gap columns
+ * under the equal-frequency models K80/JC69, where P(t) rows are permutations of each other) differ
+ * here only by rounding of the spectral products; Eigen's maxCoeff returns the FIRST maximum of an
+ * exact tie, so values within 1e-10 (1 + |max|) of the maximum count as tied. */
+__device__ inline int argmax4_tied(const double* v) {
+	const double mx = max4d(v), tol = 1e-10 * (1.0 + fabs(mx));
+	if(v[0] >= mx - tol) return 0;
+	if(v[1] >= mx - tol) return 1;
+	if(v[2] >= mx - tol) return 2;
+	return 3;
+}
 __device__ inline double sel4(const double* v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
 
 /* e = exp(M - max M), returns max M (the log scale); all -inf -> zeros */
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 		double R[4];
 		siteR(j, R);
 		const int b = cd[j];
-		const int b1 = argmax4d(R), b2 = b >= 0 ? b : piMax;
+		const int b1 = argmax4_tied(R), b2 = b >= 0 ? b : piMax;
 		if(!weighted) { if(b1 != b2) dsum += 1; }
 		else {
 			double mx = max4d(R), w[4];
