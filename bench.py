@@ -63,22 +63,31 @@ def main():
         win = (max(0, amp_start - 200), min(args.cs_len, args.win))
     t0 = time.time()
     db, up, down = synth_gpu.make_db_gpu(args.leaves, args.cs_len, "GTR", dg_k=args.dg_k, seed=97, win=win, device=dev, log=log)
+    # reads are drawn from the log-space messages BEFORE the engine adopts (and repacks) them
+    nb = 2
+    all_reads, all_vps = [], []
+    for i in range(nb):
+        reads = synth_gpu.simulate_reads_gpu(db, up, down, args.batch, args.read_len, seed=1 + 1000 * rank + i,
+                                             amplicon_start=amp_start, amplicon_cols=amp_cols, device=dev)
+        all_reads.append(reads); all_vps.append(np.stack([synth.read_vpaths(db.hmm, r) for r in reads]))
+    # host copy of the amplicon window of the messages for the CPU baseline (oracle), log space
+    cpu_win = None
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        lo = max(db.win[0], min(r.cs_start for r in all_reads[0]) - 40)
+        hi = min(db.win[0] + db.win[1], max(r.cs_end for r in all_reads[0]) + 41)
+        cpu_win = (lo, hi, up[:, lo - db.win[0]:hi - db.win[0]].contiguous().cpu().numpy(),
+                   down[:, lo - db.win[0]:hi - db.win[0]].contiguous().cpu().numpy())
     md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if db.dg_k > 0 else None)
     D = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, db.anno_id,
                                win_start=db.win[0], win_len=db.win[1] if win else 0, device=local, msgs_on_device=True)
     log("database resident: %.1f GB in HBM, K=%d, nodes=%d, build %.0fs" % (D.hbm_bytes / 1e9, D.K, D.n_nodes, time.time() - t0))
-
-    nb = 2
-    batches, all_reads, all_vps = [], [], []
+    batches = []
     opts = E.default_opts()
     for i in range(nb):
-        reads = synth_gpu.simulate_reads_gpu(db, up, down, args.batch, args.read_len, seed=1 + 1000 * rank + i,
-                                             amplicon_start=amp_start, amplicon_cols=amp_cols, device=dev)
-        vps = np.stack([synth.read_vpaths(db.hmm, r) for r in reads])
         B = E.Batch(D, args.batch)
-        B.set_reads([r.seq for r in reads], vps)           # inputs resident in HBM before the timed region
+        B.set_reads([r.seq for r in all_reads[i]], all_vps[i])     # inputs resident in HBM before the timed region
         B.sync()
-        batches.append(B); all_reads.append(reads); all_vps.append(vps)
+        batches.append(B)
     log("reads simulated and uploaded: %d batches of %d (%.0fs)" % (nb, args.batch, time.time() - t0))
 
     def barrier():
@@ -111,10 +120,13 @@ def main():
     B.profile(True)
     acc = {}
     nprof = 3
+    wall = {}
     for _ in range(nprof):
         B.assign(opts)
         for k, v in B.timings().items():
             acc[k] = acc.get(k, 0.0) + v / nprof
+        for k, v in B.wall().items():
+            wall[k] = wall.get(k, 0.0) + v / nprof
     B.profile(False)
     cd, st, en = B.codes()
     ok = en >= st
@@ -145,15 +157,15 @@ def main():
                config=dict(workload="gg_97_otus-scale synthetic DB (%d nodes x %d CS columns, K=%d), GTR+dGamma(%d), SE %d bp amplicon reads, "
                                     "batch %d reads/step/GPU" % (D.n_nodes, args.cs_len, D.K, args.dg_k, args.read_len, args.batch),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
-               roofline=roof, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()})
+               roofline=roof, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()},
+               host_wall_ms={k: round(float(v), 2) for k, v in wall.items()})
 
     # ---- CPU baseline: the oracle (line-faithful port) on this box's host cores, rank 0, N=1 only
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         try:
             from oracle import oracle_py as O
-            w0, wl = db.win
-            lo = max(w0, int(st[ok].min()) - 8); hi = min(w0 + wl, int(en[ok].max()) + 9)
-            up_h = up[:, lo - w0:hi - w0].contiguous().cpu().numpy(); down_h = down[:, lo - w0:hi - w0].contiguous().cpu().numpy()
+            lo, hi, up_h, down_h = cpu_win
+            assert lo <= int(st[ok].min()) and int(en[ok].max()) < hi
             m = O.Model(db.model.type_id, db.model.pi, db.model.par)
             H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
             T = O.Tree(db.parent, db.blen, db.seq, up_h, down_h, db.height, m, db.dg_r if db.dg_k > 0 else None, db.anno_id,

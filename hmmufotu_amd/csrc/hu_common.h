@@ -33,8 +33,13 @@ struct HuDbDev {
 	const int32_t* parent;
 	const double* blen;
 	const double* height;
+	/* directed-edge messages, packed once at load time into LINEAR space: 4 doubles
+	 * e_i = exp(M_i) * 2^-k with k = rint(max_i M_i / ln 2) kept in upK/downK, so that the kernels
+	 * never evaluate exp() on a message again (the reference does, per site, per use) */
 	const double* up;          /* [n][winLen][4] */
 	const double* down;
+	const int32_t* upK;        /* [n][winLen] */
+	const int32_t* downK;
 	/* profile */
 	int32_t K, L;
 	const double* EM;          /* [K+1][4] */

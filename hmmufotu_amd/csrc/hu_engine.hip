@@ -9,6 +9,9 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 #include "hu_kern_align.h"
@@ -17,6 +20,19 @@
 	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
 
 static const double kInf = std::numeric_limits<double>::infinity();
+
+/* the <= 50-record host stages (filterPlacements, calcQValues) are independent per read */
+template<class F> static void parallel_for(size_t n, F f) {
+	unsigned nt = std::thread::hardware_concurrency();
+	if(nt > 16) nt = 16;
+	if(n < 512 || nt <= 1) { for(size_t i = 0; i < n; ++i) f(i); return; }
+	std::atomic<size_t> next{0};
+	const size_t chunk = 64;
+	std::vector<std::thread> th;
+	for(unsigned t = 0; t < nt; ++t) th.emplace_back([&] {
+		for(;;) { size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk); for(size_t i = a; i < e; ++i) f(i); } });
+	for(auto& t : th) t.join();
+}
 
 struct hu_db {
 	int device = 0;
@@ -147,12 +163,25 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		if((rc = dev_upload(db, &q, db->blen.data(), (size_t) n)) != HU_OK) return fail(rc); d.blen = q;
 		if((rc = dev_upload(db, &q, db->height.data(), (size_t) n)) != HU_OK) return fail(rc); d.height = q;
 	}
-	if(tree->msgs_on_device) { d.up = tree->up; d.down = tree->down; db->hbmBytes += 2 * (int64_t) n * winLen * 32; }
-	else {
-		double* q;
+	{
+		double *qu, *qd;
 		const size_t cnt = (size_t) n * winLen * 4;
-		if((rc = dev_upload(db, &q, tree->up, cnt)) != HU_OK) return fail(rc); d.up = q;
-		if((rc = dev_upload(db, &q, tree->down, cnt)) != HU_OK) return fail(rc); d.down = q;
+		if(tree->msgs_on_device) { qu = const_cast<double*>(tree->up); qd = const_cast<double*>(tree->down); db->hbmBytes += 2 * (int64_t) cnt * 8; }
+		else {
+			if((rc = dev_upload(db, &qu, tree->up, cnt)) != HU_OK) return fail(rc);
+			if((rc = dev_upload(db, &qd, tree->down, cnt)) != HU_OK) return fail(rc);
+		}
+		/* pack once: log-space .ptu messages -> linear 4-vectors + binary exponent, in place */
+		int32_t *ku, *kd;
+		const size_t ns = (size_t) n * winLen;
+		if((rc = dev_alloc(db, &ku, ns)) != HU_OK) return fail(rc);
+		if((rc = dev_alloc(db, &kd, ns)) != HU_OK) return fail(rc);
+		(void) hipGetLastError();
+		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(qu, ku, ns);
+		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(qd, kd, ns);
+		hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+		if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("message packing failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
+		d.up = qu; d.down = qd; d.upK = ku; d.downK = kd;
 	}
 	{ /* profile */
 		const int K = d.K;
@@ -307,6 +336,7 @@ struct hu_batch {
 	hipEvent_t ev[2 * HU_T_COUNT];
 	bool evSet[HU_T_COUNT] = {false};
 	float ms[HU_T_COUNT];
+	double wall[4] = {0, 0, 0, 0};
 	/* device */
 	DBuf<char> dBases, dTraces, dRows;
 	DBuf<HuReadDesc> dDescs;
@@ -667,10 +697,12 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 	}
 	b->places.clear(); b->hCands.clear();
 	b->candOffs.assign(n + 1, 0);
-	std::vector<HostPlace> pl;
-	for(size_t r = 0; r < n; ++r) {
-		pl.clear();
+	std::vector<std::vector<HostPlace>> per(n);
+	const double maxError = o->max_error;
+	parallel_for(n, [&](size_t r) {
+		std::vector<HostPlace>& pl = per[r];
 		const int cnt = b->hAlns[r].status == HU_READ_OK ? b->hSeedCnt[r] : 0;
+		pl.reserve(cnt);
 		for(int s = 0; s < cnt; ++s) {
 			const HuEstOut& e = b->hEst[r * HU_MAX_SEEDS + s];
 			HostPlace p;
@@ -684,10 +716,12 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 			std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
 			const double bestLL = pl[0].loglik;
 			size_t g = 0;
-			for(; g < pl.size(); ++g) if(bestLL - pl[g].loglik > o->max_error) break;
+			for(; g < pl.size(); ++g) if(bestLL - pl[g].loglik > maxError) break;
 			pl.erase(pl.begin() + g, pl.end());
 		}
-		for(const HostPlace& p : pl) {
+	});
+	for(size_t r = 0; r < n; ++r) {
+		for(const HostPlace& p : per[r]) {
 			b->places.push_back(p);
 			HuCand c; c.read = (int32_t) r; c.node = p.cNode; c.ratio0 = p.ratio; c.wnr0 = p.wnr;
 			b->hCands.push_back(c);
@@ -741,14 +775,14 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 	 * SURVEY.md F4); reproduced, not fixed */
 	const double e1 = std::exp(1.0);
 	const double siteLL = std::log((db->mdl.pi[0] * e1 + db->mdl.pi[2] * e1) + (db->mdl.pi[1] * e1 + db->mdl.pi[3] * e1));
-	std::vector<HostPlace> pl;
-	std::vector<std::pair<int32_t, double>> tax;
-	for(size_t r = 0; r < n; ++r) {
+	parallel_for(n, [&](size_t r) {
+		std::vector<HostPlace> pl;
+		std::vector<std::pair<int32_t, double>> tax;
 		hu_place_rec& br = b->best[r];
 		br.c_node = br.p_node = br.a_node = -1; br.n_cand = 0;
 		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = NAN;
 		const int64_t lo = b->candOffs[r], hi = b->candOffs[r + 1];
-		if(hi <= lo) continue;
+		if(hi <= lo) return;
 		pl.assign(b->places.begin() + lo, b->places.begin() + hi);
 		const int nsite = b->hEnd[r] - b->hStart[r] + 1;
 		double ll = 0;
@@ -795,7 +829,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		br.c_node = p.cNode; br.p_node = p.pNode; br.a_node = p.aNode; br.n_cand = (int32_t) pl.size();
 		br.wuv = p.wuv; br.ratio = p.ratio; br.wnr = p.wnr; br.loglik = p.loglik; br.height = p.height;
 		br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik;
-	}
+	});
 	b->state = ST_FINISHED;
 	return HU_OK;
 }
@@ -803,13 +837,24 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
 	int rc;
 	if(!b || !o) return HU_ERR_ARG;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+	auto t0 = now();
 	if(!b->fromCodes && (rc = hu_align_batch(b, o)) != HU_OK) return rc;
+	auto t1 = now();
 	if((rc = hu_seed_batch(b, o)) != HU_OK) return rc;
 	if((rc = hu_estimate_batch(b, o)) != HU_OK) return rc;
 	if((rc = hu_filter_batch(b, o)) != HU_OK) return rc;
+	auto t2 = now();
 	if((rc = hu_place_batch(b, o)) != HU_OK) return rc;
-	return hu_finish_batch(b, o);
+	auto t3 = now();
+	rc = hu_finish_batch(b, o);
+	auto t4 = now();
+	b->wall[0] = ms(t0, t1); b->wall[1] = ms(t1, t2); b->wall[2] = ms(t2, t3); b->wall[3] = ms(t3, t4);
+	return rc;
 }
+/* host wall-clock of the last hu_assign_batch: align | seed+estimate+filter | place | finish (ms) */
+extern "C" int hu_batch_wall(hu_batch* b, double* ms4) { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; }
 
 /* ------------------------------------------------------------------------------ results */
 extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align, char* trace, int trace_stride) {

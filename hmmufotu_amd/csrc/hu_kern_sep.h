@@ -210,6 +210,39 @@ __device__ inline void load4(const double* p, double* v) {
 	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
+#define HU_LN2_HI 6.93147180369123816490e-01
+#define HU_LN2_LO 1.90821492927058770002e-10
+#define HU_LN2 0.693147180559945309417232121458
+
+/* one-time packing of the log-space messages of the .ptu into the linear form of HuDbDev */
+__global__ __launch_bounds__(256) void k_pack_msgs(double* __restrict__ msg, int32_t* __restrict__ k2, size_t nsites) {
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if(i >= nsites) return;
+	double M[4];
+	const double2 a = *reinterpret_cast<const double2*>(msg + i * 4), b = *reinterpret_cast<const double2*>(msg + i * 4 + 2);
+	M[0] = a.x; M[1] = a.y; M[2] = b.x; M[3] = b.y;
+	const double mx = fmax(fmax(M[0], M[1]), fmax(M[2], M[3]));
+	int k = 0;
+	double e[4] = {0, 0, 0, 0};
+	if(mx != -INFINITY) {
+		k = (int) rint(mx * (1.0 / HU_LN2));
+		for(int c = 0; c < 4; ++c) e[c] = exp(fma(-(double) k, HU_LN2_LO, fma(-(double) k, HU_LN2_HI, M[c])));
+	}
+	*reinterpret_cast<double2*>(msg + i * 4) = make_double2(e[0], e[1]);
+	*reinterpret_cast<double2*>(msg + i * 4 + 2) = make_double2(e[2], e[3]);
+	k2[i] = k;
+}
+
+/* inferState in linear space (argmax of a product == argmax of the sum of logs); exact-arithmetic
+ * ties (see argmax4_tied) resolve to the first index */
+__device__ inline int argmax4_tied_lin(const double* z) {
+	const double thr = max4d(z) * (1.0 - 1e-9);
+	if(z[0] >= thr) return 0;
+	if(z[1] >= thr) return 1;
+	if(z[2] >= thr) return 2;
+	return 3;
+}
+
 struct HuEstOut { double ratio, wnr, loglik; };
 
 /* one wave per (read, seed); lanes stride the sites of [start, end] */
@@ -234,35 +267,29 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 	for(int k = 0; k < 4; ++k) { Eu[k] = exp(mdl.lam[k] * wur); Ev[k] = exp(mdl.lam[k] * wvr); }
 	const int start = rstart[read], end = rend[read];
 	const int8_t* __restrict__ cd = codes + (size_t) read * db.csLen;
-	const int64_t mOff = ((int64_t) u * db.winLen - db.winStart) * 4; /* + 4 j, j >= winStart */
-	const double* __restrict__ Ub = db.up;
-	const double* __restrict__ Vb = db.down;
+	const int64_t sOff = (int64_t) u * db.winLen - db.winStart; /* + j, j >= winStart */
 	const int piMax = argmax4d(mdl.logpi);
 	double piw[4]; /* inferWeight(log pi) */
 	{ double mx = max4d(mdl.logpi), sm; for(int i = 0; i < 4; ++i) piw[i] = exp(mdl.logpi[i] - mx); sm = (piw[0] + piw[2]) + (piw[1] + piw[3]); for(int i = 0; i < 4; ++i) piw[i] /= sm; }
 
-	auto siteR = [&](int j, double* R) {
-		double M[4], e[4], a[4], c[4];
-		load4(Ub + (mOff + (int64_t) j * 4), M);
-		double ls = lin_msg(M, e);
-		if(wur == 0) { for(int i = 0; i < 4; ++i) c[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Eu, a, c); }
-		for(int i = 0; i < 4; ++i) R[i] = log(c[i]) + ls;
-		load4(Vb + (mOff + (int64_t) j * 4), M);
-		ls = lin_msg(M, e);
+	/* z_i = (P(wur) e^U)_i (P(wvr) e^V)_i in linear space; log R_j = log z + (kU + kV) ln 2 */
+	auto siteZ = [&](int j, double* z) {
+		double e[4], a[4], c[4];
+		load4(db.up + (sOff + j) * 4, e);
+		if(wur == 0) { for(int i = 0; i < 4; ++i) z[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Eu, a, z); }
+		load4(db.down + (sOff + j) * 4, e);
 		if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Ev, a, c); }
-		for(int i = 0; i < 4; ++i) R[i] += log(c[i]) + ls;
+		for(int i = 0; i < 4; ++i) z[i] *= c[i];
 	};
 	double dsum = 0, nsum = 0;
 	for(int j = start + lane; j <= end; j += 64) {
-		double R[4];
-		siteR(j, R);
+		double z[4];
+		siteZ(j, z);
 		const int b = cd[j];
-		const int b1 = argmax4_tied(R), b2 = b >= 0 ? b : piMax;
+		const int b1 = argmax4_tied_lin(z), b2 = b >= 0 ? b : piMax;
 		if(!weighted) { if(b1 != b2) dsum += 1; }
 		else {
-			double mx = max4d(R), w[4];
-			for(int i = 0; i < 4; ++i) w[i] = exp(R[i] - mx);
-			double w1 = sel4(w, b1) / ((w[0] + w[2]) + (w[1] + w[3]));
+			double w1 = sel4(z, b1) / ((z[0] + z[2]) + (z[1] + z[3]));
 			double w2 = b >= 0 ? 1.0 : piw[b2];
 			if(b1 != b2) dsum += w1 * w2;
 			nsum += w1 * w2;
@@ -278,24 +305,22 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 	for(int k = 0; k < 4; ++k) En[k] = exp(mdl.lam[k] * wnr);
 	{ double a[4]; to_eig(mdl, mdl.pi, a); if(wnr == 0) { for(int i = 0; i < 4; ++i) Ppi[i] = mdl.pi[i]; } else conv_eig(mdl, En, a, Ppi); }
 	double ll = 0;
+	long long ksum = 0;
 	for(int j = start + lane; j <= end; j += 64) {
-		double R[4], c[4];
-		siteR(j, R);
+		double z[4], c[4];
+		siteZ(j, z);
 		const int b = cd[j];
 		if(b >= 0) {
 			if(wnr == 0) { for(int i = 0; i < 4; ++i) c[i] = i == b ? 1.0 : 0.0; }
 			else { double a[4]; for(int k = 0; k < 4; ++k) a[k] = mdl.U1[k*4+b]; conv_eig(mdl, En, a, c); }
 		}
 		else for(int i = 0; i < 4; ++i) c[i] = Ppi[i];
-		double X[4];
-		for(int i = 0; i < 4; ++i) X[i] = R[i] + log(c[i]);
-		double mx = max4d(X);
-		if(mx == -INFINITY) { ll += -INFINITY; continue; }
-		double e[4];
-		for(int i = 0; i < 4; ++i) e[i] = exp(X[i] - mx);
-		ll += log((mdl.pi[0] * e[0] + mdl.pi[2] * e[2]) + (mdl.pi[1] * e[1] + mdl.pi[3] * e[3])) + mx;
+		ll += log((mdl.pi[0] * z[0] * c[0] + mdl.pi[2] * z[2] * c[2]) + (mdl.pi[1] * z[1] * c[1] + mdl.pi[3] * z[3] * c[3]));
+		ksum += (long long) db.upK[sOff + j] + (long long) db.downK[sOff + j];
 	}
 	ll = wave_sum(ll);
+	for(int m = 32; m > 0; m >>= 1) ksum += __shfl_xor(ksum, m);
+	ll += (double) ksum * HU_LN2;
 	if(lane == 0) { HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = ll; out[(size_t) read * HU_MAX_SEEDS + s] = o; }
 }
 
@@ -363,9 +388,9 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 		__syncthreads();
 		/* (i) message r->n from children u, v; EM on the n-r branch against the read's leaf message */
 		for(int j = lane; j < n; j += 64) {
-			double M[4], eU[4], eV[4], aU[4], aV[4];
-			load4(Ub + (size_t) j * 4, M); lin_msg(M, eU); to_eig(mdl, eU, aU);
-			load4(Vb + (size_t) j * 4, M); lin_msg(M, eV); to_eig(mdl, eV, aV);
+			double eU[4], eV[4], aU[4], aV[4];
+			load4(Ub + (size_t) j * 4, eU); to_eig(mdl, eU, aU);
+			load4(Vb + (size_t) j * 4, eV); to_eig(mdl, eV, aV);
 			double X[4] = {0, 0, 0, 0};
 			for(int k = 0; k < Kc; ++k) {
 				double cu[4], cv[4];
@@ -404,9 +429,9 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 		__syncthreads();
 		/* (ii) message r->u from children v, n; EM on the u-r branch against u's own message */
 		for(int j = lane; j < n; j += 64) {
-			double M[4], eU[4], eV[4], aV[4];
-			load4(Ub + (size_t) j * 4, M); lin_msg(M, eU);
-			load4(Vb + (size_t) j * 4, M); lin_msg(M, eV); to_eig(mdl, eV, aV);
+			double eU[4], eV[4], aV[4];
+			load4(Ub + (size_t) j * 4, eU);
+			load4(Vb + (size_t) j * 4, eV); to_eig(mdl, eV, aV);
 			const int b = cdr[j];
 			const int bi = b >= 0 ? b : 4;
 			double X[4] = {0, 0, 0, 0};

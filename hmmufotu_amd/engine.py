@@ -274,6 +274,11 @@ class Batch:
     def sync(self): _chk(load_library().hu_batch_sync(self.h))
     def profile(self, enable=True): _chk(load_library().hu_batch_profile(self.h, C.c_int(int(enable))))
 
+    def wall(self):
+        ms = np.zeros(4)
+        _chk(load_library().hu_batch_wall(self.h, _p(ms, C.c_double)))
+        return dict(align=ms[0], seed_estimate_filter=ms[1], place=ms[2], finish=ms[3])
+
     def timings(self):
         ms = np.zeros(8, np.float32)
         _chk(load_library().hu_batch_timings(self.h, _p(ms, C.c_float)))

@@ -89,7 +89,8 @@ typedef struct {
 	const double* anno_dist;  /* [n] annoDist (may be NULL)                                        */
 	int64_t win_start;        /* first CS column (0-based) covered by up/down                      */
 	int64_t win_len;          /* 0 = all cs_len columns                                            */
-	int32_t msgs_on_device;   /* up/down are DEVICE pointers the DB adopts (not copied, not freed) */
+	int32_t msgs_on_device;   /* up/down are DEVICE pointers the DB adopts: not copied, not freed, and
+	                           * REWRITTEN IN PLACE into the engine's packed linear form             */
 } hu_tree_desc;
 
 /* CLI defaults of src/hmmufotu.cpp:37-57 */
@@ -194,6 +195,8 @@ enum { HU_T_VITERBI = 0, HU_T_ALIGN_BUILD = 1, HU_T_SEED_PDIST = 2, HU_T_SEED_TO
 int hu_batch_timings(hu_batch* b, float* ms /* [HU_T_COUNT] */);
 /* enable/disable event recording around kernels (off by default: zero overhead) */
 int hu_batch_profile(hu_batch* b, int enable);
+/* host wall-clock (ms) of the last hu_assign_batch: align | seed+estimate+filter | place | finish */
+int hu_batch_wall(hu_batch* b, double* ms4);
 
 #ifdef __cplusplus
 }
