@@ -95,15 +95,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        batches[w % nb].assign(opts)
+    # two batches in flight, each driven by its own host thread on its own HIP stream (the C ABI's
+    # threading model): the host stages of one batch overlap the kernels of the other
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(nb)
+
+    def run_steps(i, steps):
+        out = None
+        for _ in range(steps):
+            batches[i].assign(opts)
+            out = batches[i].placements()
+        return out
+
+    def run(total):
+        share = [total // nb + (1 if i < total % nb else 0) for i in range(nb)]
+        futs = [pool.submit(run_steps, i, share[i]) for i in range(nb) if share[i]]
+        return [f.result() for f in futs]
+
+    run(args.warmup)
     barrier()
     t1 = time.perf_counter()
-    recs = None
-    for s in range(args.steps):
-        B = batches[s % nb]
-        B.assign(opts)
-        recs = B.placements()
+    recs = run(args.steps)[-1]
     if world > 1:                                           # the one collective: final result gather over RCCL
         gathered = gather_records(recs, dev)
     barrier()

@@ -572,9 +572,17 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	b->hVit.resize(b->nSeq);
 	(void) hipGetLastError(); /* the HIP runtime is shared with torch: drop stale sticky errors that are not ours */
 	if(b->nSeq) {
+		int maxLen = 1;
+		for(int s = 0; s < b->nSeq; ++s) maxLen = std::max(maxLen, (int) b->hDescs[s].len);
+		const int ldsRows = maxLen + 1;
+		const size_t vlds = (size_t) 9 * ldsRows * sizeof(double);
 		{
 			Timer t(b, HU_T_VITERBI);
-			k_viterbi<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p);
+			if(vlds <= 96 * 1024 && !getenv("HU_VITERBI_HBM")) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
+				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+				k_viterbi_lds<<<b->nSeq, 64, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
+			}
+			else k_viterbi<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p);
 		}
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));

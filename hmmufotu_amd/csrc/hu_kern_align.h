@@ -200,6 +200,160 @@ __global__ __launch_bounds__(64) void k_viterbi(HuDbDev db, const HuReadDesc* __
 	outs[s] = o;
 }
 
+/* traceback shared by both fill kernels: buildViterbiTrace (src/BandedHMMP7.cpp:943-1006) */
+__device__ inline void vit_trace(const HuDbDev& db, const VitCtx& ctx, const HuReadDesc& rd, char* __restrict__ traces,
+		double bestS, int bestCol, int bestRow, HuVitOut& o) {
+	const int K = db.K;
+	o.minScore = bestS; o.traceLen = 0; o.alnStart = o.alnEnd = o.alnFrom = o.alnTo = 0;
+	if(!(bestS < INFINITY)) { o.status = HU_READ_NEEDS_FULL; return; }
+	char* tr = traces + rd.traceOff;
+	int n = 0;
+	char st = bestCol <= K ? 'M' : 'I';
+	int i = bestRow, j = bestCol <= K ? bestCol : K;
+	o.alnEnd = j; o.alnTo = bestRow;
+	const int R = rd.nRegions;
+	tr[n++] = 'E';
+	while(i >= 1 && j >= 0) {
+		tr[n++] = st;
+		if(st == 'M') {
+			double mD, iD, dD;
+			vit_lookup(ctx, R, i - 1, j - 1, mD, iD, dD);
+			const double* tp = db.T + (size_t)(j - 1) * 8;
+			const double pB = vit_bcol(ctx, i) + db.entryC[j];
+			double mn = INFINITY; char nx = 'B';
+			if(j > 1) {
+				const double pM = mD + tp[0], pI = iD + tp[3], pD = dD + tp[5];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pM < mn) { nx = 'M'; mn = pM; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+				if(pD < mn) { nx = 'D'; mn = pD; }
+			}
+			else {
+				const double pI = iD + tp[3];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			st = nx; i--; j--;
+		}
+		else if(st == 'I') {
+			double mU, iU, dU;
+			vit_lookup(ctx, R, i - 1, j, mU, iU, dU);
+			const double* tj = db.T + (size_t) j * 8;
+			double mn = INFINITY; char nx;
+			if(j > 0) {
+				nx = 'M';
+				const double pM = mU + tj[1], pI = iU + tj[4];
+				if(pM < mn) { nx = 'M'; mn = pM; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			else {
+				nx = 'B';
+				const double pB = vit_bcol(ctx, i) + db.T[1], pI = iU + tj[4];
+				if(pB < mn) { nx = 'B'; mn = pB; }
+				if(pI < mn) { nx = 'I'; mn = pI; }
+			}
+			st = nx; i--;
+		}
+		else if(st == 'D') {
+			double mL, iL, dL;
+			vit_lookup(ctx, R, i, j - 1, mL, iL, dL);
+			const double* tp = db.T + (size_t)(j - 1) * 8;
+			double mn = INFINITY; char nx = 'M';
+			const double pM = mL + tp[2], pD = dL + tp[6];
+			if(pM < mn) { nx = 'M'; mn = pM; }
+			if(pD < mn) { nx = 'D'; mn = pD; }
+			st = nx; j--;
+		}
+		else break;
+	}
+	o.alnStart = j + 1; o.alnFrom = i + 1;
+	if(tr[n - 1] != 'B') tr[n++] = 'B';
+	for(int a = 0, b = n - 1; a < b; ++a, --b) { char t = tr[a]; tr[a] = tr[b]; tr[b] = t; }
+	o.traceLen = n;
+	o.status = (o.alnStart > 0 && o.alnFrom > 0) ? HU_READ_OK : HU_READ_INVALID;
+}
+
+/* LDS-staged variant: the last two anti-diagonals of the running phase live in LDS (three rotating
+ * buffers x {M,I,D} x read length), so the inner loop touches HBM only to file each cell for the
+ * traceback (fire-and-forget stores) and for the few perimeter cells that read an earlier phase.
+ * The S minimum is tracked while filling.  One wave per sequence; DS operations of one wave
+ * execute in order, so consecutive diagonals need no s_barrier and no vmcnt wait. */
+__global__ __launch_bounds__(64) void k_viterbi_lds(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		double* __restrict__ scratch, char* __restrict__ traces, double tNN, double tNB, double tEC, double tCC,
+		HuVitOut* __restrict__ outs, int ldsRows) {
+	extern __shared__ double vsh[];
+	const int s = blockIdx.x, lane = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const int L = rd.len, K = db.K;
+	if(rd.nRegions <= 0) { if(lane == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	const char* __restrict__ x = bases + rd.baseOff;
+	double* scr = scratch + rd.scratchOff * 3;
+	VitCtx ctx = { &rd, scr, tNN, tNB };
+	double bestS = INFINITY; int bestCol = 0x7fffffff, bestRow = 0x7fffffff;
+	const int nR = rd.nRegions;
+	for(int r = 0; r < nR; ++r) {
+		const HuRegion g = rd.reg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		for(int dg = 0; dg <= ni + nj - 2; ++dg) {
+			double* cur = vsh + (size_t)(dg % 3) * 3 * ldsRows;
+			const double* p1 = vsh + (size_t)((dg + 2) % 3) * 3 * ldsRows;
+			const double* p2 = vsh + (size_t)((dg + 1) % 3) * 3 * ldsRows;
+			const int lo = dg - (nj - 1) > 0 ? dg - (nj - 1) : 0, hi = dg < ni - 1 ? dg : ni - 1;
+			for(int q = lo + lane; q <= hi; q += 64) {
+				const int i = g.i0 + q, j = g.j0 + dg - q;
+				const int dist = (i - g.from) - (j - g.start);
+				if(g.band && !(dist <= g.nIns && dist >= -g.nDel)) continue;
+				const int b = c_sym_map[(int) x[i - 1] & 127];
+				double mD, iD, dD, mU, iU, dU, mL, iL, dL;
+				/* (i-1, j-1): band distance unchanged */
+				if(q >= 1 && j - 1 >= g.j0) { mD = p2[q - 1]; iD = p2[ldsRows + q - 1]; dD = p2[2 * ldsRows + q - 1]; }
+				else vit_lookup(ctx, r, i - 1, j - 1, mD, iD, dD);
+				/* (i-1, j): distance - 1 */
+				if(q >= 1 && (!g.band || dist - 1 >= -g.nDel)) { mU = p1[q - 1]; iU = p1[ldsRows + q - 1]; }
+				else vit_lookup(ctx, r, i - 1, j, mU, iU, dU);
+				/* (i, j-1): distance + 1 */
+				if(j - 1 >= g.j0 && (!g.band || dist + 1 <= g.nIns)) { mL = p1[q]; dL = p1[2 * ldsRows + q]; }
+				else vit_lookup(ctx, r, i, j - 1, mL, iL, dL);
+				const double* tp = db.T + (size_t)(j - 1) * 8;
+				const double* tj = db.T + (size_t) j * 8;
+				double best = fmin(mD + tp[0], fmin(iD + tp[3], dD + tp[5]));
+				if(g.withB) best = fmin(vit_bcol(ctx, i) + db.entryC[j], best);
+				const double M = db.EM[(size_t) j * 4 + b] + best;
+				const double I = db.EI[(size_t) j * 4 + b] + fmin(mU + tj[1], iU + tj[4]);
+				const double D = (j > 1 && j < K) ? fmin(mL + tp[2], dL + tp[6]) : INFINITY;
+				cur[q] = M; cur[ldsRows + q] = I; cur[2 * ldsRows + q] = D;
+				const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + q) * 3;
+				scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+				/* S candidates of this cell unless a later phase recomputes it */
+				bool later = false;
+				for(int r2 = r + 1; r2 < nR; ++r2) if(reg_contains(rd.reg[r2], i, j)) later = true;
+				if(!later) {
+					const double cc = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+					double sv = __dadd_rn(__dadd_rn(M, db.exitC[j]), tEC);
+					if(i < L) sv = __dadd_rn(sv, cc);
+					if(sv < bestS || (sv == bestS && (j < bestCol || (j == bestCol && i < bestRow)))) { bestS = sv; bestCol = j; bestRow = i; }
+					if(j == K) {
+						double s2 = __dadd_rn(__dadd_rn(I, db.T[(size_t) K * 8 + 3]), tEC);
+						if(i < L) s2 = __dadd_rn(s2, cc);
+						if(s2 < bestS || (s2 == bestS && (K + 1 < bestCol || (K + 1 == bestCol && i < bestRow)))) { bestS = s2; bestCol = K + 1; bestRow = i; }
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	for(int m = 32; m > 0; m >>= 1) {
+		const double os = __shfl_xor(bestS, m); const int oc = __shfl_xor(bestCol, m), orow = __shfl_xor(bestRow, m);
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	__syncthreads(); /* every cell filed in HBM before lane 0 walks back through them */
+	if(lane != 0) return;
+	HuVitOut o;
+	vit_trace(db, ctx, rd, traces, bestS, bestCol, bestRow, o);
+	outs[s] = o;
+}
+
 /* getPaddingSeq(..., JUSTIFIED) of a non-empty insert (src/BandedHMMP7.cpp:1168-1178) */
 __device__ inline void pad_justified(char* dst, int L, const char* ins, int n) {
 	if(n >= L) {

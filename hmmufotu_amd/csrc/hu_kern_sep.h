@@ -63,42 +63,61 @@ __device__ inline unsigned long long seed_key(uint32_t d, uint32_t N, uint32_t n
 	return (q << 24) | node;
 }
 
+/* bin of a (d, N) pair: floor(4096 d / N), or HU_TOPK_BINS for N == 0; pairs at or beyond `limit`
+ * (in units of 1/4096) collapse into bin `limit` without a division */
+__device__ inline uint32_t seed_bin(uint32_t d, uint32_t N, uint32_t limit) {
+	if(N == 0) return limit < HU_TOPK_BINS ? limit : HU_TOPK_BINS;
+	if(limit < HU_TOPK_BINS && (unsigned long long) d * 4096ull >= (unsigned long long) limit * N) return limit;
+	return (d << 12) / N;
+}
+
 __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* __restrict__ pairs, double maxHeight,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN) {
 	__shared__ uint32_t hist[HU_TOPK_BINS + 1];
 	__shared__ uint32_t chunk[256];
 	__shared__ unsigned long long keys[HU_TOPK_CAP];
-	__shared__ uint32_t sh[4];
+	__shared__ uint32_t sh[5];
 	const int read = blockIdx.x, tid = threadIdx.x;
 	const uint32_t* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
-	for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
-	__syncthreads();
-	for(int node = tid; node < db.nNodes; node += 256) {
-		if(node == db.root || !(db.height[node] <= maxHeight)) continue;
-		uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
-		uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
-		atomicAdd(&hist[bin], 1u);
-	}
-	__syncthreads();
-	/* threshold bin: first bin whose cumulative count reaches the number of seeds wanted */
 	const int per = (HU_TOPK_BINS + 1 + 255) / 256;
-	{
-		uint32_t s = 0;
-		for(int i = tid * per; i < (tid + 1) * per && i <= HU_TOPK_BINS; ++i) s += hist[i];
-		chunk[tid] = s;
+	/* the wanted seeds are the nearest nodes: histogram only distances < 1/4 first (the bulk of the
+	 * tree is farther and would serialise on a few hot LDS counters); fall back to all bins if short */
+	uint32_t limit = 1024;
+	for(int attempt = 0; attempt < 2; ++attempt) {
+		for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
+		__syncthreads();
+		uint32_t over = 0;
+		for(int node = tid; node < db.nNodes; node += 256) {
+			if(node == db.root || !(db.height[node] <= maxHeight)) continue;
+			const uint32_t v = pr[node], bin = seed_bin(v >> 16, v & 0xffffu, limit);
+			if(bin == limit && limit < HU_TOPK_BINS) over++;
+			else atomicAdd(&hist[bin], 1u);
+		}
+		for(int m = 32; m > 0; m >>= 1) over += __shfl_xor(over, m);
+		if((tid & 63) == 0 && over) atomicAdd(&hist[limit], over);
+		__syncthreads();
+		{
+			uint32_t sm = 0;
+			for(int i = tid * per; i < (tid + 1) * per && i <= HU_TOPK_BINS; ++i) sm += hist[i];
+			chunk[tid] = sm;
+		}
+		__syncthreads();
+		if(tid == 0) {
+			uint32_t total = 0;
+			for(int i = 0; i < 256; ++i) total += chunk[i];
+			uint32_t need = total < (uint32_t) maxNSeed ? total : (uint32_t) maxNSeed;
+			uint32_t cum = 0; int c = 0;
+			while(c < 255 && cum + chunk[c] < need) { cum += chunk[c]; ++c; }
+			int b = c * per;
+			while(b < HU_TOPK_BINS && cum + hist[b] < need) { cum += hist[b]; ++b; }
+			sh[0] = need; sh[1] = (uint32_t) b; sh[2] = cum + hist[b]; sh[3] = 0;
+			sh[4] = (limit < HU_TOPK_BINS && (uint32_t) b >= limit && need > 0) ? 1u : 0u; /* threshold fell into the overflow bin */
+		}
+		__syncthreads();
+		if(!sh[4]) break;
+		limit = HU_TOPK_BINS;
+		__syncthreads();
 	}
-	__syncthreads();
-	if(tid == 0) {
-		uint32_t total = 0;
-		for(int i = 0; i < 256; ++i) total += chunk[i];
-		uint32_t need = total < (uint32_t) maxNSeed ? total : (uint32_t) maxNSeed;
-		uint32_t cum = 0; int c = 0;
-		while(c < 255 && cum + chunk[c] < need) { cum += chunk[c]; ++c; }
-		int b = c * per;
-		while(b < HU_TOPK_BINS && cum + hist[b] < need) { cum += hist[b]; ++b; }
-		sh[0] = need; sh[1] = (uint32_t) b; sh[2] = cum + hist[b]; sh[3] = 0;
-	}
-	__syncthreads();
 	const uint32_t need = sh[0], thr = sh[1], cntLE = sh[2];
 	if(need == 0) { if(tid == 0) seedCnt[read] = 0; return; }
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
@@ -106,9 +125,8 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	if(cntLE <= HU_TOPK_CAP) {
 		for(int node = tid; node < db.nNodes; node += 256) {
 			if(node == db.root || !(db.height[node] <= maxHeight)) continue;
-			uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
-			uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
-			if(bin <= thr) { uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
+			const uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+			if(seed_bin(d, N, thr + 1) <= thr) { uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
 		}
 		__syncthreads();
 		uint32_t n2 = 1;
@@ -138,9 +156,8 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 			unsigned long long best = ~0ull;
 			for(int node = tid; node < db.nNodes; node += 256) {
 				if(node == db.root || !(db.height[node] <= maxHeight)) continue;
-				uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
-				uint32_t bin = N ? (d << 12) / N : HU_TOPK_BINS;
-				if(bin > thr) continue;
+				const uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+				if(seed_bin(d, N, thr + 1) > thr) continue;
 				unsigned long long k = seed_key(d, N, (uint32_t) node);
 				if((first || k > last) && k < best) best = k;
 			}

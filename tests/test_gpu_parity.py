@@ -105,6 +105,12 @@ def test_align_parity(cfg):
     B.close(); D.close()
 
 
+def test_hbm_staged_viterbi_kernel(monkeypatch):
+    """reads too long for the LDS-staged wavefront take the HBM-staged kernel: same results"""
+    monkeypatch.setenv("HU_VITERBI_HBM", "1")
+    test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
+
+
 def test_align_modes_and_bad_reads():
     E = _engine()
     db = get_db(120, 700, "GTR", dg_k=4)
