@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	const int read = blockIdx.x, tid = threadIdx.x;
 	const uint32_t* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
 	const int per = (HU_TOPK_BINS + 1 + 255) / 256;
+	const bool useHeight = !(maxHeight == INFINITY);
 	/* the wanted seeds are the nearest nodes: histogram only distances < 1/4 first (the bulk of the
 	 * tree is farther and would serialise on a few hot LDS counters); fall back to all bins if short */
 	uint32_t limit = 1024;
@@ -87,11 +88,17 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 		for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
 		__syncthreads();
 		uint32_t over = 0;
-		for(int node = tid; node < db.nNodes; node += 256) {
-			if(node == db.root || !(db.height[node] <= maxHeight)) continue;
-			const uint32_t v = pr[node], bin = seed_bin(v >> 16, v & 0xffffu, limit);
-			if(bin == limit && limit < HU_TOPK_BINS) over++;
-			else atomicAdd(&hist[bin], 1u);
+		for(int base = tid * 4; base < db.nNodes; base += 1024) {
+			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
+			const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+			for(int e = 0; e < 4; ++e) {
+				const int node = base + e;
+				if(node >= db.nNodes || node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
+				const uint32_t bin = seed_bin(vv[e] >> 16, vv[e] & 0xffffu, limit);
+				if(bin == limit && limit < HU_TOPK_BINS) over++;
+				else atomicAdd(&hist[bin], 1u);
+			}
 		}
 		for(int m = 32; m > 0; m >>= 1) over += __shfl_xor(over, m);
 		if((tid & 63) == 0 && over) atomicAdd(&hist[limit], over);
@@ -123,10 +130,16 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
 	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
 	if(cntLE <= HU_TOPK_CAP) {
-		for(int node = tid; node < db.nNodes; node += 256) {
-			if(node == db.root || !(db.height[node] <= maxHeight)) continue;
-			const uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
-			if(seed_bin(d, N, thr + 1) <= thr) { uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
+		for(int base = tid * 4; base < db.nNodes; base += 1024) {
+			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
+			const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+			for(int e = 0; e < 4; ++e) {
+				const int node = base + e;
+				if(node >= db.nNodes || node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
+				const uint32_t d = vv[e] >> 16, N = vv[e] & 0xffffu;
+				if(seed_bin(d, N, thr + 1) <= thr) { uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
+			}
 		}
 		__syncthreads();
 		uint32_t n2 = 1;
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 		for(uint32_t s = 0; s < need; ++s) {
 			unsigned long long best = ~0ull;
 			for(int node = tid; node < db.nNodes; node += 256) {
-				if(node == db.root || !(db.height[node] <= maxHeight)) continue;
+				if(node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
 				const uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
 				if(seed_bin(d, N, thr + 1) > thr) continue;
 				unsigned long long k = seed_key(d, N, (uint32_t) node);
