@@ -146,6 +146,8 @@ def main():
     best = B.placements()
     cand = B.candidates()
     C = float(np.diff(cand["offs"]).mean())
+    place_iters = dict(outer_mean=float((cand["iters"] & 255).mean()), outer_max=int((cand["iters"] & 255).max()),
+                       em_mean=float((cand["iters"] >> 8).mean()), em_max=int((cand["iters"] >> 8).max()))
     S = 50
     scan_bytes = float((D.n_nodes - 1) * (en[ok] - st[ok] + 1).sum())          # (nNodes-1)*R per read, int8 sites
     peak = 8000.0
@@ -170,7 +172,7 @@ def main():
                                     "batch %d reads/step/GPU" % (D.n_nodes, args.cs_len, D.K, args.dg_k, args.read_len, args.batch),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
                roofline=roof, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()},
-               host_wall_ms={k: round(float(v), 2) for k, v in wall.items()})
+               host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
     # ---- CPU baseline: the oracle (line-faithful port) on this box's host cores, rank 0, N=1 only
     if rank == 0 and world == 1 and args.cpu_sample != 0:

@@ -798,7 +798,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		for(int64_t c = lo; c < hi; ++c) { /* PTUnrooted::placeSeq const (src/PhyloTreeUnrooted.cpp:936-952) */
 			HostPlace& p = pl[c - lo];
 			const HuPlaceOut& po = b->hPlaceOut[c];
-			p.loglik = ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters;
+			p.loglik = ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
 			p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
 			b->places[c] = p;
 		}

@@ -360,7 +360,7 @@ struct HuPlaceOut { double wnr, wur; int32_t iters, pad; };
 
 /* Felsenstein's EM for one branch (src/PhyloTreeUnrooted.cpp:749-798) on the per-site ratios
  * rho_j = A_j / B_j kept in LDS: p <- mean_j p0 / (rho_j q0 + p0); NaN sites are skipped. */
-__device__ inline double em_branch(const double* rho, int n, double w0, double maxL, int lane) {
+__device__ inline double em_branch(const double* rho, int n, double w0, double maxL, int lane, int& emIters) {
 	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0;
 	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
 		double s = 0, c = 0;
@@ -370,6 +370,7 @@ __device__ inline double em_branch(const double* rho, int n, double w0, double m
 		}
 		s = wave_sum(s); c = wave_sum(c);
 		p = s / c; q = 1 - p;
+		++emIters;
 		if(fabs(log(q) - log(q0)) < HU_BRANCH_EPS) break;
 		p0 = p; q0 = q;
 	}
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 	for(int i = 0; i < 4; ++i) pi2 += mdl.pi[i] * mdl.pi[i];
 	double api[4];
 	to_eig(mdl, mdl.pi, api);
-	int iter = 0;
+	int iter = 0, emIters = 0;
 	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
 		/* E tables for the u and v branches */
 		for(int i = lane; i < Kc * 4; i += 64) {
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 			rho[j] = r;
 		}
 		__syncthreads();
-		wnr = em_branch(rho, n, lenNR, 1.0, lane);
+		wnr = em_branch(rho, n, lenNR, 1.0, lane, emIters);
 		lenNR = wnr;
 		__syncthreads();
 		/* tables for the n branch: E, and P(wnr r_k) applied to each possible leaf vector */
@@ -477,12 +478,12 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 			rho[j] = A / (piX * piU);
 		}
 		__syncthreads();
-		wur = em_branch(rho, n, lenUR, w0j, lane);
+		wur = em_branch(rho, n, lenUR, w0j, lane, emIters);
 		lenUR = wur;
 		lenVR = w0j - wur;
 		__syncthreads();
 		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
 		wur0 = wur; wnr0 = wnr;
 	}
-	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = 0; out[blockIdx.x] = o; }
+	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
 }
