@@ -30,8 +30,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--leaves", type=int, default=int(os.environ.get("HU_BENCH_LEAVES", 99322)))
     ap.add_argument("--cs-len", type=int, default=7682)
     ap.add_argument("--read-len", type=int, default=250)
@@ -149,19 +149,30 @@ def main():
     place_iters = dict(outer_mean=float((cand["iters"] & 255).mean()), outer_max=int((cand["iters"] & 255).max()),
                        em_mean=float((cand["iters"] >> 8).mean()), em_max=int((cand["iters"] >> 8).max()))
     S = 50
-    scan_bytes = float((D.n_nodes - 1) * (en[ok] - st[ok] + 1).sum())          # (nNodes-1)*R per read, int8 sites
     peak = 8000.0
-    roof = dict(bound="hbm", kernel="k_seed_pdist", achieved=scan_bytes / (acc["seed_pdist"] * 1e-3) / 1e9, peak=peak, unit="GB/s",
-                traffic=None)
-    roof["frac"] = roof["achieved"] / peak
-    tfile = os.path.join(ROOT, "profiles", "traffic_seed_pdist.json")
+    nread = int(ok.sum())
+    Rsum = float((en[ok] - st[ok] + 1).sum())
+    Wp = args.read_len + 60
+    # algorithmic bytes per launch (SURVEY.md §8d per-unit figures x units of one launch)
+    alg = dict(viterbi=nread * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum, seed_topk=4.0 * D.n_nodes * nread,
+               estimate=S * 65.0 * Rsum, place=C * 64.0 * Rsum)
+    pmc_name = dict(viterbi="k_viterbi_lds", seed_pdist="k_seed_pdist<16>", seed_topk="k_seed_topk", estimate="k_estimate", place="k_place")
+    pmc = {}
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            roof["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(tfile))["kernels"]
         except Exception:
-            pass
-    W = args.read_len + 60
-    bytes_per_read = (D.n_nodes - 1) * R + S * 65 * R + C * 64 * R + args.read_len + 136 * W + args.cs_len + 128
+            pmc = {}
+    kern = []
+    for k in ("viterbi", "seed_pdist", "seed_topk", "estimate", "place"):
+        ms = acc[k]
+        tr = pmc.get(pmc_name[k], {}).get("hbm_bytes_per_launch") if args.batch == 8192 and args.leaves == 99322 else None
+        kern.append(dict(kernel=pmc_name[k], ms=round(ms, 3), algorithmic_bytes=alg[k], achieved=alg[k] / (ms * 1e-3) / 1e9, unit="GB/s",
+                         frac=alg[k] / (ms * 1e-3) / 1e9 / peak, traffic=tr, traffic_gbps=(tr / (ms * 1e-3) / 1e9 if tr else None)))
+    dom = max(kern, key=lambda x: x["ms"])
+    roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], traffic=dom["traffic"])
+    bytes_per_read = (D.n_nodes - 1) * R + S * 65 * R + C * 64 * R + args.read_len + 136 * Wp + args.cs_len + 128
     path = dict(bytes_per_read=bytes_per_read, achieved=bytes_per_read * value / world / 1e9, unit="GB/s per GPU",
                 frac=bytes_per_read * value / world / 1e9 / peak, mean_R=R, mean_candidates=C)
 
@@ -171,7 +182,7 @@ def main():
                config=dict(workload="gg_97_otus-scale synthetic DB (%d nodes x %d CS columns, K=%d), GTR+dGamma(%d), SE %d bp amplicon reads, "
                                     "batch %d reads/step/GPU" % (D.n_nodes, args.cs_len, D.K, args.dg_k, args.read_len, args.batch),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
-               roofline=roof, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()},
+               roofline=roof, roofline_kernels=kern, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()},
                host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
     # ---- CPU baseline: the oracle (line-faithful port) on this box's host cores, rank 0, N=1 only

@@ -580,7 +580,8 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			Timer t(b, HU_T_VITERBI);
 			if(vlds <= 96 * 1024 && !getenv("HU_VITERBI_HBM")) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
 				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
-				k_viterbi_lds<<<b->nSeq, 64, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
+				k_viterbi_lds<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
+				k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
 			}
 			else k_viterbi<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p);
 		}
@@ -863,6 +864,67 @@ extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
 }
 /* host wall-clock of the last hu_assign_batch: align | seed+estimate+filter | place | finish (ms) */
 extern "C" int hu_batch_wall(hu_batch* b, double* ms4) { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; }
+
+/* ------------------------------------------------------------------------------ host helpers */
+extern "C" int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6) {
+	if(!db || !cs || !out6) return HU_ERR_ARG;
+	(void) cs_end; (void) cs_to;
+	const std::vector<int32_t>& cs2p = db->prof.cs2p;
+	int start = 0, end = 0, from = 0, to = 0, nIns = 0, nDel = 0;
+	int i = cs_from, j = cs_start;
+	for(const char* c = cs; *c; ++c) {
+		const int k = (j >= 0 && j < (int) cs2p.size()) ? cs2p[j] : 0;   /* getProfileLoc */
+		const bool nonGap = host_sym(*c) >= 0;                            /* abc->isSymbol */
+		if(from == 0 && nonGap) from = i;
+		if(nonGap) to = i;
+		if(k != 0) { if(start == 0) start = k; end = k; if(!nonGap) nDel++; }
+		else if(nonGap) nIns++;
+		j++;
+		if(nonGap) i++;
+	}
+	out6[0] = start; out6[1] = end; out6[2] = from; out6[3] = to; out6[4] = nIns; out6[5] = nDel;
+	return HU_OK;
+}
+
+extern "C" const char* hu_tsv_header(void) {
+	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"
+	       "branch_id\tbranch_ratio\ttaxon_id\ttaxon_anno\tanno_dist\tloglik\tQ_placement\tQ_taxon";
+}
+
+/* operator<<(ostream&, double) at default precision == printf("%g") */
+static void put_g(std::string& o, double v) { char t[40]; snprintf(t, sizeof(t), "%g", v); o += t; }
+
+extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		char* buf, int64_t cap) {
+	if(!b || !ids) { hu_set_error("hu_batch_format_tsv: bad argument"); return HU_ERR_ARG; }
+	if(b->state < ST_FINISHED || b->fromCodes) { hu_set_error("hu_batch_format_tsv: batch is not finished"); return HU_ERR_STATE; }
+	const int L = b->db->dev.csLen;
+	std::vector<char> rows((size_t) b->n * L);
+	if(b->n) {
+		if(hipSetDevice(b->db->device) != hipSuccess || hipMemcpyAsync(rows.data(), b->dRows.p, rows.size(), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+				hipStreamSynchronize(b->stream) != hipSuccess) { hu_set_error("hu_batch_format_tsv: device copy failed"); return HU_ERR_DEVICE; }
+	}
+	std::string o;
+	for(int r = 0; r < b->n; ++r) {
+		const HuAlnDev& a = b->hAlns[r];
+		if(a.status != HU_READ_OK) continue;
+		const hu_place_rec& p = b->best[r];
+		o += ids[r]; o += '\t'; if(descs && descs[r]) o += descs[r]; o += '\t';
+		o += std::to_string(a.seqStart) + "\t" + std::to_string(a.seqEnd) + "\t" + std::to_string(a.hmmStart) + "\t" + std::to_string(a.hmmEnd) + "\t" +
+				std::to_string(a.csStart) + "\t" + std::to_string(a.csEnd) + "\t";
+		put_g(o, a.cost); o += '\t';
+		o.append(&rows[(size_t) r * L], L); o += '\t';
+		if(p.c_node >= 0) {
+			o += std::to_string(p.c_node) + "->" + std::to_string(p.p_node) + "\t"; put_g(o, p.ratio); o += '\t';
+			o += std::to_string(p.a_node) + "\t"; if(annos && annos[p.a_node]) o += annos[p.a_node]; o += '\t';
+			put_g(o, p.anno_dist); o += '\t'; put_g(o, p.loglik); o += '\t'; put_g(o, p.q_place); o += '\t'; put_g(o, p.q_taxon);
+		}
+		else o += "NULL\tnan\t-1\tUNASSIGNED\tnan\tnan\tnan\tnan"; /* default-constructed PTPlacement (src/PhyloTreeUnrooted.cpp:60-65) */
+		o += '\n';
+	}
+	if(buf && cap > 0) { const size_t m = std::min<size_t>((size_t) cap, o.size()); memcpy(buf, o.data(), m); }
+	return (int64_t) o.size();
+}
 
 /* ------------------------------------------------------------------------------ results */
 extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align, char* trace, int trace_stride) {

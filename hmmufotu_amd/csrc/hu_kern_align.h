@@ -276,16 +276,23 @@ __device__ inline void vit_trace(const HuDbDev& db, const VitCtx& ctx, const HuR
 /* LDS-staged variant: the last two anti-diagonals of the running phase live in LDS (three rotating
  * buffers x {M,I,D} x read length), so the inner loop touches HBM only to file each cell for the
  * traceback (fire-and-forget stores) and for the few perimeter cells that read an earlier phase.
- * The S minimum is tracked while filling.  One wave per sequence; DS operations of one wave
- * execute in order, so consecutive diagonals need no s_barrier and no vmcnt wait. */
-__global__ __launch_bounds__(64) void k_viterbi_lds(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+ * The S minimum is tracked while filling.  One workgroup of 4 waves per sequence: a 250-bp read has
+ * anti-diagonals of up to ~210 cells, so 256 lanes take a whole diagonal per step, and the LDS
+ * footprint (72 B x read length) caps a CU at 8 sequences = 32 waves, the full complement.
+ * Between diagonals only LDS must be ordered: s_waitcnt lgkmcnt(0) + s_barrier, never vmcnt. */
+#define HU_VIT_THREADS 256
+__device__ inline void vit_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(HU_VIT_THREADS) void k_viterbi_lds(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
 		double* __restrict__ scratch, char* __restrict__ traces, double tNN, double tNB, double tEC, double tCC,
 		HuVitOut* __restrict__ outs, int ldsRows) {
 	extern __shared__ double vsh[];
-	const int s = blockIdx.x, lane = threadIdx.x;
+	__shared__ double redS[HU_VIT_THREADS / 64];
+	__shared__ int redC[HU_VIT_THREADS / 64], redR[HU_VIT_THREADS / 64];
+	const int s = blockIdx.x, tid = threadIdx.x;
 	const HuReadDesc& rd = descs[s];
 	const int L = rd.len, K = db.K;
-	if(rd.nRegions <= 0) { if(lane == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	if(rd.nRegions <= 0) { if(tid == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
 	const char* __restrict__ x = bases + rd.baseOff;
 	double* scr = scratch + rd.scratchOff * 3;
 	VitCtx ctx = { &rd, scr, tNN, tNB };
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64) void k_viterbi_lds(HuDbDev db, const HuReadDesc
 			const double* p1 = vsh + (size_t)((dg + 2) % 3) * 3 * ldsRows;
 			const double* p2 = vsh + (size_t)((dg + 1) % 3) * 3 * ldsRows;
 			const int lo = dg - (nj - 1) > 0 ? dg - (nj - 1) : 0, hi = dg < ni - 1 ? dg : ni - 1;
-			for(int q = lo + lane; q <= hi; q += 64) {
+			for(int q = lo + tid; q <= hi; q += HU_VIT_THREADS) {
 				const int i = g.i0 + q, j = g.j0 + dg - q;
 				const int dist = (i - g.from) - (j - g.start);
 				if(g.band && !(dist <= g.nIns && dist >= -g.nDel)) continue;
@@ -340,16 +347,36 @@ __global__ __launch_bounds__(64) void k_viterbi_lds(HuDbDev db, const HuReadDesc
 					}
 				}
 			}
-			__builtin_amdgcn_wave_barrier();
+			vit_lds_barrier();
 		}
 	}
 	for(int m = 32; m > 0; m >>= 1) {
 		const double os = __shfl_xor(bestS, m); const int oc = __shfl_xor(bestCol, m), orow = __shfl_xor(bestRow, m);
 		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
 	}
-	__syncthreads(); /* every cell filed in HBM before lane 0 walks back through them */
-	if(lane != 0) return;
+	if((tid & 63) == 0) { redS[tid >> 6] = bestS; redC[tid >> 6] = bestCol; redR[tid >> 6] = bestRow; }
+	__syncthreads(); /* also: every cell filed in HBM before thread 0 walks back through them */
+	if(tid != 0) return;
+	for(int wv = 1; wv < HU_VIT_THREADS / 64; ++wv) {
+		const double os = redS[wv]; const int oc = redC[wv], orow = redR[wv];
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	/* the traceback runs in k_viterbi_trace, one LANE per sequence: it is a chain of dependent
+	 * loads, so thousands of them must be in flight at once, not one per workgroup */
 	HuVitOut o;
+	o.minScore = bestS; o.alnEnd = bestCol; o.alnTo = bestRow; o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
+	outs[s] = o;
+}
+
+__global__ __launch_bounds__(64) void k_viterbi_trace(HuDbDev db, const HuReadDesc* __restrict__ descs, const double* __restrict__ scratch,
+		char* __restrict__ traces, double tNN, double tNB, HuVitOut* __restrict__ outs, int nSeq) {
+	const int s = blockIdx.x * 64 + threadIdx.x;
+	if(s >= nSeq) return;
+	HuVitOut o = outs[s];
+	if(o.traceLen != -1) return; /* invalid read, or already traced */
+	const HuReadDesc& rd = descs[s];
+	VitCtx ctx = { &rd, scratch + rd.scratchOff * 3, tNN, tNB };
+	const double bestS = o.minScore; const int bestCol = o.alnEnd, bestRow = o.alnTo;
 	vit_trace(db, ctx, rd, traces, bestS, bestCol, bestRow, o);
 	outs[s] = o;
 }

@@ -192,6 +192,25 @@ __device__ inline double wave_sum(double x) {
 	for(int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m);
 	return x; /* butterfly: bitwise identical in every lane */
 }
+/* wave64 sum on the DPP network (quad_perm, row_half_mirror, row_mirror, row_bcast:15/31), total read
+ * back from lane 63 into SGPRs: ~18 VALU operations instead of 12 ds_bpermute round trips, and the
+ * result is wave-uniform by construction (loop control of the EM) */
+template<int CTRL, int ROW_MASK>
+__device__ inline double dpp_add(double v) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+	return v + __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum_uniform(double v) {
+	v = dpp_add<0xB1, 0xf>(v);   /* quad_perm:[1,0,3,2] */
+	v = dpp_add<0x4E, 0xf>(v);   /* quad_perm:[2,3,0,1] */
+	v = dpp_add<0x141, 0xf>(v);  /* row_half_mirror */
+	v = dpp_add<0x140, 0xf>(v);  /* row_mirror */
+	v = dpp_add<0x142, 0xa>(v);  /* row_bcast:15 into rows 1,3 */
+	v = dpp_add<0x143, 0xc>(v);  /* row_bcast:31 into rows 2,3 */
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
 __device__ inline double max4d(const double* v) { return fmax(fmax(v[0], v[1]), fmax(v[2], v[3])); }
 __device__ inline int argmax4d(const double* v) { /* Eigen maxCoeff(&i): first strict maximum */
 	int b = 0;
@@ -275,8 +294,11 @@ __device__ inline int argmax4_tied_lin(const double* z) {
 
 struct HuEstOut { double ratio, wnr, loglik; };
 
-/* one wave per (read, seed); lanes stride the sites of [start, end] */
-__global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+/* one wave per (read, seed); lanes stride the sites of [start, end].  UNR sites per loop trip: the
+ * loads of all of them are issued before the first is consumed (the kernel is bound by memory
+ * latency x occupancy, not by bandwidth: measured by capping waves per CU). */
+template<int UNR>
+__device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
@@ -303,26 +325,34 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 	{ double mx = max4d(mdl.logpi), sm; for(int i = 0; i < 4; ++i) piw[i] = exp(mdl.logpi[i] - mx); sm = (piw[0] + piw[2]) + (piw[1] + piw[3]); for(int i = 0; i < 4; ++i) piw[i] /= sm; }
 
 	/* z_i = (P(wur) e^U)_i (P(wvr) e^V)_i in linear space; log R_j = log z + (kU + kV) ln 2 */
-	auto siteZ = [&](int j, double* z) {
-		double e[4], a[4], c[4];
-		load4(db.up + (sOff + j) * 4, e);
-		if(wur == 0) { for(int i = 0; i < 4; ++i) z[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Eu, a, z); }
-		load4(db.down + (sOff + j) * 4, e);
-		if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = e[i]; } else { to_eig(mdl, e, a); conv_eig(mdl, Ev, a, c); }
+	auto zOf = [&](const double* eU, const double* eV, double* z) {
+		double a[4], c[4];
+		if(wur == 0) { for(int i = 0; i < 4; ++i) z[i] = eU[i]; } else { to_eig(mdl, eU, a); conv_eig(mdl, Eu, a, z); }
+		if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = eV[i]; } else { to_eig(mdl, eV, a); conv_eig(mdl, Ev, a, c); }
 		for(int i = 0; i < 4; ++i) z[i] *= c[i];
 	};
 	double dsum = 0, nsum = 0;
-	for(int j = start + lane; j <= end; j += 64) {
-		double z[4];
-		siteZ(j, z);
-		const int b = cd[j];
-		const int b1 = argmax4_tied_lin(z), b2 = b >= 0 ? b : piMax;
-		if(!weighted) { if(b1 != b2) dsum += 1; }
-		else {
-			double w1 = sel4(z, b1) / ((z[0] + z[2]) + (z[1] + z[3]));
-			double w2 = b >= 0 ? 1.0 : piw[b2];
-			if(b1 != b2) dsum += w1 * w2;
-			nsum += w1 * w2;
+	for(int j0 = start + lane; j0 <= end; j0 += 64 * UNR) {
+		double eU[UNR][4], eV[UNR][4]; int bb[UNR];
+#pragma unroll
+		for(int t = 0; t < UNR; ++t) {
+			const int j = j0 + 64 * t <= end ? j0 + 64 * t : j0;
+			load4(db.up + (sOff + j) * 4, eU[t]); load4(db.down + (sOff + j) * 4, eV[t]); bb[t] = cd[j];
+		}
+#pragma unroll
+		for(int t = 0; t < UNR; ++t) {
+			if(j0 + 64 * t > end) continue;
+			double z[4];
+			zOf(eU[t], eV[t], z);
+			const int b = bb[t];
+			const int b1 = argmax4_tied_lin(z), b2 = b >= 0 ? b : piMax;
+			if(!weighted) { if(b1 != b2) dsum += 1; }
+			else {
+				double w1 = sel4(z, b1) / ((z[0] + z[2]) + (z[1] + z[3]));
+				double w2 = b >= 0 ? 1.0 : piw[b2];
+				if(b1 != b2) dsum += w1 * w2;
+				nsum += w1 * w2;
+			}
 		}
 	}
 	dsum = wave_sum(dsum);
@@ -336,17 +366,28 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 	{ double a[4]; to_eig(mdl, mdl.pi, a); if(wnr == 0) { for(int i = 0; i < 4; ++i) Ppi[i] = mdl.pi[i]; } else conv_eig(mdl, En, a, Ppi); }
 	double ll = 0;
 	long long ksum = 0;
-	for(int j = start + lane; j <= end; j += 64) {
-		double z[4], c[4];
-		siteZ(j, z);
-		const int b = cd[j];
-		if(b >= 0) {
-			if(wnr == 0) { for(int i = 0; i < 4; ++i) c[i] = i == b ? 1.0 : 0.0; }
-			else { double a[4]; for(int k = 0; k < 4; ++k) a[k] = mdl.U1[k*4+b]; conv_eig(mdl, En, a, c); }
+	for(int j0 = start + lane; j0 <= end; j0 += 64 * UNR) {
+		double eU[UNR][4], eV[UNR][4]; int bb[UNR]; int kk[UNR];
+#pragma unroll
+		for(int t = 0; t < UNR; ++t) {
+			const int j = j0 + 64 * t <= end ? j0 + 64 * t : j0;
+			load4(db.up + (sOff + j) * 4, eU[t]); load4(db.down + (sOff + j) * 4, eV[t]); bb[t] = cd[j];
+			kk[t] = db.upK[sOff + j] + db.downK[sOff + j];
 		}
-		else for(int i = 0; i < 4; ++i) c[i] = Ppi[i];
-		ll += log((mdl.pi[0] * z[0] * c[0] + mdl.pi[2] * z[2] * c[2]) + (mdl.pi[1] * z[1] * c[1] + mdl.pi[3] * z[3] * c[3]));
-		ksum += (long long) db.upK[sOff + j] + (long long) db.downK[sOff + j];
+#pragma unroll
+		for(int t = 0; t < UNR; ++t) {
+			if(j0 + 64 * t > end) continue;
+			double z[4], c[4];
+			zOf(eU[t], eV[t], z);
+			const int b = bb[t];
+			if(b >= 0) {
+				if(wnr == 0) { for(int i = 0; i < 4; ++i) c[i] = i == b ? 1.0 : 0.0; }
+				else { double a[4]; for(int k = 0; k < 4; ++k) a[k] = mdl.U1[k*4+b]; conv_eig(mdl, En, a, c); }
+			}
+			else for(int i = 0; i < 4; ++i) c[i] = Ppi[i];
+			ll += log((mdl.pi[0] * z[0] * c[0] + mdl.pi[2] * z[2] * c[2]) + (mdl.pi[1] * z[1] * c[1] + mdl.pi[3] * z[3] * c[3]));
+			ksum += (long long) kk[t];
+		}
 	}
 	ll = wave_sum(ll);
 	for(int m = 32; m > 0; m >>= 1) ksum += __shfl_xor(ksum, m);
@@ -354,21 +395,47 @@ __global__ __launch_bounds__(64) void k_estimate(HuDbDev db, HuModelDev mdl, con
 	if(lane == 0) { HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = ll; out[(size_t) read * HU_MAX_SEEDS + s] = o; }
 }
 
+#define HU_EST_KERNEL(NAME, UNR, MINW) \
+__global__ __launch_bounds__(64, MINW) void NAME(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes, \
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs, \
+		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN, \
+		int weighted, HuEstOut* __restrict__ out) { \
+	estimate_body<UNR>(db, mdl, codes, rstart, rend, pairs, seedCnt, seedId, seedDN, weighted, out); \
+}
+/* measured on MI355X (8192 reads, R = 1363): UNR 1 -> 12.3 ms, 2 -> 12.4, 4 -> 13.3 (register pressure
+ * costs a wave per SIMD); forcing 5-6 waves per SIMD spills and doubles the time.  At UNR 1 the kernel
+ * moves 76.6 GB per launch (PMC) = 6.2 TB/s, the achievable HBM rate. */
+HU_EST_KERNEL(k_estimate, 1, 1)
+
 /* ------------------------------------------------------------------------------------------ */
 struct HuCand { int32_t read, node; double ratio0, wnr0; };
 struct HuPlaceOut { double wnr, wur; int32_t iters, pad; };
 
 /* Felsenstein's EM for one branch (src/PhyloTreeUnrooted.cpp:749-798) on the per-site ratios
- * rho_j = A_j / B_j kept in LDS: p <- mean_j p0 / (rho_j q0 + p0); NaN sites are skipped. */
+ * rho_j = A_j / B_j kept in LDS: p <- mean_j p0 / (rho_j q0 + p0); NaN sites are skipped (their count
+ * does not change between iterations and is taken once).  The quotient is a reciprocal refined by two
+ * Newton steps (full double precision for finite non-zero denominators, IEEE division otherwise). */
 __device__ inline double em_branch(const double* rho, int n, double w0, double maxL, int lane, int& emIters) {
 	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0;
+	double c = 0;
+	for(int j = lane; j < n; j += 64) c += isnan(rho[j]) ? 0.0 : 1.0;
+	c = wave_sum_uniform(c);
 	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
-		double s = 0, c = 0;
+		double s = 0;
 		for(int j = lane; j < n; j += 64) {
-			double r = rho[j];
-			if(!isnan(r)) { s += p0 / (r * q0 + p0); c += 1; }
+			const double r = rho[j];
+			const double x = fma(r, q0, p0);
+			double t;
+			if(x > 1e-300 && x < 1e300) {
+				double y = __builtin_amdgcn_rcp(x);
+				y = fma(y, fma(-x, y, 1.0), y);
+				y = fma(y, fma(-x, y, 1.0), y);
+				t = p0 * y;
+			}
+			else t = p0 / x;
+			s += isnan(r) ? 0.0 : t;
 		}
-		s = wave_sum(s); c = wave_sum(c);
+		s = wave_sum_uniform(s);
 		p = s / c; q = 1 - p;
 		++emIters;
 		if(fabs(log(q) - log(q0)) < HU_BRANCH_EPS) break;
@@ -379,14 +446,52 @@ __device__ inline double em_branch(const double* rho, int n, double w0, double m
 	return w;
 }
 
-/* One wave per candidate placement.  Messages stay in linear space, scaled by their own
- * maximum; P(t r_k) acts in the eigenbasis so a category costs 4 mul + 16 fma per message.
- * The r->v message of the reference's outer iteration is never read by anything and is not
- * evaluated.  LDS: rho[n] + E tables + leaf-conv table. */
-__global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+/* per-site bodies of the two sweeps of one outer iteration (see k_place) */
+struct PlaceCtx {
+	const HuModelDev* mdl; const double* Etab; const double* Ltab; int Kc; double lenUR, lenVR, pi2;
+};
+__device__ inline double place_site_rn(const PlaceCtx& c, const double* eU, const double* eV, int b) {
+	const HuModelDev& mdl = *c.mdl;
+	double aU[4], aV[4];
+	to_eig(mdl, eU, aU); to_eig(mdl, eV, aV);
+	double X[4] = {0, 0, 0, 0};
+	for(int k = 0; k < c.Kc; ++k) {
+		double cu[4], cv[4];
+		if(c.lenUR == 0) { for(int i = 0; i < 4; ++i) cu[i] = eU[i]; } else conv_eig(mdl, c.Etab + k * 4, aU, cu);
+		if(c.lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, c.Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
+		for(int i = 0; i < 4; ++i) X[i] += cu[i] * cv[i];
+	}
+	const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
+	if(b >= 0) return sel4(X, b) / piX;
+	return ((mdl.pi[0] * mdl.pi[0] * X[0] + mdl.pi[2] * mdl.pi[2] * X[2]) + (mdl.pi[1] * mdl.pi[1] * X[1] + mdl.pi[3] * mdl.pi[3] * X[3])) / (piX * c.pi2);
+}
+__device__ inline double place_site_ru(const PlaceCtx& c, const double* eU, const double* eV, int b) {
+	const HuModelDev& mdl = *c.mdl;
+	double aV[4];
+	to_eig(mdl, eV, aV);
+	const int bi = b >= 0 ? b : 4;
+	double X[4] = {0, 0, 0, 0};
+	for(int k = 0; k < c.Kc; ++k) {
+		double cv[4];
+		if(c.lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, c.Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
+		const double* cn = c.Ltab + (k * 5 + bi) * 4;
+		for(int i = 0; i < 4; ++i) X[i] += cv[i] * cn[i];
+	}
+	const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
+	const double piU = (mdl.pi[0] * eU[0] + mdl.pi[2] * eU[2]) + (mdl.pi[1] * eU[1] + mdl.pi[3] * eU[3]);
+	const double A = (mdl.pi[0] * X[0] * eU[0] + mdl.pi[2] * X[2] * eU[2]) + (mdl.pi[1] * X[1] * eU[1] + mdl.pi[3] * X[3] * eU[3]);
+	return A / (piX * piU);
+}
+
+/* One wave per candidate placement.  Messages stay in linear space (packed at load time); P(t r_k)
+ * acts in the eigenbasis so a category costs 4 mul + 16 fma per message.  The r->v message of the
+ * reference's outer iteration is never read by anything and is not evaluated.
+ * LDS: rho[n] + E tables + leaf-conv table.  PAIR: two sites per loop trip (loads of both issued
+ * before either is consumed). */
+template<bool PAIR>
+__device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out) {
-	extern __shared__ double lds[];
+		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, double* lds) {
 	const int lane = threadIdx.x;
 	const HuCand cd = cands[blockIdx.x];
 	const int read = cd.read, u = cd.node;
@@ -417,24 +522,23 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 			Etab[1 * HU_MAX_DGK * 4 + i] = exp(l * (lenVR * r));
 		}
 		__syncthreads();
+		PlaceCtx pc = { &mdl, Etab, Ltab, Kc, lenUR, lenVR, pi2 };
 		/* (i) message r->n from children u, v; EM on the n-r branch against the read's leaf message */
-		for(int j = lane; j < n; j += 64) {
-			double eU[4], eV[4], aU[4], aV[4];
-			load4(Ub + (size_t) j * 4, eU); to_eig(mdl, eU, aU);
-			load4(Vb + (size_t) j * 4, eV); to_eig(mdl, eV, aV);
-			double X[4] = {0, 0, 0, 0};
-			for(int k = 0; k < Kc; ++k) {
-				double cu[4], cv[4];
-				if(lenUR == 0) { for(int i = 0; i < 4; ++i) cu[i] = eU[i]; } else conv_eig(mdl, Etab + k * 4, aU, cu);
-				if(lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
-				for(int i = 0; i < 4; ++i) X[i] += cu[i] * cv[i];
+		if(PAIR) {
+			for(int j = lane; j < n; j += 128) {
+				const int j2 = j + 64; const bool two = j2 < n; const int jj = two ? j2 : j;
+				double eU[4], eV[4], fU[4], fV[4];
+				load4(Ub + (size_t) j * 4, eU); load4(Vb + (size_t) j * 4, eV);
+				load4(Ub + (size_t) jj * 4, fU); load4(Vb + (size_t) jj * 4, fV);
+				const int b = cdr[j], b2 = cdr[jj];
+				rho[j] = place_site_rn(pc, eU, eV, b);
+				if(two) rho[j2] = place_site_rn(pc, fU, fV, b2);
 			}
-			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
-			const int b = cdr[j];
-			double r;
-			if(b >= 0) r = sel4(X, b) / piX;
-			else r = ((mdl.pi[0] * mdl.pi[0] * X[0] + mdl.pi[2] * mdl.pi[2] * X[2]) + (mdl.pi[1] * mdl.pi[1] * X[1] + mdl.pi[3] * mdl.pi[3] * X[3])) / (piX * pi2);
-			rho[j] = r;
+		}
+		else for(int j = lane; j < n; j += 64) {
+			double eU[4], eV[4];
+			load4(Ub + (size_t) j * 4, eU); load4(Vb + (size_t) j * 4, eV);
+			rho[j] = place_site_rn(pc, eU, eV, cdr[j]);
 		}
 		__syncthreads();
 		wnr = em_branch(rho, n, lenNR, 1.0, lane, emIters);
@@ -459,23 +563,21 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 		}
 		__syncthreads();
 		/* (ii) message r->u from children v, n; EM on the u-r branch against u's own message */
-		for(int j = lane; j < n; j += 64) {
-			double eU[4], eV[4], aV[4];
-			load4(Ub + (size_t) j * 4, eU);
-			load4(Vb + (size_t) j * 4, eV); to_eig(mdl, eV, aV);
-			const int b = cdr[j];
-			const int bi = b >= 0 ? b : 4;
-			double X[4] = {0, 0, 0, 0};
-			for(int k = 0; k < Kc; ++k) {
-				double cv[4];
-				if(lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
-				const double* cn = Ltab + (k * 5 + bi) * 4;
-				for(int i = 0; i < 4; ++i) X[i] += cv[i] * cn[i];
+		if(PAIR) {
+			for(int j = lane; j < n; j += 128) {
+				const int j2 = j + 64; const bool two = j2 < n; const int jj = two ? j2 : j;
+				double eU[4], eV[4], fU[4], fV[4];
+				load4(Ub + (size_t) j * 4, eU); load4(Vb + (size_t) j * 4, eV);
+				load4(Ub + (size_t) jj * 4, fU); load4(Vb + (size_t) jj * 4, fV);
+				const int b = cdr[j], b2 = cdr[jj];
+				rho[j] = place_site_ru(pc, eU, eV, b);
+				if(two) rho[j2] = place_site_ru(pc, fU, fV, b2);
 			}
-			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
-			const double piU = (mdl.pi[0] * eU[0] + mdl.pi[2] * eU[2]) + (mdl.pi[1] * eU[1] + mdl.pi[3] * eU[3]);
-			const double A = (mdl.pi[0] * X[0] * eU[0] + mdl.pi[2] * X[2] * eU[2]) + (mdl.pi[1] * X[1] * eU[1] + mdl.pi[3] * X[3] * eU[3]);
-			rho[j] = A / (piX * piU);
+		}
+		else for(int j = lane; j < n; j += 64) {
+			double eU[4], eV[4];
+			load4(Ub + (size_t) j * 4, eU); load4(Vb + (size_t) j * 4, eV);
+			rho[j] = place_site_ru(pc, eU, eV, cdr[j]);
 		}
 		__syncthreads();
 		wur = em_branch(rho, n, lenUR, w0j, lane, emIters);
@@ -487,3 +589,13 @@ __global__ __launch_bounds__(64) void k_place(HuDbDev db, HuModelDev mdl, const 
 	}
 	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
 }
+
+#define HU_PLACE_KERNEL(NAME, PAIR, MINW) \
+__global__ __launch_bounds__(64, MINW) void NAME(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes, \
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out) { \
+	extern __shared__ double lds[]; \
+	place_body<PAIR>(db, mdl, codes, rstart, rend, cands, out, lds); \
+}
+/* measured (same setting): one site per trip 27.6 ms, two sites per trip 26.5 ms, either with a
+ * forced 4 waves per SIMD 28.3-29.7 ms (spills) */
+HU_PLACE_KERNEL(k_place, true, 1)

@@ -212,6 +212,12 @@ class Database:
         _chk(load_library().hu_db_model_pr(self.h, C.c_int(len(t)), _p(t, C.c_double), _p(P, C.c_double)))
         return P
 
+    def build_align_path(self, cs_start, cs_end, cs: str, cs_from, cs_to):
+        out = np.zeros(6, np.int32)
+        _chk(load_library().hu_build_align_path(self.h, C.c_int(cs_start), C.c_int(cs_end), cs.encode(), C.c_int(cs_from), C.c_int(cs_to),
+                                                _p(out, C.c_int32)))
+        return out
+
     def profile(self):
         K = self.K
         out = dict(EM=np.zeros((K + 1, 4)), EI=np.zeros((K + 1, 4)), T=np.zeros((K + 1, 7)), p2cs=np.zeros(K + 1, np.int32),
@@ -336,6 +342,18 @@ class Batch:
         out = np.zeros(self.n, PLACE_DTYPE)
         _chk(load_library().hu_batch_get_placements(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def format_tsv(self, ids, descs=None, annos=None) -> str:
+        lib = load_library()
+        lib.hu_batch_format_tsv.restype = C.c_int64
+        arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
+        a_ids, a_desc, a_anno = arr(ids), arr(descs), arr(annos)
+        need = lib.hu_batch_format_tsv(self.h, a_ids, a_desc, a_anno, None, C.c_int64(0))
+        if need < 0:
+            _chk(int(need))
+        buf = C.create_string_buffer(int(need) + 1)
+        lib.hu_batch_format_tsv(self.h, a_ids, a_desc, a_anno, buf, C.c_int64(need))
+        return buf.raw[:need].decode("latin1")
 
     def close(self):
         if self.h:

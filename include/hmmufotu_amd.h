@@ -143,6 +143,11 @@ int hu_db_get_model(const hu_db* db, hu_model_desc* out);
 /* device-side DNASubModel::Pr(t) (src/GTR.h:116-121 and friends), for parity tests */
 int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P /* [n][16] row-major */);
 
+/* BandedHMMP7::buildAlignPath (src/BandedHMMP7.cpp:894-941): the CSLoc of a CSFM hit (1-based CS
+ * start/end + the gapped CS string, src/CSLoc.h) and the seed's 1-based read range -> the
+ * ViterbiAlignPath row {start,end,from,to,nIns,nDel} hu_batch_set_reads takes.  Host only. */
+int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6);
+
 /* ---- batch ------------------------------------------------------------------------------ */
 int hu_batch_create(hu_db* db, int max_reads, hu_batch** out);
 void hu_batch_destroy(hu_batch* b);
@@ -186,6 +191,17 @@ int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* logl
 /* all candidates after placement, in filterPlacements order: offs [n+1]; arrays sized offs[n] */
 int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters);
 int hu_batch_get_placements(hu_batch* b, hu_place_rec* best /* [n] */);
+
+/* One TSV line per read exactly as the main loop prints it (src/hmmufotu.cpp:736-739: id, description,
+ * HmmAlignment operator<< src/BandedHMMP7.cpp:1215-1221, PTPlacement::write
+ * src/PhyloTreeUnrooted.h:1611-1617; doubles at the default 6-significant-digit ostream precision).
+ * ids/descs: n C strings; annos: taxon annotation per NODE (may be NULL -> empty column).  Reads whose
+ * status is not HU_READ_OK produce no line, like the reference.  Writes into buf (capacity cap) and
+ * returns the number of bytes needed (call again with a larger buffer if > cap). */
+int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		char* buf, int64_t cap);
+/* the header line of the assignment file (src/hmmufotu.cpp:592-594) */
+const char* hu_tsv_header(void);
 
 /* ---- measurement ------------------------------------------------------------------------
  * per-kernel device time of the LAST call of each stage, measured with HIP events on the

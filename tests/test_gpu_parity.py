@@ -296,3 +296,43 @@ def test_db_load_from_reference_formats(tmp_path):
     for k in ("c_node", "a_node", "ratio", "wnr", "q_place"):
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
     D1.close(); D2.close()
+
+
+def test_build_align_path_and_tsv():
+    """host helpers of the ABI: buildAlignPath against the oracle, and the TSV line format"""
+    E = _engine()
+    from hmmufotu_amd import synth
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 12, 150)
+    D = E.Database.from_synth(db)
+    for r in reads[:6]:
+        for sf in (0, 5, len(r.seq) - 20):
+            c0, c1 = int(r.cols[sf]), int(r.cols[sf + 19])
+            s = ["-"] * (c1 - c0 + 1)
+            for k in range(20):
+                s[int(r.cols[sf + k]) - c0] = r.seq[sf + k]
+            cs = "".join(s)
+            assert list(D.build_align_path(c0 + 1, c1 + 1, cs, sf + 1, sf + 20)) == list(H.build_align_path(c0 + 1, c1 + 1, cs, sf + 1, sf + 20))
+    seqs = [r.seq for r in reads]
+    seqs[2] = "?" + seqs[2][1:]                                   # invalid read: no TSV line
+    B = E.Batch(D, 16)
+    B.set_reads(seqs, vps)
+    B.assign(E.default_opts())
+    ids = ["r%d" % i for i in range(len(seqs))]
+    tsv = B.format_tsv(ids, ["desc %d" % i for i in range(len(seqs))], db.annos)
+    lines = tsv.strip("\n").split("\n")
+    assert len(lines) == len(seqs) - 1 and all(not l.startswith("r2\t") for l in lines)
+    best = B.placements(); alns = B.alignments()
+    for l in lines:
+        f = l.split("\t")
+        assert len(f) == 18
+        i = int(f[0][1:])
+        rec, b = alns["recs"][i], best[i]
+        assert f[1] == "desc %d" % i
+        assert [int(x) for x in f[2:8]] == [rec[k] for k in ("seq_start", "seq_end", "hmm_start", "hmm_end", "cs_start", "cs_end")]
+        assert f[8] == "%g" % rec["cost"] and f[9] == alns["align"][i] and len(f[9]) == db.cs_len
+        assert f[10] == "%d->%d" % (b["c_node"], b["p_node"]) and f[11] == "%g" % b["ratio"]
+        assert int(f[12]) == b["a_node"] and f[13] == db.annos[b["a_node"]]
+        assert f[14] == "%g" % b["anno_dist"] and f[15] == "%g" % b["loglik"] and f[16] == "%g" % b["q_place"] and f[17] == "%g" % b["q_taxon"]
+    B.close(); D.close()
