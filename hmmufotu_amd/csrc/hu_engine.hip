@@ -15,6 +15,7 @@
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 #include "hu_kern_align.h"
+#include "hu_kern_tree.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
 	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
@@ -301,6 +302,71 @@ extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpy(P, dP, (size_t) n * 128, hipMemcpyDeviceToHost));
 	(void) hipFree(dt); (void) hipFree(dP);
+	return HU_OK;
+}
+
+/* ------------------------------------------------------------------------------ tree pre-evaluation */
+extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent, const double* blen, int8_t* seq,
+		const hu_model_desc* model, int device, int64_t win_start, int64_t win_len, double* up_dev, double* down_dev, double* height) {
+	if(n < 2 || cs_len < 1 || !parent || !blen || !seq || !model || !up_dev || !down_dev) { hu_set_error("hu_tree_evaluate: bad argument"); return HU_ERR_ARG; }
+	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
+	if(win_len <= 0) { win_start = 0; win_len = cs_len; }
+	if(win_start < 0 || win_start + win_len > cs_len) { hu_set_error("hu_tree_evaluate: window out of range"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(device));
+	HuModelDev mdl;
+	int rc = hu_model_prepare(model, &mdl);
+	if(rc != HU_OK) return rc;
+	int root = -1;
+	std::vector<int32_t> cnt(n + 1, 0), depth(n, -1);
+	for(int i = 0; i < n; ++i) {
+		if(parent[i] < 0) { if(root >= 0) { hu_set_error("tree has more than one root"); return HU_ERR_ARG; } root = i; }
+		else if(parent[i] >= n) { hu_set_error("parent of node %d out of range", i); return HU_ERR_ARG; }
+		else cnt[parent[i] + 1]++;
+	}
+	if(root < 0) { hu_set_error("tree has no root"); return HU_ERR_ARG; }
+	for(int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+	std::vector<int32_t> childIdx(std::max(n - 1, 1)), fill(cnt.begin(), cnt.end() - 1);
+	for(int i = 0; i < n; ++i) if(parent[i] >= 0) childIdx[fill[parent[i]]++] = i;   /* children in node-id order */
+	/* depths by BFS from the root (no assumption on node numbering) */
+	std::vector<int32_t> order; order.reserve(n); order.push_back(root); depth[root] = 0;
+	for(size_t h = 0; h < order.size(); ++h) { const int u = order[h]; for(int c = cnt[u]; c < cnt[u + 1]; ++c) { depth[childIdx[c]] = depth[u] + 1; order.push_back(childIdx[c]); } }
+	if((int) order.size() != n) { hu_set_error("tree is not connected"); return HU_ERR_ARG; }
+	int maxD = 0;
+	for(int i = 0; i < n; ++i) maxD = std::max(maxD, depth[i]);
+	std::vector<int32_t> lvOff(maxD + 2, 0);
+	for(int i = 0; i < n; ++i) lvOff[depth[i] + 1]++;
+	for(int d = 0; d <= maxD; ++d) lvOff[d + 1] += lvOff[d];
+	/* BFS order is already sorted by depth */
+	HuTreeDev t;
+	t.n = n; t.csLen = cs_len; t.root = root; t.winStart = win_start; t.winLen = win_len; t.up = up_dev; t.down = down_dev;
+	int32_t *dPar = nullptr, *dOff = nullptr, *dIdx = nullptr, *dOrd = nullptr; double* dLen = nullptr; int8_t* dSeq = nullptr;
+	auto cleanup = [&]() { (void) hipFree(dPar); (void) hipFree(dOff); (void) hipFree(dIdx); (void) hipFree(dOrd); (void) hipFree(dLen); (void) hipFree(dSeq); };
+	#define TCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { hu_set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return HU_ERR_DEVICE; } } while(0)
+	TCHK(hipMalloc((void**) &dPar, (size_t) n * 4)); TCHK(hipMalloc((void**) &dOff, (size_t)(n + 1) * 4)); TCHK(hipMalloc((void**) &dIdx, childIdx.size() * 4));
+	TCHK(hipMalloc((void**) &dOrd, (size_t) n * 4)); TCHK(hipMalloc((void**) &dLen, (size_t) n * 8)); TCHK(hipMalloc((void**) &dSeq, (size_t) n * cs_len));
+	TCHK(hipMemcpy(dPar, parent, (size_t) n * 4, hipMemcpyHostToDevice)); TCHK(hipMemcpy(dOff, cnt.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+	TCHK(hipMemcpy(dIdx, childIdx.data(), childIdx.size() * 4, hipMemcpyHostToDevice)); TCHK(hipMemcpy(dOrd, order.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+	TCHK(hipMemcpy(dLen, blen, (size_t) n * 8, hipMemcpyHostToDevice)); TCHK(hipMemcpy(dSeq, seq, (size_t) n * cs_len, hipMemcpyHostToDevice));
+	t.parent = dPar; t.blen = dLen; t.childOff = dOff; t.childIdx = dIdx; t.seq = dSeq;
+	(void) hipGetLastError();
+	const unsigned gx = (unsigned)((win_len + 255) / 256);
+	for(int d = maxD; d >= 0; --d) { /* post-order by levels */
+		const int m = lvOff[d + 1] - lvOff[d];
+		for(int a = 0; a < m; a += 65535) k_tree_up<<<dim3(gx, std::min(65535, m - a)), 256>>>(t, mdl, dOrd + lvOff[d] + a);
+	}
+	for(int d = 1; d <= maxD; ++d) { /* pre-order by levels */
+		const int m = lvOff[d + 1] - lvOff[d];
+		for(int a = 0; a < m; a += 65535) k_tree_down<<<dim3(gx, std::min(65535, m - a)), 256>>>(t, mdl, dOrd + lvOff[d] + a);
+	}
+	TCHK(hipGetLastError());
+	TCHK(hipDeviceSynchronize());
+	TCHK(hipMemcpy(seq, dSeq, (size_t) n * cs_len, hipMemcpyDeviceToHost));
+	#undef TCHK
+	cleanup();
+	if(height) { /* calcNodeHeight: distance to the nearest descendant leaf (src/PhyloTreeUnrooted.cpp:274-287) */
+		for(int i = 0; i < n; ++i) height[i] = cnt[i] == cnt[i + 1] ? 0.0 : kInf;
+		for(int h = n - 1; h > 0; --h) { const int u = order[h], p = parent[u]; height[p] = std::min(height[p], height[u] + blen[u]); }
+	}
 	return HU_OK;
 }
 

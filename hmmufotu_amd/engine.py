@@ -157,6 +157,19 @@ def parse_files(hmm_path=None, ptu_path=None):
     return out
 
 
+def tree_evaluate(parent, blen, seq, model: ModelDesc, up_ptr: int, down_ptr: int, win_start=0, win_len=0, device=0):
+    """hu_tree_evaluate: fills the DEVICE buffers at up_ptr/down_ptr ([n][win_len][4] float64, log space),
+    returns (seq with inferred inner rows, heights)."""
+    parent = np.ascontiguousarray(parent, np.int32); blen = np.ascontiguousarray(blen, np.float64)
+    seq = np.ascontiguousarray(seq, np.int8).copy()
+    n, L = seq.shape
+    h = np.zeros(n)
+    _chk(load_library().hu_tree_evaluate(C.c_int32(n), C.c_int32(L), _p(parent, C.c_int32), _p(blen, C.c_double), _p(seq, C.c_int8),
+                                         C.byref(model), C.c_int(device), C.c_int64(win_start), C.c_int64(win_len),
+                                         C.c_void_p(int(up_ptr)), C.c_void_p(int(down_ptr)), _p(h, C.c_double)))
+    return seq, h
+
+
 class Database:
     """Profile + pre-evaluated tree packed once into HBM (hu_db)."""
 

@@ -95,61 +95,15 @@ def make_db_gpu(n_leaves: int, cs_len: int, model_name="GTR", dg_k=0, dg_alpha=0
     w0, wl = (0, cs_len) if win is None else (int(win[0]), int(win[1]))
     up = torch.empty((n, wl, 4), dtype=torch.float64, device=device)
     down = torch.zeros((n, wl, 4), dtype=torch.float64, device=device)
-    logpi = torch.tensor(np.log(model.pi), device=device)
-    eye = torch.full((5, 4), float("-inf"), dtype=torch.float64, device=device)
-    eye[4] = logpi
-    for i in range(4):
-        eye[i, i] = 0.0
-    for a in range(0, len(leaf_idx), chunk * 4):
-        li = leaf_d[a:a + chunk * 4]
-        codes = seq[li, w0:w0 + wl].long()
-        codes = torch.where(codes >= 0, codes, torch.full_like(codes, 4))
-        up[li] = eye[codes]
-    child1 = np.full(n, -1, np.int64); child2 = np.full(n, -1, np.int64)
-    for i in range(1, n):
-        p = parent[i]
-        if child1[p] < 0:
-            child1[p] = i
-        else:
-            child2[p] = i
-    P_d = lambda idx: torch.tensor(Pall[idx], device=device)
-    use_dg = dg_k > 0
-    for lv in reversed(levels):
-        inner = lv[~is_leaf[lv]]
-        for a in range(0, len(inner), chunk):
-            idx = inner[a:a + chunk]
-            c1, c2 = child1[idx], child2[idx]
-            X = _conv(P_d(c1), up[torch.tensor(c1, device=device)]) + _conv(P_d(c2), up[torch.tensor(c2, device=device)])
-            up[torch.tensor(idx, device=device)] = _row_mean_exp(X) if use_dg else X[:, 0]
-    log("up pass: %.1fs" % (time.time() - t0))
-    sib = np.full(n, -1, np.int64)
-    for i in range(1, n):
-        p = parent[i]
-        sib[i] = child2[p] if child1[p] == i else child1[p]
-    for lv in levels[1:]:
-        for a in range(0, len(lv), chunk):
-            idx = lv[a:a + chunk]
-            s = sib[idx]; p = parent[idx]
-            X = _conv(P_d(s), up[torch.tensor(s, device=device)])
-            nr = p != 0
-            if nr.any():
-                pi_ = p[nr]
-                X[torch.tensor(np.nonzero(nr)[0], device=device)] += _conv(P_d(pi_), down[torch.tensor(pi_, device=device)])
-            # reference sums [parent, sibling] in that order; addition of two terms commutes
-            down[torch.tensor(idx, device=device)] = _row_mean_exp(X) if use_dg else X[:, 0]
-    log("down pass: %.1fs" % (time.time() - t0))
-    # ---- ancestral sequences: argmax of the up message inside the window; the true simulated
-    # ancestor outside it (never read: reads only touch window columns)
-    inner_idx = np.nonzero(~is_leaf)[0]
-    for a in range(0, len(inner_idx), chunk * 4):
-        ii = torch.tensor(inner_idx[a:a + chunk * 4], device=device)
-        seq[ii, w0:w0 + wl] = up[ii].argmax(-1).to(torch.int8)
+    # messages, ancestral sequences and heights by the engine's own tree pre-evaluation kernels
+    # (hu_tree_evaluate); tests/test_gpu_parity.py checks them against the oracle
+    from . import engine as E
+    md = E.model_desc(model.type_id, model.pi, model.par, r if dg_k > 0 else None)
+    torch.cuda.synchronize()
     seq_h = seq.cpu().numpy()
-    height = np.full(n, np.inf)
-    height[is_leaf] = 0.0
-    for i in range(n - 1, 0, -1):                       # preorder numbering: children after parents
-        p = parent[i]
-        height[p] = min(height[p], height[i] + blen[i])
+    seq_h, height = E.tree_evaluate(parent, blen, seq_h, md, up.data_ptr(), down.data_ptr(), w0, wl if win is not None else 0,
+                                    device=torch.device(device).index or 0)
+    log("tree pre-evaluation (up + down): %.1fs" % (time.time() - t0))
     sub = leaf_idx[rng.choice(len(leaf_idx), size=min(len(leaf_idx), 4000), replace=False)]
     leaves = seq_h[sub]
     n_taxa = 64

@@ -143,6 +143,17 @@ int hu_db_get_model(const hu_db* db, hu_model_desc* out);
 /* device-side DNASubModel::Pr(t) (src/GTR.h:116-121 and friends), for parity tests */
 int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P /* [n][16] row-major */);
 
+/* ---- tree pre-evaluation (the core of hmmufotu-build) ---------------------
+ * Messages of every directed edge by a post-order and a pre-order sweep, equivalent to the reference's
+ * "setRoot(i); evaluate()" loop over all nodes (src/hmmufotu-build.cpp:454-459), with the discrete
+ * Gamma averaging of src/PhyloTreeUnrooted.cpp:320-346; ancestral sequences by per-site argmax
+ * (src/PhyloTreeUnrooted.cpp:1085-1093), node heights (:274-287).  seq [n][cs_len] holds the leaf
+ * rows on entry; inner rows are filled inside the column window.  up_dev/down_dev are DEVICE buffers
+ * [n][win_len][4] (log space, the .ptu convention; up[root] = root message) that can be handed to
+ * hu_db_create with msgs_on_device = 1. */
+int hu_tree_evaluate(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const double* blen, int8_t* seq,
+		const hu_model_desc* model, int device, int64_t win_start, int64_t win_len, double* up_dev, double* down_dev, double* height);
+
 /* BandedHMMP7::buildAlignPath (src/BandedHMMP7.cpp:894-941): the CSLoc of a CSFM hit (1-based CS
  * start/end + the gapped CS string, src/CSLoc.h) and the seed's 1-based read range -> the
  * ViterbiAlignPath row {start,end,from,to,nIns,nDel} hu_batch_set_reads takes.  Host only. */

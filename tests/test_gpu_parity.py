@@ -336,3 +336,33 @@ def test_build_align_path_and_tsv():
         assert int(f[12]) == b["a_node"] and f[13] == db.annos[b["a_node"]]
         assert f[14] == "%g" % b["anno_dist"] and f[15] == "%g" % b["loglik"] and f[16] == "%g" % b["q_place"] and f[17] == "%g" % b["q_taxon"]
     B.close(); D.close()
+
+
+@pytest.mark.parametrize("model,dg_k", [("GTR", 4), ("GTR", 0), ("K80", 0), ("TN93", 3)])
+def test_tree_pre_evaluation(model, dg_k):
+    """hu_tree_evaluate (device two-pass pruning) vs the oracle's restatement of
+    loglik/evaluate: every directed-edge message, the ancestral argmax sequences and the node heights"""
+    E = _engine()
+    import torch
+    from oracle import oracle_py as O
+    db = get_db(60, 300, model, dg_k=dg_k, seed=13)
+    n, L = db.seq.shape
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if dg_k else None)
+    leaf_only = np.where(db.is_leaf[:, None], db.seq, 0).astype(np.int8)
+    for (w0, wl) in ((0, 0), (40, 200)):
+        W = wl or L
+        up = torch.full((n, W, 4), 7.0, dtype=torch.float64, device="cuda:0"); down = torch.zeros_like(up)
+        seq, h = E.tree_evaluate(db.parent, db.blen, leaf_only, md, up.data_ptr(), down.data_ptr(), w0, wl)
+        torch.cuda.synchronize()
+        m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+        oup, odown, oseq, oh = O.tree_evaluate(db.parent, db.blen, leaf_only, m, db.dg_r if dg_k else None)
+        gu, gd = up.cpu().numpy(), down.cpu().numpy()
+        ou, od = oup[:, w0:w0 + W], odown[:, w0:w0 + W]
+        fin = np.isfinite(ou)
+        assert (np.isfinite(gu) == fin).all()
+        assert np.abs(gu[fin] - ou[fin]).max() < 1e-9 * max(1.0, np.abs(ou[fin]).max())
+        assert np.abs(gd[1:] - od[1:]).max() < 1e-9 * max(1.0, np.abs(od[1:]).max())
+        inner = ~db.is_leaf
+        assert (seq[inner][:, w0:w0 + W] == oseq[inner][:, w0:w0 + W]).all()
+        assert (seq[db.is_leaf] == leaf_only[db.is_leaf]).all()
+        assert np.abs(h - oh).max() < 1e-12 and np.abs(h - db.height).max() < 1e-12
