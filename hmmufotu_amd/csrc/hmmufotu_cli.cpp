@@ -1,0 +1,194 @@
+// hmmufotu-amd — command-line driver with the option surface of the reference's `hmmufotu`
+// (src/hmmufotu.cpp:71-110, defaults :37-57) around the batched engine.  Host C++ only: option parsing,
+// FASTA/FASTQ reading, the seed scans (hu_seed_index_*), strand auto-detection (:500-542), batching, TSV.
+// Not implemented (out of scope this round): -C/--chimera*, -a alignment FASTA output,
+// --align-only, gz/bz2 inputs.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "../../include/hmmufotu_amd.h"
+
+struct Read { std::string id, desc, seq; };
+
+static bool next_read(std::istream& in, bool fastq, Read& r) {
+	std::string line;
+	r = Read();
+	if(fastq) {
+		while(std::getline(in, line)) if(!line.empty() && line[0] == '@') break;
+		if(!in || line.empty() || line[0] != '@') return false;
+		std::string q, plus;
+		if(!std::getline(in, r.seq) || !std::getline(in, plus) || !std::getline(in, q)) return false;
+	}
+	else {
+		while(std::getline(in, line)) if(!line.empty() && line[0] == '>') break;
+		if(!in || line.empty() || line[0] != '>') return false;
+		while(in.peek() != EOF && in.peek() != '>') { std::string s; std::getline(in, s); while(!s.empty() && (s.back() == '\r' || s.back() == ' ')) s.pop_back(); r.seq += s; }
+	}
+	const size_t sp = line.find_first_of(" \t");
+	r.id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+	if(sp != std::string::npos) r.desc = line.substr(sp + 1);
+	while(!r.seq.empty() && (r.seq.back() == '\r' || r.seq.back() == '\n')) r.seq.pop_back();
+	for(char& c : r.seq) c = (char) toupper((unsigned char) c);
+	return true;
+}
+static std::string revcom(const std::string& s) { /* IUPACNucl complements (src/IUPACNucl.cpp:52-71) */
+	std::string r(s.rbegin(), s.rend());
+	for(char& c : r) switch(c) {
+		case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'U': c = 'A'; break;
+		case 'Y': c = 'R'; break; case 'R': c = 'Y'; break; case 'K': c = 'M'; break; case 'M': c = 'K'; break;
+		case 'B': c = 'V'; break; case 'V': c = 'B'; break; case 'D': c = 'H'; break; case 'H': c = 'D'; break; default: break; }
+	return r;
+}
+static void usage(const char* p) {
+	std::cerr << "Usage:    " << p << "  <HmmUFOtu-DB> <READ-FILE1> [READ-FILE2] [options]\n"
+		"Options:    -o FILE  -L|--seed-len INT [20]  -R INT [50]  --single  -s|--strand INT [0]  -t|--test INT [100]\n"
+		"            -i|--ignore  -N INT [50]  -d|--max-diff DBL  -H|--max-height DBL  -e|--err DBL [20]\n"
+		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
+		"            --batch INT [8192]  --gpu INT [0]  -v  -h|--help\n";
+}
+#define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
+
+struct Packed { std::string bases; std::vector<int64_t> offs{0}; std::vector<int32_t> vp;
+	void add(const std::string& s) { bases += s; offs.push_back((int64_t) bases.size()); }
+	void clear() { bases.clear(); offs.assign(1, 0); vp.clear(); } int n() const { return (int) offs.size() - 1; } };
+
+int main(int argc, char** argv) {
+	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
+	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, verbose = 0;
+	bool single = false;
+	hu_opts o; hu_default_opts(&o);
+	std::string cmd;
+	for(int i = 0; i < argc; ++i) { cmd += argv[i]; cmd += i + 1 < argc ? " " : ""; }
+	for(int i = 1; i < argc; ++i) {
+		std::string a = argv[i];
+		auto val = [&]() -> const char* { if(i + 1 >= argc) { std::cerr << "Error: option " << a << " needs a value\n"; exit(EXIT_FAILURE); } return argv[++i]; };
+		if(a == "-h" || a == "--help") { usage(argv[0]); return EXIT_SUCCESS; }
+		else if(a == "-o") outFn = val();
+		else if(a == "-L" || a == "--seed-len") seedLen = atoi(val());
+		else if(a == "-R") seedRegion = atoi(val());
+		else if(a == "--single") single = true;
+		else if(a == "-s" || a == "--strand") strand = atoi(val());
+		else if(a == "-t" || a == "--test") nTest = atoi(val());
+		else if(a == "-i" || a == "--ignore") o.ignore_orient = 1;
+		else if(a == "-N") o.max_nseed = atoi(val());
+		else if(a == "-d" || a == "--max-diff") o.max_diff = atof(val());
+		else if(a == "-H" || a == "--max-height") o.max_height = atof(val());
+		else if(a == "-e" || a == "--err") o.max_error = atof(val());
+		else if(a == "-m" || a == "--method") method = val();
+		else if(a == "--ML") o.only_ml = 1;
+		else if(a == "--prior") prior = val();
+		else if(a == "--fmt") fmt = val();
+		else if(a == "--batch") batch = atoi(val());
+		else if(a == "--gpu") gpu = atoi(val());
+		else if(a == "-v") verbose++;
+		else if(a == "-S" || a == "--seed" || a == "-p" || a == "--process") (void) val(); /* accepted, no effect: lookups are deterministic */
+		else if(a[0] == '-' && a.size() > 1) { std::cerr << "Error: unknown option " << a << std::endl; usage(argv[0]); return EXIT_FAILURE; }
+		else pos.push_back(a);
+	}
+	if(pos.size() < 2 || pos.size() > 3) { usage(argv[0]); return EXIT_FAILURE; }
+	/* validation as src/hmmufotu.cpp:293-348 */
+	if(seedLen < 15 || seedLen > 25) { std::cerr << "-L|--seed-len must be in range [15, 25]" << std::endl; return EXIT_FAILURE; }
+	if(seedRegion < seedLen) { std::cerr << "-R cannot be smaller than -L" << std::endl; return EXIT_FAILURE; }
+	if(strand < 0 || strand > 2) { std::cerr << "-s|--strand must be 0, 1, or 2" << std::endl; return EXIT_FAILURE; }
+	if(o.max_nseed < 1 || o.max_nseed > 64) { std::cerr << "-N must be in range [1, 64]" << std::endl; return EXIT_FAILURE; }
+	if(!(o.max_error >= 0)) { std::cerr << "-e|--err must be non-negative" << std::endl; return EXIT_FAILURE; }
+	if(method != "unweighted" && method != "weighted") { std::cerr << "-m|--method must be either 'unweighted' or 'weighted'" << std::endl; return EXIT_FAILURE; }
+	if(prior != "uniform" && prior != "height") { std::cerr << "--prior must be either 'uniform' or 'height'" << std::endl; return EXIT_FAILURE; }
+	o.weighted = method == "weighted"; o.prior = prior == "height" ? HU_PRIOR_HEIGHT : HU_PRIOR_UNIFORM;
+	const bool paired = pos.size() == 3;
+	o.align_mode = (paired || !single) ? HU_MODE_GLOBAL : HU_MODE_NGCL;               /* src/hmmufotu.cpp:358 */
+	std::string fwdFn = pos[1], revFn = paired ? pos[2] : "";
+	auto is_fastq = [&](const std::string& fn) { if(!fmt.empty()) return fmt == "fastq"; return fn.size() > 2 && (fn.rfind(".fastq") == fn.size() - 6 || fn.rfind(".fq") == fn.size() - 3); };
+
+	hu_db* db = nullptr;
+	CHK(hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), gpu, &db));
+	int32_t K, L, nNodes, root; int64_t hbm;
+	CHK(hu_db_info(db, &K, &L, &nNodes, &root, &hbm));
+	if(verbose) std::cerr << "database loaded: K=" << K << " csLen=" << L << " nodes=" << nNodes << " HBM=" << hbm / 1e9 << " GB" << std::endl;
+	std::vector<int32_t> parent(nNodes), p2cs(K + 1); std::vector<int8_t> seq((size_t) nNodes * L);
+	CHK(hu_db_get_tree(db, parent.data(), nullptr, seq.data(), nullptr));
+	CHK(hu_db_get_profile(db, nullptr, nullptr, nullptr, p2cs.data(), nullptr, nullptr));
+	hu_seed_index* ix = nullptr;
+	CHK(hu_seed_index_create(nNodes, L, parent.data(), seq.data(), K, p2cs.data(), seedLen, &ix));
+	if(verbose) std::cerr << "seed index built: " << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers" << std::endl;
+	hu_batch* gb = nullptr;
+	CHK(hu_batch_create(db, batch, &gb));
+
+	/* strand auto-detection on the first nTest reads by alignment cost (src/hmmufotu.cpp:500-542) */
+	if(strand == 0) {
+		std::ifstream tin(fwdFn);
+		if(!tin) { std::cerr << "Unable to test forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
+		Packed f, r; Read rd;
+		for(int i = 0; i < nTest && i < batch && next_read(tin, is_fastq(fwdFn), rd); ++i) { f.add(rd.seq); r.add(revcom(rd.seq)); }
+		double fwdScore = 0, revScore = 0;
+		std::vector<hu_align_rec> af(f.n()), ar(f.n());
+		if(f.n() > 0) {
+			f.vp.resize((size_t) f.n() * 12); r.vp.resize((size_t) f.n() * 12);
+			CHK(hu_seed_index_lookup(ix, f.n(), f.bases.data(), f.offs.data(), seedRegion, o.align_mode, f.vp.data()));
+			CHK(hu_seed_index_lookup(ix, r.n(), r.bases.data(), r.offs.data(), seedRegion, o.align_mode, r.vp.data()));
+			CHK(hu_batch_set_reads(gb, f.n(), f.bases.data(), f.offs.data(), f.vp.data(), nullptr, nullptr, nullptr));
+			CHK(hu_align_batch(gb, &o)); CHK(hu_batch_get_alignments(gb, af.data(), nullptr, nullptr, 0));
+			CHK(hu_batch_set_reads(gb, r.n(), r.bases.data(), r.offs.data(), r.vp.data(), nullptr, nullptr, nullptr));
+			CHK(hu_align_batch(gb, &o)); CHK(hu_batch_get_alignments(gb, ar.data(), nullptr, nullptr, 0));
+			for(int i = 0; i < f.n(); ++i) {
+				const double cf = af[i].status == HU_READ_OK ? af[i].cost : INFINITY, cr = ar[i].status == HU_READ_OK ? ar[i].cost : INFINITY;
+				if(cf < cr) fwdScore++; else revScore++;
+			}
+		}
+		if(fwdScore >= (fwdScore + revScore) * 0.9) strand = 1;
+		else if(revScore >= (fwdScore + revScore) * 0.9) strand = 2;
+		else { std::cerr << "Failed to determine read strandness. Try larger -t|--test or determine manually" << std::endl; return EXIT_FAILURE; }
+		if(verbose) std::cerr << "Read strand determined as " << strand << std::endl;
+	}
+	if(strand == 2 && paired) std::swap(fwdFn, revFn);
+	std::ifstream fin(fwdFn), rin;
+	if(!fin) { std::cerr << "Unable to open forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
+	if(paired) { rin.open(revFn); if(!rin) { std::cerr << "Unable to open reverse seq file '" << revFn << "'" << std::endl; return EXIT_FAILURE; } }
+	std::ofstream fout; if(!outFn.empty()) { fout.open(outFn); if(!fout) { std::cerr << "Unable to write to '" << outFn << "'" << std::endl; return EXIT_FAILURE; } }
+	std::ostream& out = outFn.empty() ? std::cout : fout;
+	out << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << hu_tsv_header() << "\n";
+
+	std::vector<const char*> annos(nNodes);
+	for(int i = 0; i < nNodes; ++i) annos[i] = hu_db_get_annotation(db, i);
+	Packed f, r; std::vector<std::string> ids, descs;
+	long total = 0, placed = 0;
+	auto flush = [&]() -> int {
+		const int n = f.n();
+		if(n == 0) return HU_OK;
+		f.vp.assign((size_t) n * 12, 0);
+		int rc;
+		if((rc = hu_seed_index_lookup(ix, n, f.bases.data(), f.offs.data(), seedRegion, o.align_mode, f.vp.data())) != HU_OK) return rc;
+		if(paired) { r.vp.assign((size_t) n * 12, 0); if((rc = hu_seed_index_lookup(ix, n, r.bases.data(), r.offs.data(), seedRegion, o.align_mode, r.vp.data())) != HU_OK) return rc; }
+		if((rc = hu_batch_set_reads(gb, n, f.bases.data(), f.offs.data(), f.vp.data(), paired ? r.bases.data() : nullptr, paired ? r.offs.data() : nullptr,
+				paired ? r.vp.data() : nullptr)) != HU_OK) return rc;
+		if((rc = hu_assign_batch(gb, &o)) != HU_OK) return rc;
+		std::vector<const char*> pid(n), pdesc(n);
+		for(int i = 0; i < n; ++i) { pid[i] = ids[i].c_str(); pdesc[i] = descs[i].c_str(); }
+		const int64_t need = hu_batch_format_tsv(gb, pid.data(), pdesc.data(), annos.data(), nullptr, 0);
+		if(need < 0) return (int) need;
+		std::string buf((size_t) need, '\0');
+		hu_batch_format_tsv(gb, pid.data(), pdesc.data(), annos.data(), &buf[0], need);
+		out << buf;
+		for(char c : buf) if(c == '\n') placed++;
+		total += n;
+		f.clear(); r.clear(); ids.clear(); descs.clear();
+		return HU_OK;
+	};
+	Read a, b;
+	while(next_read(fin, is_fastq(fwdFn), a) && (!paired || next_read(rin, is_fastq(revFn), b))) {
+		std::string s = a.seq;
+		if(strand == 2 && !paired) s = revcom(s);          /* wrong strand for single-strand reads (src/hmmufotu.cpp:617-618) */
+		f.add(s); ids.push_back(a.id); descs.push_back(a.desc);
+		if(paired) r.add(revcom(b.seq));                   /* mates are reverse-complemented at read time (:609) */
+		if(f.n() == batch) CHK(flush());
+	}
+	CHK(flush());
+	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << std::endl;
+	hu_batch_destroy(gb); hu_seed_index_destroy(ix); hu_db_destroy(db);
+	return EXIT_SUCCESS;
+}

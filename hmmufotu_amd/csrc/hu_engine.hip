@@ -45,6 +45,7 @@ struct hu_db {
 	std::vector<int32_t> parent, annoId;
 	std::vector<double> blen, height, annoDist;
 	std::vector<int8_t> seq;
+	std::vector<std::string> annos, names;   /* only when loaded from a .ptu */
 	std::vector<void*> allocs;
 	int64_t hbmBytes = 0;
 };
@@ -216,7 +217,9 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	memset(&td, 0, sizeof(td));
 	td.n_nodes = t.n; td.cs_len = t.csLen; td.parent = t.parent.data(); td.blen = t.blen.data(); td.seq = t.seq.data();
 	td.up = t.up.data(); td.down = t.down.data(); td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
-	return hu_db_create(&pd, &td, &t.model, device, out);
+	rc = hu_db_create(&pd, &td, &t.model, device, out);
+	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; }
+	return rc;
 }
 
 /* host-only parse of the two files (no device needed): used by the format tests */
@@ -276,6 +279,10 @@ extern "C" int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, in
 	if(parent) memcpy(parent, db->parent.data(), db->parent.size() * 4); if(blen) memcpy(blen, db->blen.data(), db->blen.size() * 8);
 	if(seq) memcpy(seq, db->seq.data(), db->seq.size()); if(height) memcpy(height, db->height.data(), db->height.size() * 8);
 	return HU_OK;
+}
+extern "C" const char* hu_db_get_annotation(const hu_db* db, int32_t node) {
+	if(!db || node < 0 || node >= (int32_t) db->annos.size()) return "";
+	return db->annos[node].c_str();
 }
 extern "C" int hu_db_get_model(const hu_db* db, hu_model_desc* out) { if(!db || !out) return HU_ERR_ARG; *out = db->mdesc; return HU_OK; }
 

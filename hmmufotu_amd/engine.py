@@ -73,7 +73,7 @@ def build_library(force: bool = False) -> str:
     deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".cpp", ".h"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "hmmufotu_amd.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps):
-        subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src, "-B", "all"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -168,6 +168,35 @@ def tree_evaluate(parent, blen, seq, model: ModelDesc, up_ptr: int, down_ptr: in
                                          C.byref(model), C.c_int(device), C.c_int64(win_start), C.c_int64(win_len),
                                          C.c_void_p(int(up_ptr)), C.c_void_p(int(down_ptr)), _p(h, C.c_double)))
     return seq, h
+
+
+class SeedIndex:
+    """Host k-mer index standing in for the CSFM lookup of alignSeq (hu_seed_index_*)."""
+
+    def __init__(self, parent, seq, hmm, seed_len=20):
+        self.parent = np.ascontiguousarray(parent, np.int32); self.seq = np.ascontiguousarray(seq, np.int8)
+        self.p2cs = np.ascontiguousarray(hmm.p2cs, np.int32)
+        n, L = self.seq.shape
+        self.h = C.c_void_p()
+        _chk(load_library().hu_seed_index_create(C.c_int32(n), C.c_int32(L), _p(self.parent, C.c_int32), _p(self.seq, C.c_int8),
+                                                 C.c_int32(int(hmm.K)), _p(self.p2cs, C.c_int32), C.c_int32(seed_len), C.byref(self.h)))
+        lib = load_library(); lib.hu_seed_index_size.restype = C.c_int64
+        self.size = int(lib.hu_seed_index_size(self.h))
+
+    def lookup(self, reads, seed_region=50, align_mode=0):
+        n = len(reads)
+        cat = "".join(reads).encode("latin1")
+        offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
+        vp = np.zeros((n, 2, 6), np.int32)
+        _chk(load_library().hu_seed_index_lookup(self.h, C.c_int(n), cat, _p(offs, C.c_int64), C.c_int(seed_region), C.c_int(align_mode),
+                                                 _p(vp, C.c_int32)))
+        return vp
+
+    def __del__(self):
+        try:
+            load_library().hu_seed_index_destroy(self.h)
+        except Exception:
+            pass
 
 
 class Database:

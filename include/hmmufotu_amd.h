@@ -140,6 +140,8 @@ int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double* T, int32_
 		double* entry_cost, double* exit_cost);
 int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, int8_t* seq, double* height);
 int hu_db_get_model(const hu_db* db, hu_model_desc* out);
+/* PTUNode::getAnno() of a node of a database loaded with hu_db_load ("" otherwise) */
+const char* hu_db_get_annotation(const hu_db* db, int32_t node);
 /* device-side DNASubModel::Pr(t) (src/GTR.h:116-121 and friends), for parity tests */
 int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P /* [n][16] row-major */);
 
@@ -158,6 +160,19 @@ int hu_tree_evaluate(int32_t n_nodes, int32_t cs_len, const int32_t* parent, con
  * start/end + the gapped CS string, src/CSLoc.h) and the seed's 1-based read range -> the
  * ViterbiAlignPath row {start,end,from,to,nIns,nDel} hu_batch_set_reads takes.  Host only. */
 int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6);
+
+/* ---- host seed lookup -----------------------------------------------------
+ * Stand-in for CSFMIndex::locateOne + BandedHMMP7::buildAlignPath as alignSeq uses them
+ * (src/HmmUFOtu_main.cpp:50-84): a hash index over the seed_len-mers of the leaf sequences.  Takes the
+ * FIRST occurrence where the reference draws a random one (src/CSFMIndex.cpp:139).  Host only. */
+typedef struct hu_seed_index hu_seed_index;
+int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
+		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out);
+void hu_seed_index_destroy(hu_seed_index* ix);
+int64_t hu_seed_index_size(const hu_seed_index* ix);
+/* the 5' and (GLOBAL mode) 3' seed scans for n reads -> vpaths [n][2][6] for hu_batch_set_reads */
+int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
+		int align_mode, int32_t* vpaths);
 
 /* ---- batch ------------------------------------------------------------------------------ */
 int hu_batch_create(hu_db* db, int max_reads, hu_batch** out);

