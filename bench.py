@@ -100,11 +100,17 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(nb)
 
+    timed_ms = [dict() for _ in range(nb)]
+    timed_n = [0] * nb
+
     def run_steps(i, steps):
         out = None
         for _ in range(steps):
             batches[i].assign(opts)
             out = batches[i].placements()
+            for k, v in batches[i].timings().items():       # HIP events on this batch's stream, every timed step
+                timed_ms[i][k] = timed_ms[i].get(k, 0.0) + v
+            timed_n[i] += 1
         return out
 
     def run(total):
@@ -112,7 +118,11 @@ def main():
         futs = [pool.submit(run_steps, i, share[i]) for i in range(nb) if share[i]]
         return [f.result() for f in futs]
 
+    for B in batches:
+        B.profile(True)
     run(args.warmup)
+    for i in range(nb):
+        timed_ms[i].clear(); timed_n[i] = 0
     barrier()
     t1 = time.perf_counter()
     recs = run(args.steps)[-1]
@@ -128,18 +138,23 @@ def main():
     value = total_reads / dt
 
     # ---- per-kernel device times (HIP events on the batch's stream) + roofline of the scan kernel
-    B = batches[0]
-    B.profile(True)
+    # kernel time inside the timed region (two batches in flight: kernels of both streams share the GPU)
     acc = {}
+    for i in range(nb):
+        for k, v in timed_ms[i].items():
+            acc[k] = acc.get(k, 0.0) + v
+    acc = {k: v / max(1, sum(timed_n)) for k, v in acc.items()}
+    # and with one batch alone on the GPU
+    B = batches[0]
+    iso = {}
     nprof = 3
     wall = {}
     for _ in range(nprof):
         B.assign(opts)
         for k, v in B.timings().items():
-            acc[k] = acc.get(k, 0.0) + v / nprof
+            iso[k] = iso.get(k, 0.0) + v / nprof
         for k, v in B.wall().items():
             wall[k] = wall.get(k, 0.0) + v / nprof
-    B.profile(False)
     cd, st, en = B.codes()
     ok = en >= st
     R = float((en[ok] - st[ok] + 1).mean())
@@ -156,7 +171,7 @@ def main():
     # algorithmic bytes per launch (SURVEY.md §8d per-unit figures x units of one launch)
     alg = dict(viterbi=nread * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum, seed_topk=4.0 * D.n_nodes * nread,
                estimate=S * 65.0 * Rsum, place=C * 64.0 * Rsum)
-    pmc_name = dict(viterbi="k_viterbi_lds", seed_pdist="k_seed_pdist<16>", seed_topk="k_seed_topk", estimate="k_estimate", place="k_place")
+    pmc_name = dict(viterbi="k_viterbi_lds", seed_pdist="k_seed_pdist<16>", seed_topk="k_seed_topk", estimate="k_estimate_blk<6, 256>", place="k_place")
     pmc = {}
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile):
@@ -183,6 +198,7 @@ def main():
                                     "batch %d reads/step/GPU" % (D.n_nodes, args.cs_len, D.K, args.dg_k, args.read_len, args.batch),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
                roofline=roof, roofline_kernels=kern, roofline_path=path, kernel_ms={k: round(v, 3) for k, v in acc.items()},
+               kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},
                host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
     # ---- CPU baseline: the oracle (line-faithful port) on this box's host cores, rank 0, N=1 only

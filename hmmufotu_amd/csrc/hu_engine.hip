@@ -16,6 +16,7 @@
 #include "hu_kern_sep.h"
 #include "hu_kern_align.h"
 #include "hu_kern_tree.h"
+#include "hu_kern_blk.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
 	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
@@ -751,8 +752,22 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 	(void) hipGetLastError();
 	if(n) {
 		Timer t(b, HU_T_ESTIMATE);
-		k_estimate<<<b->n * HU_MAX_SEEDS, 64, 0, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p,
-				b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p);
+		int maxR = 1;
+		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
+		const bool stream = getenv("HU_STREAMING_SEP") != nullptr;
+		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
+		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
+		/* register-resident variant (messages cross HBM once) while a read's region fits 256 x SPT sites, the
+		 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
+		 * streaming 12.3 ms with twice the HBM traffic. */
+		const int spt = (maxR + 255) / 256;
+		if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 4) k_estimate_blk<4, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 6) k_estimate_blk<6, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());
 	b->state = ST_ESTIMATED;
@@ -833,7 +848,18 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_PLACE);
-			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p);
+			int spt = getenv("HU_STREAMING_SEP") ? 99 : (maxR + HU_BLK_THREADS - 1) / HU_BLK_THREADS;
+			if(!getenv("HU_PLACE_BLK")) spt = 99; /* measured: the 4-wave register-resident variant is slower (57.9 vs 26.2 ms): one wave per SIMD cannot hide the EM's dependent chains */
+			const char* pl = getenv("HU_PLACE_LDS");
+			const size_t ldsx = pl ? std::max(lds, (size_t) atoi(pl)) : lds;
+			#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
+			if(spt <= 2) k_place_blk<2><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 4) k_place_blk<4><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 6) k_place_blk<6><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 8) k_place_blk<8><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 12) k_place_blk<12><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else k_place<<<(unsigned) nc, 64, ldsx, b->stream>>>(PL_ARGS);
+			#undef PL_ARGS
 		}
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->hPlaceOut.data(), b->dPlaceOut.p, nc * sizeof(HuPlaceOut), hipMemcpyDeviceToHost, b->stream));
