@@ -421,3 +421,94 @@ def test_cli_end_to_end(tmp_path):
     assert subprocess.run([cli, pre, fa, "-L", "30"], capture_output=True).returncode != 0
     assert subprocess.run([cli, str(tmp_path / "nodb"), fa], capture_output=True).returncode != 0
     B.close(); D.close()
+
+
+def test_edge_cases_small_tree_short_reads_and_window():
+    """fewer eligible nodes than max_nseed (NaN distances sort last), reads shorter than the seed
+    length (full DP), a database resident only for a column window"""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(16, 300, "GTR", dg_k=4, seed=21)                 # 31 nodes < 50 seeds
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 10, 60)
+    seqs = [r.seq for r in reads]
+    seqs[0] = seqs[0][:12]; vps[0] = 0                            # shorter than a 20-mer: no seed, full Viterbi
+    seqs[1] = seqs[1][:1]; vps[1] = 0                             # a single base
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, seqs, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+    out = B.alignments(want_align=True); cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds(); best = B.placements()
+    for i, s in enumerate(seqs):
+        a = H.align(s, vps[i])
+        assert out["recs"][i]["status"] == 1 and a["ok"] and out["align"][i] == a["align"] and out["recs"][i]["cost"] == a["cost"], i
+        res = T.assign(cd[i], int(st[i]), int(en[i]), O.default_opts())
+        k = len(res["seed_ids"])
+        assert k == db.n_nodes - 1 == cnt[i] and (ids[i, :k] == res["seed_ids"]).all(), i    # every non-root node, NaN last
+        assert best[i]["n_cand"] == res["n"]
+    B.close(); D.close()
+    # column-window residency: same placements as the fully resident database; reads outside are refused
+    db2 = get_db(120, 700, "GTR", dg_k=4)
+    reads, vps = sim_reads(db2, 8, 120)
+    md = E.model_desc(db2.model.type_id, db2.model.pi, db2.model.par, db2.dg_r)
+    Dfull = E.Database.from_synth(db2)
+    lo, hi = 20, 690
+    Dwin = E.Database.from_arrays(db2.hmm, db2.parent, db2.blen, db2.seq, db2.up[:, lo:hi].copy(), db2.down[:, lo:hi].copy(), db2.height, md,
+                                  db2.anno_id, db2.anno_dist, win_start=lo, win_len=hi - lo)
+    res = []
+    for D in (Dfull, Dwin):
+        B = E.Batch(D, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts); res.append(B.placements().copy()); B.close()
+    for k in ("c_node", "a_node", "ratio", "wnr", "est_loglik"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    Dtiny = E.Database.from_arrays(db2.hmm, db2.parent, db2.blen, db2.seq, db2.up[:, 300:400].copy(), db2.down[:, 300:400].copy(), db2.height, md,
+                                   win_start=300, win_len=100)
+    B = E.Batch(Dtiny, 8); B.set_reads([r.seq for r in reads], vps)
+    with pytest.raises(E.EngineError, match="outside the resident message window"):
+        B.assign(opts)
+    B.close(); Dfull.close(); Dwin.close(); Dtiny.close()
+
+
+def test_topk_degenerate_tie_mass():
+    """thousands of nodes at exactly the same distance: the bounded slow path of k_seed_topk must still
+    return the (dist, id) order"""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(2600, 200, "JC69", dg_k=0, seed=5, mean_blen=1e-9)       # all sequences identical up to gaps
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 4, 30, amplicon=True, cols=150)
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts)
+    cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
+    for i in range(len(reads)):
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]))
+        assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all()
+    B.close(); D.close()
+
+
+def test_pe_full_pipeline_against_oracle_batch():
+    """paired-end reads through the whole path vs the oracle's per-read task (alignSeq x2, merge, SEP)"""
+    E = _engine()
+    from hmmufotu_amd import synth
+    from oracle import oracle_py as O
+    db = get_db(120, 1400, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    rng = np.random.default_rng(15)
+    ins = synth.simulate_reads(db, 20, 100000, rng, amplicon_start=60, amplicon_cols=1200, jitter=20)
+    fw, rv, vf, vr = [], [], [], []
+    for r in ins:
+        n = len(r.seq)
+        f = synth.SimRead(r.seq[:110], r.cols[:110], r.node, r.rc, r.cs_start, r.cs_end)
+        m = synth.SimRead(r.seq[n - 110:], r.cols[n - 110:], r.node, r.rc, r.cs_start, r.cs_end)
+        fw.append(f.seq); rv.append(m.seq); vf.append(synth.read_vpaths(db.hmm, f)); vr.append(synth.read_vpaths(db.hmm, m))
+    opts = E.default_opts()
+    D = E.Database.from_synth(db); B = E.Batch(D, 32)
+    B.set_reads(fw, np.stack(vf), rv, np.stack(vr)); B.assign(opts)
+    best = B.placements(); recs = B.alignments(want_align=False)["recs"]
+    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2)
+    assert (recs["status"] == ref["aln_ints"][:, 7]).all()
+    assert (recs["cs_start"] == ref["aln_ints"][:, 4]).all() and (recs["cs_end"] == ref["aln_ints"][:, 5]).all()
+    assert np.array_equal(recs["cost"], ref["cost"])
+    assert (best["n_cand"] == ref["n_cand"]).all()
+    agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
+    assert agree >= 0.8, agree                                     # exact-arithmetic ties may swap (see check_order_and_best)
+    B.close(); D.close()
