@@ -455,7 +455,11 @@ def simulate_reads(db: SynthDB, n_reads: int, read_len: int, rng: np.random.Gene
     the ungapped string truncated to read_len."""
     out = []
     L = db.cs_len
+    tries = 0
     while len(out) < n_reads:
+        tries += 1
+        if tries > 200 * n_reads + 1000:
+            raise RuntimeError("simulate_reads: cannot draw reads with >= 40 bases from this database/window")
         node = int(rng.integers(1, db.n_nodes))
         rc = float(rng.random())
         if amplicon_start is None:

@@ -428,9 +428,9 @@ def test_edge_cases_small_tree_short_reads_and_window():
     length (full DP), a database resident only for a column window"""
     E = _engine()
     from oracle import oracle_py as O
-    db = get_db(16, 300, "GTR", dg_k=4, seed=21)                 # 31 nodes < 50 seeds
+    db = get_db(16, 400, "GTR", dg_k=4, seed=21, n_match=150)    # 31 nodes < 50 seeds
     _, H, T = oracle_objects(db)
-    reads, vps = sim_reads(db, 10, 60)
+    reads, vps = sim_reads(db, 10, 60, cols=250)
     seqs = [r.seq for r in reads]
     seqs[0] = seqs[0][:12]; vps[0] = 0                            # shorter than a 20-mer: no seed, full Viterbi
     seqs[1] = seqs[1][:1]; vps[1] = 0                             # a single base
@@ -472,9 +472,9 @@ def test_topk_degenerate_tie_mass():
     return the (dist, id) order"""
     E = _engine()
     from oracle import oracle_py as O
-    db = get_db(2600, 200, "JC69", dg_k=0, seed=5, mean_blen=1e-9)       # all sequences identical up to gaps
+    db = get_db(2600, 200, "JC69", dg_k=0, seed=5, mean_blen=1e-9, n_match=120)   # all sequences identical up to gaps
     _, H, T = oracle_objects(db)
-    reads, vps = sim_reads(db, 4, 30, amplicon=True, cols=150)
+    reads, vps = sim_reads(db, 4, 60, amplicon=True, cols=140)
     opts = E.default_opts()
     D, B = _run_stages(E, db, reads, vps, opts)
     B.get_seed(opts)
