@@ -45,12 +45,19 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    backend = os.environ.get("HU_BENCH_BACKEND", "nccl")     # "gloo" + HU_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on one GPU
+    if os.environ.get("HU_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else "cpu"              # where collective payloads live
 
     from hmmufotu_amd import engine as E, synth, synth_gpu
     from hmmufotu_amd.shard import gather_records
@@ -127,11 +134,11 @@ def main():
     t1 = time.perf_counter()
     recs = run(args.steps)[-1]
     if world > 1:                                           # the one collective: final result gather over RCCL
-        gathered = gather_records(recs, dev)
+        gathered = gather_records(recs, cdev)
     barrier()
     dt = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_reads = args.batch * args.steps * world

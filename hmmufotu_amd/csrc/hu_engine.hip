@@ -180,8 +180,8 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		if((rc = dev_alloc(db, &ku, ns)) != HU_OK) return fail(rc);
 		if((rc = dev_alloc(db, &kd, ns)) != HU_OK) return fail(rc);
 		(void) hipGetLastError();
-		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(qu, ku, ns);
-		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(qd, kd, ns);
+		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(db->mdl, qu, ku, ns);
+		k_pack_msgs<<<(unsigned)((ns + 255) / 256), 256>>>(db->mdl, qd, kd, ns);
 		hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
 		if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("message packing failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
 		d.up = qu; d.down = qd; d.upK = ku; d.downK = kd;
@@ -848,17 +848,11 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_PLACE);
-			int spt = getenv("HU_STREAMING_SEP") ? 99 : (maxR + HU_BLK_THREADS - 1) / HU_BLK_THREADS;
-			if(!getenv("HU_PLACE_BLK")) spt = 99; /* measured: the 4-wave register-resident variant is slower (57.9 vs 26.2 ms): one wave per SIMD cannot hide the EM's dependent chains */
-			const char* pl = getenv("HU_PLACE_LDS");
-			const size_t ldsx = pl ? std::max(lds, (size_t) atoi(pl)) : lds;
+			/* (a 4-wave register-resident variant was measured at 57.9 ms against 26.2 ms for this one:
+			 * one wave per SIMD cannot hide the EM's dependent chains; forcing occupancy down by LDS also
+			 * slows it: 12 -> 8 -> 4 waves per CU = 26.3 -> 29.4 -> 52.0 ms) */
 			#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
-			if(spt <= 2) k_place_blk<2><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 4) k_place_blk<4><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 6) k_place_blk<6><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 8) k_place_blk<8><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 12) k_place_blk<12><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else k_place<<<(unsigned) nc, 64, ldsx, b->stream>>>(PL_ARGS);
+			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(PL_ARGS);
 			#undef PL_ARGS
 		}
 		HIPCHK(hipGetLastError());

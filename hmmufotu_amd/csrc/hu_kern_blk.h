@@ -38,11 +38,6 @@ __device__ inline long long block_sum_ll(long long v, long long* red, int& phase
 	phase ^= 1;
 	return s;
 }
-/* e = U a */
-__device__ inline void from_eig(const HuModelDev& m, const double* a, double* e) {
-#pragma unroll
-	for(int i = 0; i < 4; ++i) e[i] = fmax((m.U[i*4+0] * a[0] + m.U[i*4+1] * a[1]) + (m.U[i*4+2] * a[2] + m.U[i*4+3] * a[3]), 0.0);
-}
 
 template<int SPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
@@ -87,9 +82,9 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
 		}
 #pragma unroll
 		for(int t = 0; t < SPT; ++t) {
-			double a[4], c[4];
-			if(wur == 0) { for(int i = 0; i < 4; ++i) z[t][i] = eU[t][i]; } else { to_eig(mdl, eU[t], a); conv_eig(mdl, Eu, a, z[t]); }
-			if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = eV[t][i]; } else { to_eig(mdl, eV[t], a); conv_eig(mdl, Ev, a, c); }
+			double c[4];                                   /* messages arrive in the eigenbasis */
+			conv_eig(mdl, Eu, eU[t], z[t]);
+			conv_eig(mdl, Ev, eV[t], c);
 			for(int i = 0; i < 4; ++i) z[t][i] *= c[i];
 		}
 	}
@@ -136,151 +131,3 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
 	if(tid == 0) { HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = ll; out[(size_t) read * HU_MAX_SEEDS + s] = o; }
 }
 
-/* EM on register-resident ratios; the count of usable sites is taken once */
-template<int SPT>
-__device__ inline double em_branch_blk(const double (&rho)[SPT], int n, double cnt, double w0, double maxL, double* red, int& phase, int& emIters) {
-	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0;
-	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
-		double s = 0;
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			const double r = rho[t];               /* NaN marks both "unusable site" and "beyond n" */
-			const double x = fma(r, q0, p0);
-			double tt;
-			if(x > 1e-300 && x < 1e300) {
-				double y = __builtin_amdgcn_rcp(x);
-				y = fma(y, fma(-x, y, 1.0), y);
-				y = fma(y, fma(-x, y, 1.0), y);
-				tt = p0 * y;
-			}
-			else tt = p0 / x;
-			s += isnan(r) ? 0.0 : tt;
-		}
-		s = block_sum(s, red, phase);
-		p = s / cnt; q = 1 - p;
-		++emIters;
-		if(fabs(log(q) - log(q0)) < HU_BRANCH_EPS) break;
-		p0 = p; q0 = q;
-	}
-	double w = -log(q);
-	if(w > maxL) w = maxL;
-	return w;
-}
-
-template<int SPT>
-__global__ __launch_bounds__(HU_BLK_THREADS) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out) {
-	__shared__ double red[8];
-	__shared__ double Etab[3 * HU_MAX_DGK * 4];
-	__shared__ double Ltab[HU_MAX_DGK * 5 * 4];
-	const int tid = threadIdx.x;
-	const HuCand cd = cands[blockIdx.x];
-	const int read = cd.read, u = cd.node;
-	const int start = rstart[read], end = rend[read], n = end - start + 1;
-	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
-	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;
-	const int64_t mOff = ((int64_t) u * db.winLen + (start - db.winStart)) * 4;
-	const double* __restrict__ Ub = db.up + mOff;
-	const double* __restrict__ Vb = db.down + mOff;
-	/* the candidate's two messages, once from HBM, kept in the eigenbasis */
-	double aU[SPT][4], aV[SPT][4]; int bb[SPT];
-	{
-		double eU[SPT][4], eV[SPT][4];
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			const int j = tid + HU_BLK_THREADS * t, jj = j < n ? j : 0;
-			load4(Ub + (size_t) jj * 4, eU[t]); load4(Vb + (size_t) jj * 4, eV[t]); bb[t] = cdr[jj];
-		}
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) { to_eig(mdl, eU[t], aU[t]); to_eig(mdl, eV[t], aV[t]); }
-	}
-	const double w0 = db.blen[u];
-	double lenUR = w0 * cd.ratio0, lenVR = w0 * (1 - cd.ratio0), lenNR = cd.wnr0;
-	double wur0 = lenUR, wnr0 = lenNR;
-	const double w0j = lenUR + lenVR;
-	double wur = wur0, wnr = wnr0;
-	double pi2 = 0;
-	for(int i = 0; i < 4; ++i) pi2 += mdl.pi[i] * mdl.pi[i];
-	double api[4];
-	to_eig(mdl, mdl.pi, api);
-	int iter = 0, emIters = 0, phase = 0;
-	double rho[SPT];
-	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
-		for(int i = tid; i < Kc * 4; i += HU_BLK_THREADS) {
-			const double r = mdl.rate[i >> 2], l = mdl.lam[i & 3];
-			Etab[0 * HU_MAX_DGK * 4 + i] = exp(l * (lenUR * r));
-			Etab[1 * HU_MAX_DGK * 4 + i] = exp(l * (lenVR * r));
-		}
-		lds_barrier();
-		/* (i) message r->n from children u, v; EM on the n-r branch against the read's leaf message */
-		double cnt = 0;
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			double X[4] = {0, 0, 0, 0};
-			for(int k = 0; k < Kc; ++k) {
-				double cu[4], cv[4];
-				if(lenUR == 0) from_eig(mdl, aU[t], cu); else conv_eig(mdl, Etab + k * 4, aU[t], cu);
-				if(lenVR == 0) from_eig(mdl, aV[t], cv); else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV[t], cv);
-				for(int i = 0; i < 4; ++i) X[i] += cu[i] * cv[i];
-			}
-			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
-			const int b = bb[t];
-			double r;
-			if(b >= 0) r = sel4(X, b) / piX;
-			else r = ((mdl.pi[0] * mdl.pi[0] * X[0] + mdl.pi[2] * mdl.pi[2] * X[2]) + (mdl.pi[1] * mdl.pi[1] * X[1] + mdl.pi[3] * mdl.pi[3] * X[3])) / (piX * pi2);
-			if(tid + HU_BLK_THREADS * t >= n) r = NAN;
-			rho[t] = r;
-			cnt += isnan(r) ? 0.0 : 1.0;
-		}
-		cnt = block_sum(cnt, red, phase);
-		wnr = em_branch_blk<SPT>(rho, n, cnt, lenNR, 1.0, red, phase, emIters);
-		lenNR = wnr;
-		for(int i = tid; i < Kc * 4; i += HU_BLK_THREADS)
-			Etab[2 * HU_MAX_DGK * 4 + i] = exp(mdl.lam[i & 3] * (lenNR * mdl.rate[i >> 2]));
-		lds_barrier();
-		for(int i = tid; i < Kc * 5; i += HU_BLK_THREADS) {
-			const int k = i / 5, b = i % 5;
-			double c[4];
-			if(b < 4) {
-				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = x == b ? 1.0 : 0.0; }
-				else { double a[4]; for(int m = 0; m < 4; ++m) a[m] = mdl.U1[m*4+b]; conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, a, c); }
-			}
-			else {
-				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = mdl.pi[x]; }
-				else conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, api, c);
-			}
-			for(int x = 0; x < 4; ++x) Ltab[(k * 5 + b) * 4 + x] = c[x];
-		}
-		lds_barrier();
-		/* (ii) message r->u from children v, n; EM on the u-r branch against u's own message */
-		cnt = 0;
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			const int b = bb[t], bi = b >= 0 ? b : 4;
-			double X[4] = {0, 0, 0, 0};
-			for(int k = 0; k < Kc; ++k) {
-				double cv[4];
-				if(lenVR == 0) from_eig(mdl, aV[t], cv); else conv_eig(mdl, Etab + HU_MAX_DGK * 4 + k * 4, aV[t], cv);
-				const double* cn = Ltab + (k * 5 + bi) * 4;
-				for(int i = 0; i < 4; ++i) X[i] += cv[i] * cn[i];
-			}
-			double eU[4];
-			from_eig(mdl, aU[t], eU);
-			const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
-			const double piU = (mdl.pi[0] * eU[0] + mdl.pi[2] * eU[2]) + (mdl.pi[1] * eU[1] + mdl.pi[3] * eU[3]);
-			const double A = (mdl.pi[0] * X[0] * eU[0] + mdl.pi[2] * X[2] * eU[2]) + (mdl.pi[1] * X[1] * eU[1] + mdl.pi[3] * X[3] * eU[3]);
-			double r = A / (piX * piU);
-			if(tid + HU_BLK_THREADS * t >= n) r = NAN;
-			rho[t] = r;
-			cnt += isnan(r) ? 0.0 : 1.0;
-		}
-		cnt = block_sum(cnt, red, phase);
-		wur = em_branch_blk<SPT>(rho, n, cnt, lenUR, w0j, red, phase, emIters);
-		lenUR = wur;
-		lenVR = w0j - wur;
-		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
-		wur0 = wur; wnr0 = wnr;
-	}
-	if(tid == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
-}

@@ -254,6 +254,11 @@ __device__ inline void conv_eig(const HuModelDev& m, const double* E, const doub
 	for(int i = 0; i < 4; ++i)
 		c[i] = fmax((m.U[i*4+0] * s[0] + m.U[i*4+1] * s[1]) + (m.U[i*4+2] * s[2] + m.U[i*4+3] * s[3]), 0.0);
 }
+/* e = U a (back from the eigenbasis), clamped at 0 */
+__device__ inline void from_eig(const HuModelDev& m, const double* a, double* e) {
+#pragma unroll
+	for(int i = 0; i < 4; ++i) e[i] = fmax((m.U[i*4+0] * a[0] + m.U[i*4+1] * a[1]) + (m.U[i*4+2] * a[2] + m.U[i*4+3] * a[3]), 0.0);
+}
 __device__ inline void load4(const double* p, double* v) {
 	const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
 	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
@@ -263,25 +268,6 @@ __device__ inline void load4(const double* p, double* v) {
 #define HU_LN2_LO 1.90821492927058770002e-10
 #define HU_LN2 0.693147180559945309417232121458
 
-/* one-time packing of the log-space messages of the .ptu into the linear form of HuDbDev */
-__global__ __launch_bounds__(256) void k_pack_msgs(double* __restrict__ msg, int32_t* __restrict__ k2, size_t nsites) {
-	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-	if(i >= nsites) return;
-	double M[4];
-	const double2 a = *reinterpret_cast<const double2*>(msg + i * 4), b = *reinterpret_cast<const double2*>(msg + i * 4 + 2);
-	M[0] = a.x; M[1] = a.y; M[2] = b.x; M[3] = b.y;
-	const double mx = fmax(fmax(M[0], M[1]), fmax(M[2], M[3]));
-	int k = 0;
-	double e[4] = {0, 0, 0, 0};
-	if(mx != -INFINITY) {
-		k = (int) rint(mx * (1.0 / HU_LN2));
-		for(int c = 0; c < 4; ++c) e[c] = exp(fma(-(double) k, HU_LN2_LO, fma(-(double) k, HU_LN2_HI, M[c])));
-	}
-	*reinterpret_cast<double2*>(msg + i * 4) = make_double2(e[0], e[1]);
-	*reinterpret_cast<double2*>(msg + i * 4 + 2) = make_double2(e[2], e[3]);
-	k2[i] = k;
-}
-
 /* inferState in linear space (argmax of a product == argmax of the sum of logs); exact-arithmetic
  * ties (see argmax4_tied) resolve to the first index */
 __device__ inline int argmax4_tied_lin(const double* z) {
@@ -290,6 +276,27 @@ __device__ inline int argmax4_tied_lin(const double* z) {
 	if(z[1] >= thr) return 1;
 	if(z[2] >= thr) return 2;
 	return 3;
+}
+
+/* one-time packing of the log-space messages of the .ptu into the form of HuDbDev: linear space,
+ * scaled by 2^-k (k = rint(max / ln 2), kept aside), and carried into the eigenbasis of the
+ * substitution model, a = U^-1 e — every P(t) then acts on a message as a diagonal scaling */
+__global__ __launch_bounds__(256) void k_pack_msgs(HuModelDev mdl, double* __restrict__ msg, int32_t* __restrict__ k2, size_t nsites) {
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if(i >= nsites) return;
+	double M[4];
+	load4(msg + i * 4, M);
+	const double mx = max4d(M);
+	int k = 0;
+	double e[4] = {0, 0, 0, 0}, a[4];
+	if(mx != -INFINITY) {
+		k = (int) rint(mx * (1.0 / HU_LN2));
+		for(int c = 0; c < 4; ++c) e[c] = exp(fma(-(double) k, HU_LN2_LO, fma(-(double) k, HU_LN2_HI, M[c])));
+	}
+	to_eig(mdl, e, a);
+	*reinterpret_cast<double2*>(msg + i * 4) = make_double2(a[0], a[1]);
+	*reinterpret_cast<double2*>(msg + i * 4 + 2) = make_double2(a[2], a[3]);
+	k2[i] = k;
 }
 
 struct HuEstOut { double ratio, wnr, loglik; };
@@ -325,10 +332,10 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 	{ double mx = max4d(mdl.logpi), sm; for(int i = 0; i < 4; ++i) piw[i] = exp(mdl.logpi[i] - mx); sm = (piw[0] + piw[2]) + (piw[1] + piw[3]); for(int i = 0; i < 4; ++i) piw[i] /= sm; }
 
 	/* z_i = (P(wur) e^U)_i (P(wvr) e^V)_i in linear space; log R_j = log z + (kU + kV) ln 2 */
-	auto zOf = [&](const double* eU, const double* eV, double* z) {
-		double a[4], c[4];
-		if(wur == 0) { for(int i = 0; i < 4; ++i) z[i] = eU[i]; } else { to_eig(mdl, eU, a); conv_eig(mdl, Eu, a, z); }
-		if(wvr == 0) { for(int i = 0; i < 4; ++i) c[i] = eV[i]; } else { to_eig(mdl, eV, a); conv_eig(mdl, Ev, a, c); }
+	auto zOf = [&](const double* aU, const double* aV, double* z) { /* messages arrive in the eigenbasis */
+		double c[4];
+		conv_eig(mdl, Eu, aU, z);
+		conv_eig(mdl, Ev, aV, c);
 		for(int i = 0; i < 4; ++i) z[i] *= c[i];
 	};
 	double dsum = 0, nsum = 0;
@@ -446,37 +453,45 @@ __device__ inline double em_branch(const double* rho, int n, double w0, double m
 	return w;
 }
 
-/* per-site bodies of the two sweeps of one outer iteration (see k_place) */
+/* per-site bodies of the two sweeps of one outer iteration (see k_place).  With messages in the
+ * eigenbasis, sum_k (P_k^u e^U)_i (P_k^v e^V)_i = sum_mn U_im U_in aU_m aV_n G_mn with the wave-uniform
+ * G_mn = sum_k exp(lam_m w_u r_k) exp(lam_n w_v r_k): the rate categories cost nothing per site. */
 struct PlaceCtx {
-	const HuModelDev* mdl; const double* Etab; const double* Ltab; int Kc; double lenUR, lenVR, pi2;
+	const HuModelDev* mdl; const double* G; const double* Tb; double pi2;
 };
-__device__ inline double place_site_rn(const PlaceCtx& c, const double* eU, const double* eV, int b) {
-	const HuModelDev& mdl = *c.mdl;
-	double aU[4], aV[4];
-	to_eig(mdl, eU, aU); to_eig(mdl, eV, aV);
-	double X[4] = {0, 0, 0, 0};
-	for(int k = 0; k < c.Kc; ++k) {
-		double cu[4], cv[4];
-		if(c.lenUR == 0) { for(int i = 0; i < 4; ++i) cu[i] = eU[i]; } else conv_eig(mdl, c.Etab + k * 4, aU, cu);
-		if(c.lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, c.Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
-		for(int i = 0; i < 4; ++i) X[i] += cu[i] * cv[i];
+/* X_i = sum_n U_in (sum_m U_im H_mn) */
+__device__ inline void bilinear_U(const HuModelDev& m, const double* H, double* X) {
+#pragma unroll
+	for(int i = 0; i < 4; ++i) {
+		double y[4];
+#pragma unroll
+		for(int n = 0; n < 4; ++n)
+			y[n] = (m.U[i*4+0] * H[0*4+n] + m.U[i*4+1] * H[1*4+n]) + (m.U[i*4+2] * H[2*4+n] + m.U[i*4+3] * H[3*4+n]);
+		X[i] = fmax((m.U[i*4+0] * y[0] + m.U[i*4+1] * y[1]) + (m.U[i*4+2] * y[2] + m.U[i*4+3] * y[3]), 0.0);
 	}
+}
+__device__ inline double place_site_rn(const PlaceCtx& c, const double* aU, const double* aV, int b) {
+	const HuModelDev& mdl = *c.mdl;
+	double H[16], X[4];
+#pragma unroll
+	for(int m = 0; m < 4; ++m)
+#pragma unroll
+		for(int n = 0; n < 4; ++n) H[m*4+n] = (aU[m] * aV[n]) * c.G[m*4+n];
+	bilinear_U(mdl, H, X);
 	const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
 	if(b >= 0) return sel4(X, b) / piX;
 	return ((mdl.pi[0] * mdl.pi[0] * X[0] + mdl.pi[2] * mdl.pi[2] * X[2]) + (mdl.pi[1] * mdl.pi[1] * X[1] + mdl.pi[3] * mdl.pi[3] * X[3])) / (piX * c.pi2);
 }
-__device__ inline double place_site_ru(const PlaceCtx& c, const double* eU, const double* eV, int b) {
+__device__ inline double place_site_ru(const PlaceCtx& c, const double* aU, const double* aV, int b) {
 	const HuModelDev& mdl = *c.mdl;
-	double aV[4];
-	to_eig(mdl, eV, aV);
-	const int bi = b >= 0 ? b : 4;
-	double X[4] = {0, 0, 0, 0};
-	for(int k = 0; k < c.Kc; ++k) {
-		double cv[4];
-		if(c.lenVR == 0) { for(int i = 0; i < 4; ++i) cv[i] = eV[i]; } else conv_eig(mdl, c.Etab + HU_MAX_DGK * 4 + k * 4, aV, cv);
-		const double* cn = c.Ltab + (k * 5 + bi) * 4;
-		for(int i = 0; i < 4; ++i) X[i] += cv[i] * cn[i];
-	}
+	const double* T = c.Tb + (b >= 0 ? b : 4) * 16;
+	double H[16], X[4], eU[4];
+#pragma unroll
+	for(int m = 0; m < 4; ++m)
+#pragma unroll
+		for(int n = 0; n < 4; ++n) H[m*4+n] = aV[m] * T[m*4+n];
+	bilinear_U(mdl, H, X);
+	from_eig(mdl, aU, eU);
 	const double piX = (mdl.pi[0] * X[0] + mdl.pi[2] * X[2]) + (mdl.pi[1] * X[1] + mdl.pi[3] * X[3]);
 	const double piU = (mdl.pi[0] * eU[0] + mdl.pi[2] * eU[2]) + (mdl.pi[1] * eU[1] + mdl.pi[3] * eU[3]);
 	const double A = (mdl.pi[0] * X[0] * eU[0] + mdl.pi[2] * X[2] * eU[2]) + (mdl.pi[1] * X[1] * eU[1] + mdl.pi[3] * X[3] * eU[3]);
@@ -497,9 +512,12 @@ __device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, cons
 	const int read = cd.read, u = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
 	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
-	double* Etab = lds;                    /* [3][Kc][4]: u, v, n branches          */
-	double* Ltab = Etab + 3 * HU_MAX_DGK * 4; /* [Kc][5][4] leaf convolutions          */
-	double* rho = Ltab + HU_MAX_DGK * 5 * 4;
+	double* Gtab = lds;                    /* [16]    G_mn for the (u, v) pair of branches                 */
+	double* Ttab = Gtab + 16;              /* [5][16] T^b_mn for the (v, n) pair and each leaf vector      */
+	double* ctab = Ttab + 80;              /* lam[4] rate[16] cb[5][4]: model constants that the table builders
+	                                        * index by lane (dynamic indexing of kernel arguments would push the
+	                                        * whole model block into VGPRs/scratch) */
+	double* rho = lds + 3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4; /* (offset kept: the host sizes LDS by it) */
 	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;
 	const int64_t mOff = ((int64_t) u * db.winLen + (start - db.winStart)) * 4;
 	const double* __restrict__ Ub = db.up + mOff;
@@ -513,16 +531,31 @@ __device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, cons
 	for(int i = 0; i < 4; ++i) pi2 += mdl.pi[i] * mdl.pi[i];
 	double api[4];
 	to_eig(mdl, mdl.pi, api);
+	if(lane == 0) {
+#pragma unroll
+		for(int i = 0; i < 4; ++i) ctab[i] = mdl.lam[i];
+#pragma unroll
+		for(int i = 0; i < HU_MAX_DGK; ++i) ctab[4 + i] = mdl.rate[i];
+#pragma unroll
+		for(int b = 0; b < 4; ++b)
+#pragma unroll
+			for(int n = 0; n < 4; ++n) ctab[20 + b * 4 + n] = mdl.U1[n*4+b];
+#pragma unroll
+		for(int n = 0; n < 4; ++n) ctab[20 + 16 + n] = api[n];
+	}
+	__syncthreads();
+	const double* clam = ctab; const double* crate = ctab + 4; const double* ccb = ctab + 20;
 	int iter = 0, emIters = 0;
 	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
-		/* E tables for the u and v branches */
-		for(int i = lane; i < Kc * 4; i += 64) {
-			double r = mdl.rate[i >> 2], l = mdl.lam[i & 3];
-			Etab[0 * HU_MAX_DGK * 4 + i] = exp(l * (lenUR * r));
-			Etab[1 * HU_MAX_DGK * 4 + i] = exp(l * (lenVR * r));
+		/* G_mn = sum_k exp(lam_m w_ur r_k) exp(lam_n w_vr r_k) / Kc */
+		if(lane < 16) {
+			const int m = lane >> 2, n = lane & 3;
+			double g = 0;
+			for(int k = 0; k < Kc; ++k) g += exp(clam[m] * (lenUR * crate[k])) * exp(clam[n] * (lenVR * crate[k]));
+			Gtab[lane] = g / Kc;
 		}
 		__syncthreads();
-		PlaceCtx pc = { &mdl, Etab, Ltab, Kc, lenUR, lenVR, pi2 };
+		PlaceCtx pc = { &mdl, Gtab, Ttab, pi2 };
 		/* (i) message r->n from children u, v; EM on the n-r branch against the read's leaf message */
 		if(PAIR) {
 			for(int j = lane; j < n; j += 128) {
@@ -544,22 +577,12 @@ __device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, cons
 		wnr = em_branch(rho, n, lenNR, 1.0, lane, emIters);
 		lenNR = wnr;
 		__syncthreads();
-		/* tables for the n branch: E, and P(wnr r_k) applied to each possible leaf vector */
-		for(int i = lane; i < Kc * 4; i += 64)
-			Etab[2 * HU_MAX_DGK * 4 + i] = exp(mdl.lam[i & 3] * (lenNR * mdl.rate[i >> 2]));
-		__syncthreads();
-		for(int i = lane; i < Kc * 5; i += 64) {
-			const int k = i / 5, b = i % 5;
-			double c[4];
-			if(b < 4) {
-				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = x == b ? 1.0 : 0.0; }
-				else { double a[4]; for(int m = 0; m < 4; ++m) a[m] = mdl.U1[m*4+b]; conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, a, c); }
-			}
-			else {
-				if(lenNR == 0) { for(int x = 0; x < 4; ++x) c[x] = mdl.pi[x]; }
-				else conv_eig(mdl, Etab + 2 * HU_MAX_DGK * 4 + k * 4, api, c);
-			}
-			for(int x = 0; x < 4; ++x) Ltab[(k * 5 + b) * 4 + x] = c[x];
+		/* T^b_mn = c^b_n sum_k exp(lam_m w_vr r_k) exp(lam_n w_nr r_k) / Kc, c^b = U^-1 e_b (b < 4) or U^-1 pi (gap) */
+		for(int i = lane; i < 80; i += 64) {
+			const int b = i >> 4, m = (i >> 2) & 3, n = i & 3;
+			double g = 0;
+			for(int k = 0; k < Kc; ++k) g += exp(clam[m] * (lenVR * crate[k])) * exp(clam[n] * (lenNR * crate[k]));
+			Ttab[i] = ccb[b * 4 + n] * (g / Kc);
 		}
 		__syncthreads();
 		/* (ii) message r->u from children v, n; EM on the u-r branch against u's own message */
@@ -596,6 +619,6 @@ __global__ __launch_bounds__(64, MINW) void NAME(HuDbDev db, HuModelDev mdl, con
 	extern __shared__ double lds[]; \
 	place_body<PAIR>(db, mdl, codes, rstart, rend, cands, out, lds); \
 }
-/* measured (same setting): one site per trip 27.6 ms, two sites per trip 26.5 ms, either with a
- * forced 4 waves per SIMD 28.3-29.7 ms (spills) */
-HU_PLACE_KERNEL(k_place, true, 1)
+/* measured (8192 reads, R = 1363, mean 25.6 candidates): per-category convolutions 26.3 ms; the G/T-table
+ * form 23.2 ms with one site per trip (3 waves per SIMD) and 23.9 ms with two (2 waves per SIMD) */
+HU_PLACE_KERNEL(k_place, false, 1)

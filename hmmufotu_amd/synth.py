@@ -458,7 +458,7 @@ def simulate_reads(db: SynthDB, n_reads: int, read_len: int, rng: np.random.Gene
     tries = 0
     while len(out) < n_reads:
         tries += 1
-        if tries > 200 * n_reads + 1000:
+        if tries > 5000 * n_reads + 5000:
             raise RuntimeError("simulate_reads: cannot draw reads with >= 40 bases from this database/window")
         node = int(rng.integers(1, db.n_nodes))
         rc = float(rng.random())
@@ -482,7 +482,7 @@ def simulate_reads(db: SynthDB, n_reads: int, read_len: int, rng: np.random.Gene
         x = rng.random(end - start + 1)
         base = np.minimum((x[:, None] > np.cumsum(p, -1)).sum(1), 3)
         cols = np.nonzero(~isgap)[0]
-        if len(cols) < 40:
+        if len(cols) < min(40, max(8, read_len // 2)):
             continue
         cols = cols[:read_len]
         s = BASES[base[cols]].tobytes().decode()
