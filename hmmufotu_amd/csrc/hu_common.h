@@ -9,6 +9,7 @@
 #define HU_MAX_DGK 16
 #define HU_MAX_SEEDS 64          /* capacity of per-read seed lists (max_nseed <= 64)           */
 #define HU_READ_TILE 16          /* reads per workgroup tile in the seed p-distance scan        */
+#define HU_MAX_INS 24            /* bases of one read outside the profile columns handled as a list */
 #define HU_NODE_PAD 256          /* node count is padded to a multiple of this                  */
 #define HU_MIN_LOGLIK_EXP (-510.0) /* DBL_MIN_EXP / 2 in integer arithmetic, PhyloTreeUnrooted.cpp:68 */
 #define HU_BRANCH_EPS 1e-5
@@ -29,7 +30,11 @@ struct HuModelDev {
 struct HuDbDev {
 	int32_t nNodes, nNodesPad, csLen, W, WQ, root;
 	int64_t winStart, winLen;
-	const uint4* planes;       /* [WQ][3][nNodesPad]: 4 words (128 sites) of bit-plane p per node */
+	const uint4* planes;       /* [WQ][3][nNodesPad]: 4 words (128 sites) of bit-plane p per node, in SCAN ORDER */
+	const int32_t* posCol;     /* [WQ*128] scan position -> CS column (-1 = padding): the profile (match) columns
+	                            * first, then the others.  A p-distance is a sum over columns in any order;
+	                            * in this order the few hundred bases of a read sit in 2-3 quads of 128 positions
+	                            * plus the quads of its rare inserts, instead of the ~12 quads of its CS window */
 	const int32_t* parent;
 	const double* blen;
 	const double* height;

@@ -138,15 +138,26 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 	d.winStart = winStart; d.winLen = winLen;
 	d.K = prof->K; d.L = L;
 	auto fail = [&](int code) { hu_db_destroy(db); return code; };
-	/* bit-planes of the node sequences, [WQ][3][nNodesPad] x uint4 */
+	/* scan order of the CS columns: the profile (match) columns first, then the rest, both ascending */
+	std::vector<int32_t> posCol((size_t) d.WQ * 128, -1), colPos(L, -1);
+	{
+		int p = 0;
+		for(int k = 1; k <= prof->K; ++k) { const int c = db->prof.p2cs[k] - 1; colPos[c] = p; posCol[p++] = c; }
+		for(int c = 0; c < L; ++c) if(colPos[c] < 0) { colPos[c] = p; posCol[p++] = c; }
+		int32_t* dp = nullptr;
+		if((rc = dev_upload(db, &dp, posCol.data(), posCol.size())) != HU_OK) return fail(rc);
+		d.posCol = dp;
+	}
+	/* bit-planes of the node sequences in scan order, [WQ][3][nNodesPad] x uint4 */
 	{
 		const size_t np = d.nNodesPad, cnt = (size_t) d.WQ * 3 * np;
 		std::vector<uint4> pl(cnt, make_uint4(0, 0, 0, 0));
 		for(int i = 0; i < n; ++i) {
 			const int8_t* s = &db->seq[(size_t) i * L];
-			for(int c = 0; c < L; ++c) {
-				const int code = s[c];
+			for(int cc = 0; cc < L; ++cc) {
+				const int code = s[cc];
 				if(code < 0) continue;
+				const int c = colPos[cc];
 				const int q = c >> 7, w = (c >> 5) & 3; const uint32_t bit = 1u << (c & 31);
 				uint32_t* p0 = &pl[((size_t) q * 3 + 0) * np + i].x + w;
 				uint32_t* p1 = &pl[((size_t) q * 3 + 1) * np + i].x + w;
@@ -420,7 +431,9 @@ struct hu_batch {
 	DBuf<int8_t> dCodes;
 	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId;
 	DBuf<uint32_t> dRp, dPairs, dSeedDN;
-	DBuf<int2> dTileQ;
+	DBuf<int32_t> dTileQ;
+	DBuf<uint32_t> dRq;
+	DBuf<int32_t> dIns;
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
@@ -463,7 +476,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	(void) hipStreamSynchronize(b->stream);
 	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dTileQ.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;
@@ -582,22 +595,10 @@ static int ensure_read_buffers(hu_batch* b) {
 	if((rc = b->dStart.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dEnd.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dRp.ensure(tiles * d.WQ * HU_READ_TILE * 16)) != HU_OK) return rc;
-	if((rc = b->dTileQ.ensure(tiles)) != HU_OK) return rc;
+	if((rc = b->dTileQ.ensure(tiles * (d.WQ + 1))) != HU_OK) return rc;
+	if((rc = b->dRq.ensure(std::max<size_t>(n, 1) * ((d.WQ + 31) / 32))) != HU_OK) return rc;
+	if((rc = b->dIns.ensure(std::max<size_t>(n, 1) * (HU_MAX_INS + 1))) != HU_OK) return rc;
 	return HU_OK;
-}
-
-__global__ void k_tile_ranges(int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int2* __restrict__ tileQ) {
-	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-	if(tile * HU_READ_TILE >= n) return;
-	int lo = 0x7fffffff, hi = -1;
-	for(int t = 0; t < HU_READ_TILE; ++t) {
-		const int r = tile * HU_READ_TILE + t;
-		if(r >= n) break;
-		const int s = rstart[r], e = rend[r];
-		if(e < s) continue;
-		lo = s < lo ? s : lo; hi = e > hi ? e : hi;
-	}
-	tileQ[tile] = hi >= 0 ? make_int2(lo >> 7, hi >> 7) : make_int2(0, -1);
 }
 
 extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) {
@@ -624,8 +625,8 @@ extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, con
 		HIPCHK(hipMemcpyAsync(b->dEnd.p, b->hEnd.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
 		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
 		HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
-		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p);
-		k_tile_ranges<<<(tiles + 63) / 64, 64, 0, b->stream>>>(n, b->dStart.p, b->dEnd.p, b->dTileQ.p);
+		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
+		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dTileQ.p);
 		HIPCHK(hipGetLastError());
 	}
 	b->state = ST_ALIGNED;
@@ -692,8 +693,8 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			if(b->paired) k_merge_rows<<<b->n, 256, 0, b->stream>>>(d, b->n, o->ignore_orient, b->dRows.p, b->dAlns.p);
 			const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 			HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
-			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p);
-			k_tile_ranges<<<(tiles + 63) / 64, 64, 0, b->stream>>>(b->n, b->dStart.p, b->dEnd.p, b->dTileQ.p);
+			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
+			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dTileQ.p);
 		}
 		HIPCHK(hipGetLastError());
 		b->hAlns.resize(b->nSeq);
@@ -730,7 +731,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			k_seed_pdist<HU_READ_TILE><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dPairs.p, b->n);
+			k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);

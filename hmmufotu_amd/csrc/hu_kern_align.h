@@ -496,10 +496,55 @@ __global__ __launch_bounds__(256) void k_merge_rows(HuDbDev db, int n, int ignor
 	for(int c = threadIdx.x; c < db.csLen; c += 256) if(ra[c] == '.' && rb[c] != '.') ra[c] = rb[c];
 }
 
-/* DigitalSeq codes of the aligned row + region + bit-planes for the seed scan.
+/* DigitalSeq codes of the aligned row + region + bit-planes for the seed scan (in scan order, see
+ * HuDbDev::posCol) + the read's bitmap of quads that hold at least one of its bases.
  * rp layout: rp[((tile*WQ + q) * T + t) * 16 + p*4 + w], zero outside [csStart-1, csEnd-1]. */
+__device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restrict__ cd, int start, int end, int r, int lane,
+		uint32_t* __restrict__ rp, uint32_t* __restrict__ rq, int32_t* __restrict__ ins) {
+	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
+	const int nw32 = (db.WQ + 31) / 32;
+	uint32_t* qbits = rq + (size_t) r * nw32;
+	int32_t* il = ins + (size_t) r * (HU_MAX_INS + 1);   /* [0] = count, then (scan position << 2 | base code) */
+	/* Positions >= QM*128 hold non-profile columns only: a read has a base there only where the alignment put an
+	 * insert.  Up to HU_MAX_INS of them travel as a list (one node word each in the scan); a read with more keeps
+	 * them in its bit-planes and the quads join the tile's quad list. */
+	const int QM = (db.K + 127) / 128;
+	int nIns = 0;
+	for(int base = QM * 128; base < db.WQ * 128; base += 64) {
+		const int c = db.posCol[base + lane];
+		const bool in = c >= start && c <= end && cd[c >= 0 ? c : 0] >= 0 && c >= 0;
+		nIns += __popcll(__ballot(in));
+	}
+	const bool dense = nIns > HU_MAX_INS;
+	uint32_t acc = 0;
+	int li = 0;
+	for(int base = 0; base < db.WQ * 128; base += 64) {
+		const int c = db.posCol[base + lane];
+		const int8_t code = c >= 0 ? cd[c] : (int8_t) -2;
+		const bool in = c >= start && c <= end && code >= 0;
+		const int q = base / 128, w = (base % 128) / 32;
+		const bool asList = q >= QM && !dense;
+		unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
+		if(lane == 0) {
+			if(asList) {
+				unsigned long long m = bv;
+				while(m) { const int bit = __ffsll((long long) m) - 1; m &= m - 1; il[1 + li++] = ((base + bit) << 2) | (int)(((b0 >> bit) & 1) | (((b1 >> bit) & 1) << 1)); }
+				b0 = b1 = bv = 0;
+			}
+			uint32_t* dst = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
+			dst[0 + w] = (uint32_t) b0; dst[0 + w + 1] = (uint32_t)(b0 >> 32);
+			dst[4 + w] = (uint32_t) b1; dst[4 + w + 1] = (uint32_t)(b1 >> 32);
+			dst[8 + w] = (uint32_t) bv; dst[8 + w + 1] = (uint32_t)(bv >> 32);
+			if(bv) acc |= 1u << (q & 31);
+			if((q & 31) == 31 && w == 2) { qbits[q >> 5] = acc; acc = 0; }
+		}
+	}
+	if(lane == 0) { if(db.WQ & 31) qbits[(db.WQ - 1) >> 5] = acc; il[0] = li; }
+}
+
 __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, const HuAlnDev* __restrict__ alns,
-		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp) {
+		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
+		int32_t* __restrict__ ins) {
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const HuAlnDev a = alns[r];
 	const char* row = rows + (size_t) r * db.csLen;
@@ -507,46 +552,34 @@ __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __re
 	const bool ok = a.status == HU_READ_OK;
 	const int start = ok ? a.csStart - 1 : 0, end = ok ? a.csEnd - 1 : -1;
 	if(lane == 0) { rstart[r] = start; rend[r] = end; }
-	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
-	for(int base = 0; base < db.WQ * 128; base += 64) {
-		const int c = base + lane;
-		int8_t code = -2;
-		if(c < db.csLen) {
-			char ch = row[c];
-			if(ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
-			code = c_sym_map[(int) ch & 127];
-			cd[c] = code;
-		}
-		const bool in = c >= start && c <= end && code >= 0;
-		const unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
-		if(lane == 0) {
-			const int q = base / 128, w = (base % 128) / 32;
-			uint32_t* dst = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
-			dst[0 + w] = (uint32_t) b0; dst[0 + w + 1] = (uint32_t)(b0 >> 32);
-			dst[4 + w] = (uint32_t) b1; dst[4 + w + 1] = (uint32_t)(b1 >> 32);
-			dst[8 + w] = (uint32_t) bv; dst[8 + w + 1] = (uint32_t)(bv >> 32);
-		}
+	for(int c = lane; c < db.csLen; c += 64) {
+		char ch = row[c];
+		if(ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+		cd[c] = c_sym_map[(int) ch & 127];
 	}
+	__syncthreads();
+	planes_of_codes(db, cd, start, end, r, lane, rp, rq, ins);
 }
 
 /* same, when the caller supplies DigitalSeq codes directly (hu_batch_set_aligned) */
 __global__ __launch_bounds__(64) void k_planes_from_codes(HuDbDev db, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, uint32_t* __restrict__ rp) {
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
+		int32_t* __restrict__ ins) {
 	const int r = blockIdx.x, lane = threadIdx.x;
-	const int8_t* cd = codes + (size_t) r * db.csLen;
-	const int start = rstart[r], end = rend[r];
-	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
-	for(int base = 0; base < db.WQ * 128; base += 64) {
-		const int c = base + lane;
-		const int8_t code = c < db.csLen ? cd[c] : (int8_t) -2;
-		const bool in = c >= start && c <= end && code >= 0;
-		const unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
-		if(lane == 0) {
-			const int q = base / 128, w = (base % 128) / 32;
-			uint32_t* dst = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
-			dst[0 + w] = (uint32_t) b0; dst[0 + w + 1] = (uint32_t)(b0 >> 32);
-			dst[4 + w] = (uint32_t) b1; dst[4 + w + 1] = (uint32_t)(b1 >> 32);
-			dst[8 + w] = (uint32_t) bv; dst[8 + w + 1] = (uint32_t)(bv >> 32);
-		}
+	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, lane, rp, rq, ins);
+}
+
+/* per scan tile: the quads in which any of its reads has a base -> tileQ[tile][0] = count, [1..] = quads */
+__global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint32_t* __restrict__ rq, int32_t* __restrict__ tileQ) {
+	const int tile = blockIdx.x, lane = threadIdx.x;
+	const int nw32 = (db.WQ + 31) / 32;
+	int32_t* out = tileQ + (size_t) tile * (db.WQ + 1);
+	int cnt = 0;
+	for(int w = 0; w < nw32; ++w) { /* WQ <= 512: at most 16 words; lane 0 writes the compacted list */
+		uint32_t m = 0;
+		if(lane < HU_READ_TILE) { const int r = tile * HU_READ_TILE + lane; if(r < n) m = rq[(size_t) r * nw32 + w]; }
+		for(int s = 32; s > 0; s >>= 1) m |= __shfl_xor(m, s);
+		if(lane == 0) while(m) { const int b = __ffs(m) - 1; m &= m - 1; out[1 + cnt++] = w * 32 + b; }
 	}
+	if(lane == 0) out[0] = cnt;
 }

@@ -23,35 +23,77 @@
  * Per (node, read, 32 sites): 2 xor + or + 2 and + 2 popcount-accumulate.
  * Grid: x = read tile (fastest: consecutive workgroups re-use one node block from L2),
  *       y = node block of 256. */
-template<int T>
+/* T reads x M node blocks per workgroup: a lane owns M nodes (node, node + 256, ...) and T reads, so every
+ * scalar load of a read's planes (48 B) feeds 24 M vector operations.  With M = 1 the kernel sat at ~50 % of the
+ * integer issue rate behind `s_load -> s_waitcnt lgkmcnt(0)` pairs: the scalar cache, shared by several
+ * CUs, was the limiter.  Reads [t0, t0 + T) of the 16-read layout tile blockIdx.x / (16 / T). */
+template<int T, int M, bool NOCOUNT = false>
 __global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int2* __restrict__ tileQ, uint32_t* __restrict__ pairs, int nReads) {
-	const int tile = blockIdx.x;
-	const int node = blockIdx.y * 256 + threadIdx.x;
-	const int2 qr = tileQ[tile];
-	uint32_t d[T], N[T];
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ ins, uint32_t* __restrict__ pairs, int nReads) {
+	constexpr int SPLIT = HU_READ_TILE / T;
+	const int tile = blockIdx.x / SPLIT, t0 = (blockIdx.x % SPLIT) * T;
+	const int node0 = blockIdx.y * (256 * M) + threadIdx.x;
+	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1); /* [0] = count, then the quads holding any base of the tile's reads */
+	const int nq = ql[0];
+	uint32_t d[M][T], N[M][T];
 #pragma unroll
-	for(int t = 0; t < T; ++t) { d[t] = 0; N[t] = 0; }
+	for(int m = 0; m < M; ++m)
+#pragma unroll
+		for(int t = 0; t < T; ++t) { d[m][t] = 0; N[m][t] = 0; }
 	const size_t np = (size_t) db.nNodesPad;
-	for(int q = qr.x; q <= qr.y; ++q) {
-		const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node];
-		const uint4 n1 = db.planes[((size_t) q * 3 + 1) * np + node];
-		const uint4 nv = db.planes[((size_t) q * 3 + 2) * np + node];
-		const uint32_t* __restrict__ r = rp + ((size_t) tile * db.WQ + q) * T * 16;
+	for(int qi = 0; qi < nq; ++qi) {
+		const int q = ql[1 + qi];
+		uint4 n0[M], n1[M], nv[M];
+#pragma unroll
+		for(int m = 0; m < M; ++m) {
+			const int node = node0 + 256 * m < db.nNodesPad ? node0 + 256 * m : node0;
+			n0[m] = db.planes[((size_t) q * 3 + 0) * np + node];
+			n1[m] = db.planes[((size_t) q * 3 + 1) * np + node];
+			nv[m] = db.planes[((size_t) q * 3 + 2) * np + node];
+		}
+		const uint32_t* __restrict__ r = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t0) * 16;
 #pragma unroll
 		for(int t = 0; t < T; ++t) {
 			const uint32_t* rt = r + t * 16;
-			uint32_t m, x;
-			m = nv.x & rt[8];  x = ((n0.x ^ rt[0]) | (n1.x ^ rt[4])) & m; d[t] += __popc(x); N[t] += __popc(m);
-			m = nv.y & rt[9];  x = ((n0.y ^ rt[1]) | (n1.y ^ rt[5])) & m; d[t] += __popc(x); N[t] += __popc(m);
-			m = nv.z & rt[10]; x = ((n0.z ^ rt[2]) | (n1.z ^ rt[6])) & m; d[t] += __popc(x); N[t] += __popc(m);
-			m = nv.w & rt[11]; x = ((n0.w ^ rt[3]) | (n1.w ^ rt[7])) & m; d[t] += __popc(x); N[t] += __popc(m);
+#pragma unroll
+			for(int m = 0; m < M; ++m) {
+				uint32_t k, x;
+				k = nv[m].x & rt[8];  x = ((n0[m].x ^ rt[0]) | (n1[m].x ^ rt[4])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
+				k = nv[m].y & rt[9];  x = ((n0[m].y ^ rt[1]) | (n1[m].y ^ rt[5])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
+				k = nv[m].z & rt[10]; x = ((n0[m].z ^ rt[2]) | (n1[m].z ^ rt[6])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
+				k = nv[m].w & rt[11]; x = ((n0[m].w ^ rt[3]) | (n1[m].w ^ rt[7])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
+			}
+		}
+	}
+	/* the reads' bases in non-profile columns (alignment inserts): one node word per listed position */
+#pragma unroll
+	for(int t = 0; t < T; ++t) {
+		const int read = tile * HU_READ_TILE + t0 + t;
+		if(read >= nReads) continue;
+		const int32_t* __restrict__ il = ins + (size_t) read * (HU_MAX_INS + 1);
+		const int cnt = il[0];
+		for(int e = 0; e < cnt; ++e) {
+			const int ent = il[1 + e], pos = ent >> 2, code = ent & 3;
+			const int q = pos >> 7, w = (pos >> 5) & 3, bit = pos & 31;
+#pragma unroll
+			for(int m = 0; m < M; ++m) {
+				const int node = node0 + 256 * m < db.nNodesPad ? node0 + 256 * m : node0;
+				const uint32_t* pw = reinterpret_cast<const uint32_t*>(db.planes + ((size_t) q * 3) * np + node) + w;
+				const uint32_t w0 = pw[0], w1 = pw[np * 4], wv = pw[np * 8];
+				const uint32_t valid = (wv >> bit) & 1u, nc = ((w0 >> bit) & 1u) | (((w1 >> bit) & 1u) << 1);
+				N[m][t] += valid; d[m][t] += valid & (nc != (uint32_t) code ? 1u : 0u);
+			}
 		}
 	}
 #pragma unroll
-	for(int t = 0; t < T; ++t) {
-		const int read = tile * T + t;
-		if(read < nReads) pairs[(size_t) read * np + node] = (d[t] << 16) | N[t];
+	for(int m = 0; m < M; ++m) {
+		const int node = node0 + 256 * m;
+		if(node >= db.nNodesPad) continue;
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const int read = tile * HU_READ_TILE + t0 + t;
+			if(read < nReads) pairs[(size_t) read * np + node] = (d[m][t] << 16) | N[m][t];
+		}
 	}
 }
 
