@@ -53,6 +53,7 @@ struct HuDbDev {
 	const double* entryC;
 	const double* exitC;
 	const int32_t* p2cs;       /* [K+2] */
+	const double* placeConst;  /* [HU_PC_COUNT] */
 };
 
 /* one dynamic-programming phase of the banded Viterbi (src/BandedHMMP7.cpp:794-881) */
@@ -75,6 +76,16 @@ struct HuReadDesc {
 };
 
 void hu_set_error(const char* fmt, ...);
+
+/* model constants of the table-driven placement kernel (k_place_blk), one buffer of doubles per database */
+#define HU_PC_LAM 0              /* [4]      eigenvalues                                                      */
+#define HU_PC_RATE 4             /* [16]     dGamma rates (rate[0] = 1 without dGamma)                         */
+#define HU_PC_W 20               /* [5][16]  W^b_mn = U_bm U_bn (b < 4), W^4_mn = sum_i pi_i^2 U_im U_in / sum pi^2 */
+#define HU_PC_C 100              /* [4][4][4] C_mnk = sum_i pi_i U_im U_in U_ik                                */
+#define HU_PC_CB 164             /* [5][4]   c^b = U^-1 e_b (b < 4), c^4 = U^-1 pi                              */
+#define HU_PC_S 184              /* [4]      s_k = sum_i pi_i U_ik                                             */
+#define HU_PC_COUNT 188
+void hu_place_consts(const HuModelDev& m, double* pc);
 
 /* host-side model preparation */
 int hu_model_prepare(const hu_model_desc* d, HuModelDev* out);

@@ -210,6 +210,9 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		if((rc = dev_upload(db, &q, db->prof.entryC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.entryC = q;
 		if((rc = dev_upload(db, &q, db->prof.exitC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.exitC = q;
 		if((rc = dev_upload(db, &p, p2.data(), p2.size())) != HU_OK) return fail(rc); d.p2cs = p;
+		double pc[HU_PC_COUNT];
+		hu_place_consts(db->mdl, pc);
+		if((rc = dev_upload(db, &q, pc, (size_t) HU_PC_COUNT)) != HU_OK) return fail(rc); d.placeConst = q;
 	}
 	if((rc = init_sym_map()) != HU_OK) return fail(rc);
 	*out = db;
@@ -843,19 +846,26 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 	if(nc) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
-		const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
-		if(lds > 160 * 1024) { hu_set_error("alignment region of %d columns does not fit the placement kernel's LDS", maxR); return HU_ERR_ARG; }
-		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		const int spt = (maxR + HU_BLK_THREADS - 1) / HU_BLK_THREADS;
+		const bool stream = getenv("HU_STREAMING_SEP") != nullptr || spt > 12;
 		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
-		{
+		#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
+		if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
+			const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
+			if(lds > 160 * 1024) { hu_set_error("alignment region of %d columns does not fit the placement kernel's LDS", maxR); return HU_ERR_ARG; }
+			if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 			Timer t(b, HU_T_PLACE);
-			/* (a 4-wave register-resident variant was measured at 57.9 ms against 26.2 ms for this one:
-			 * one wave per SIMD cannot hide the EM's dependent chains; forcing occupancy down by LDS also
-			 * slows it: 12 -> 8 -> 4 waves per CU = 26.3 -> 29.4 -> 52.0 ms) */
-			#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
 			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(PL_ARGS);
-			#undef PL_ARGS
 		}
+		else { /* one workgroup per candidate, messages and per-site ratios register-resident */
+			Timer t(b, HU_T_PLACE);
+			if(spt <= 2) k_place_blk<2><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 4) k_place_blk<4><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 6) k_place_blk<6><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else if(spt <= 8) k_place_blk<8><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			else k_place_blk<12><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+		}
+		#undef PL_ARGS
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->hPlaceOut.data(), b->dPlaceOut.p, nc * sizeof(HuPlaceOut), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));

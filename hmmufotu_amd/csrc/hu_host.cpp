@@ -116,6 +116,33 @@ int hu_model_prepare(const hu_model_desc* d, HuModelDev* out) {
 	return HU_OK;
 }
 
+/* constants of k_place_blk: with messages in the eigenbasis (a = U^-1 e) every per-site quantity of the joint
+ * branch-length optimisation is a bilinear form a_U^T M a_V; the model-dependent factors of those 4x4 tables: */
+void hu_place_consts(const HuModelDev& m, double* pc) {
+	for(int i = 0; i < 4; ++i) pc[HU_PC_LAM + i] = m.lam[i];
+	for(int i = 0; i < HU_MAX_DGK; ++i) pc[HU_PC_RATE + i] = m.rate[i];
+	double pi2 = 0;
+	for(int i = 0; i < 4; ++i) pi2 += m.pi[i] * m.pi[i];
+	for(int a = 0; a < 4; ++a) for(int c = 0; c < 4; ++c) {
+		for(int b = 0; b < 4; ++b) pc[HU_PC_W + b * 16 + a * 4 + c] = m.U[b*4+a] * m.U[b*4+c];
+		double g = 0;
+		for(int i = 0; i < 4; ++i) g += m.pi[i] * m.pi[i] * m.U[i*4+a] * m.U[i*4+c];
+		pc[HU_PC_W + 4 * 16 + a * 4 + c] = g / pi2;
+		for(int k = 0; k < 4; ++k) {
+			double t = 0;
+			for(int i = 0; i < 4; ++i) t += m.pi[i] * m.U[i*4+a] * m.U[i*4+c] * m.U[i*4+k];
+			pc[HU_PC_C + (a * 4 + c) * 4 + k] = t;
+		}
+	}
+	for(int k = 0; k < 4; ++k) {
+		for(int b = 0; b < 4; ++b) pc[HU_PC_CB + b * 4 + k] = m.U1[k*4+b];
+		double a = 0, s = 0;
+		for(int i = 0; i < 4; ++i) { a += m.U1[k*4+i] * m.pi[i]; s += m.pi[i] * m.U[i*4+k]; }
+		pc[HU_PC_CB + 4 * 4 + k] = a;
+		pc[HU_PC_S + k] = s;
+	}
+}
+
 /* host-only export for CPU tests of the spectral forms */
 extern "C" int hu_model_spectral(const hu_model_desc* d, double* U, double* lam, double* U1) {
 	HuModelDev m;
