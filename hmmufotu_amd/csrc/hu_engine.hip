@@ -859,11 +859,42 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		}
 		else { /* one workgroup per candidate, messages and per-site ratios register-resident */
 			Timer t(b, HU_T_PLACE);
-			if(spt <= 2) k_place_blk<2><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 4) k_place_blk<4><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 6) k_place_blk<6><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else if(spt <= 8) k_place_blk<8><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
-			else k_place_blk<12><<<(unsigned) nc, HU_BLK_THREADS, 0, b->stream>>>(PL_ARGS);
+			const char* ev = getenv("HU_PLACE_VAR");
+			const int var = ev ? atoi(ev) : 0;
+			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS)
+			if(spt <= 2) PL_GO(2, 4, 2, 1, 1);
+			else if(spt <= 4) PL_GO(4, 4, 2, 1, 1);
+			else if(spt <= 6) {
+				switch(var) {
+				case 99: { /* diagnostic: per-phase s_memtime stamps, summed over the candidates, to stderr */
+					long long* dd = nullptr;
+					HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
+					k_place_blk<6, 4, 1, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
+					std::vector<long long> hd(nc * 8);
+					HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+					HIPCHK(hipStreamSynchronize(b->stream));
+					(void) hipFree(dd);
+					double acc[8] = {0};
+					for(size_t c = 0; c < nc; ++c) for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i];
+					fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
+							acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
+					break;
+				}
+				case 1: PL_GO(6, 4, 1, 1, 1); break;
+				case 2: PL_GO(6, 4, 2, 0, 1); break;
+				case 3: PL_GO(6, 4, 1, 0, 1); break;
+				case 10: PL_GO(6, 4, 2, 1, 3); break;
+				case 11: PL_GO(6, 4, 1, 1, 3); break;
+				case 20: PL_GO(12, 2, 2, 1, 1); break;
+				case 21: PL_GO(12, 2, 1, 1, 1); break;
+				case 22: PL_GO(12, 2, 1, 1, 2); break;
+				case 23: PL_GO(12, 2, 1, 0, 2); break;
+				default: PL_GO(6, 4, 2, 1, 1); break;
+				}
+			}
+			else if(spt <= 8) PL_GO(8, 4, 2, 1, 1);
+			else PL_GO(12, 4, 2, 1, 1);
+			#undef PL_GO
 		}
 		#undef PL_ARGS
 		HIPCHK(hipGetLastError());

@@ -103,11 +103,16 @@ int hu_model_prepare(const hu_model_desc* d, HuModelDev* out) {
 	for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) S[i*4+j] = sq[i] * Q[i*4+j] * isq[j];
 	for(int i = 0; i < 4; ++i) for(int j = i + 1; j < 4; ++j) { double a = 0.5 * (S[i*4+j] + S[j*4+i]); S[i*4+j] = S[j*4+i] = a; }
 	sym_eig4(S, V, out->lam);
-	for(int i = 0; i < 4; ++i) for(int k = 0; k < 4; ++k) { out->U[i*4+k] = isq[i] * V[i*4+k]; out->U1[k*4+i] = V[i*4+k] * sq[i]; }
-	/* the zero eigenvalue is exact in theory: snap it so that P(t) rows keep summing to 1 for huge t */
+	/* the zero eigenvalue and its eigenvector sqrt(pi) are exact in theory: moved to index 0 and snapped, so that
+	 * P(t) rows keep summing to 1 for huge t, U(i,0) = 1, U1(0,i) = pi(i): component 0 of a message in the
+	 * eigenbasis is pi . e (k_place_blk normalises messages by it and keeps the other three components) */
 	int z = 0;
 	for(int k = 1; k < 4; ++k) if(std::fabs(out->lam[k]) < std::fabs(out->lam[z])) z = k;
-	out->lam[z] = 0.0;
+	if(z != 0) { std::swap(out->lam[0], out->lam[z]); for(int i = 0; i < 4; ++i) std::swap(V[i*4+0], V[i*4+z]); }
+	out->lam[0] = 0.0;
+	for(int i = 0; i < 4; ++i) V[i*4+0] = sq[i];
+	for(int i = 0; i < 4; ++i) for(int k = 0; k < 4; ++k) { out->U[i*4+k] = isq[i] * V[i*4+k]; out->U1[k*4+i] = V[i*4+k] * sq[i]; }
+	for(int i = 0; i < 4; ++i) { out->U[i*4+0] = 1.0; out->U1[0*4+i] = pi[i]; }
 	for(int i = 0; i < 4; ++i) { out->pi[i] = pi[i]; out->logpi[i] = std::log(pi[i]); }
 	out->dgK = d->dg_k;
 	if(d->dg_k < 0 || d->dg_k > HU_MAX_DGK) { hu_set_error("model: dg_k %d out of range", d->dg_k); return HU_ERR_ARG; }

@@ -139,12 +139,14 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
  * sum_i pi_i U_im U_in = delta_mn), every per-site quantity of the two sweeps is a bilinear form:
  *   sweep (i)   rho = (a_U^T N^b a_V) / (sum_m G_mm a_Um a_Vm),   N^b_mn = W^b_mn G_mn
  *   sweep (ii)  rho = (a_V^T Z^b a_U) / (sum_m T^b_mm a_Vm),       Z^b_mk = sum_n T^b_mn C_mnk, T^b_mn = c^b_n G'_mn
- * (a_U pre-scaled so that pi . e_U = 1), b = the read's base at the site or 4 for a gap, G / G' the
- * category-averaged products of exponentials of the two branch lengths involved.  The five 4x4 tables are
- * rebuilt per sweep by 80 threads; a site costs ~30 FMA + one division instead of three 4x4 matvecs per
- * rate category.  The messages (8 doubles per site) and the per-site ratios live in registers for the whole
- * optimisation: every message byte crosses HBM once (the streaming k_place re-reads them per sweep).
- * The EM step is 1 / (1 + rho_j q0/p0) summed over the sites: fma, v_rcp_f64, two Newton steps, add. */
+ * b = the read's base at the site or 4 for a gap, G / G' the category-averaged products of exponentials of the
+ * two branch lengths involved.  Component 0 of a message in the eigenbasis is pi . e (hu_model_prepare) and both
+ * ratios are invariant under a scaling of either message, so each message is divided by its component 0 and only
+ * the other three are kept: 6 doubles per site, register-resident for the whole optimisation together with the
+ * per-site ratios — every message byte crosses HBM once (the streaming k_place re-reads them per sweep).
+ * The five 4x4 tables are rebuilt per sweep by <= 100 threads; a site costs ~21 FMA + one division instead of
+ * three 4x4 matvecs per rate category.  The EM step is p0 / (rho_j q0 + p0) summed over the sites: fma,
+ * v_rcp_f64, Newton step(s), add. */
 #define HU_RHO_SKIP 1e200        /* sentinel ratio of a site the EM skips (NaN ratio in the reference, padding) */
 #define HU_TP 18                 /* doubles per table row block in LDS (16 + 2: rows of different b on different banks) */
 #define HU_EXP_MEPS 0.99999000004999983333   /* exp(-1e-5) */
@@ -158,21 +160,37 @@ __device__ inline double fast_div(double a, double b) { /* a / b to ~1 ulp for f
 	return fma(fma(-b, q, a), y, q);
 }
 
-template<int SPT>
-__device__ inline double em_branch_blk(const double (&rho)[SPT], double cnt, double w0, double maxL, double* red, int& phase, int& emIters) {
-	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0;
-	const double rc = 1.0 / cnt;
+typedef double hu_double4 __attribute__((ext_vector_type(4)));
+/* sum over the 64 lanes on the matrix pipe, identical in every lane.  A[i][k] = x(lane i + 16 k), B = ones:
+ * D[i][.] = sum_k A[i][k]; lane l holds D rows (l >> 4) + 4 r, r = 0..3; their sum T(l >> 4) is the next
+ * A[i][k = l >> 4]: D' = sum_k T_k.  (Measured slower than the DPP butterfly in k_place_blk: the two dependent
+ * f64 MFMAs cost more latency than the butterfly costs issue slots; kept for reference.) */
+__device__ inline double wave_sum_mfma(double x) {
+	const hu_double4 z = {0.0, 0.0, 0.0, 0.0};
+	hu_double4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(x, 1.0, z, 0, 0, 0);
+	const double t = (d[0] + d[1]) + (d[2] + d[3]);
+	d = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
+	return d[0];
+}
+
+/* EMV: Newton steps on v_rcp_f64 (2^-23 or better): 1 -> 2^-46 per term (a 1e-14 relative bias on the branch
+ * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: 0 = DPP butterfly, 1 = MFMA. */
+template<int SPT, int NW, int EMV, int RED>
+__device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave, double w0, double maxL,
+		double* red, double* redc, int& phase, int& emIters) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0, rc = 0;
+	if(lane == 0) redc[(phase & 1) * NW + wave] = (double) nvalidWave;
 	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
-		const double k = fast_div(q0, p0);
 		double s = 0;
-		if(k >= 1e-100 && k <= 1e100) { /* p0 / (rho q0 + p0) = 1 / (rho k + 1); skipped sites contribute < 1e-100 */
+		const bool fast = q0 >= 1e-30 && p0 >= 1e-30; /* x = rho q0 + p0 in [1e-30, 1e200]; skipped sites add < 1e-170 */
+		if(fast) {
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
-				const double x = fma(rho[t], k, 1.0);
-				double y = __builtin_amdgcn_rcp(x);
-				y = fma(fma(-x, y, 1.0), y, y);
-				y = fma(fma(-x, y, 1.0), y, y);
-				s += y;
+				const double x = fma(rho[t], q0, p0);
+				const double y = __builtin_amdgcn_rcp(x);
+				if(EMV == 1) s = fma(y, fma(-x, y, 2.0), s);
+				else { const double y1 = fma(fma(-x, y, 1.0), y, y); s = fma(y1, fma(-x, y1, 2.0), s); }
 			}
 		}
 		else { /* degenerate branch lengths (p0 = 0, q0 = 0): the reference's expression as written */
@@ -183,7 +201,22 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], double cnt, dou
 				s += r == HU_RHO_SKIP ? 0.0 : tt;
 			}
 		}
-		s = block_sum(s, red, phase);
+		s = RED ? wave_sum_mfma(s) : wave_sum_uniform(s);
+		double* r = red + (phase & 1) * NW;
+		if(lane == 0) r[wave] = s;
+		lds_barrier();
+		s = r[0];
+#pragma unroll
+		for(int w = 1; w < NW; ++w) s += r[w];
+		if(it == 0) {
+			const double* c = redc + (phase & 1) * NW;
+			double cnt = c[0];
+#pragma unroll
+			for(int w = 1; w < NW; ++w) cnt += c[w];
+			rc = 1.0 / cnt;
+		}
+		phase ^= 1;
+		if(fast) s *= p0;
 		p = s * rc; q = 1 - p;
 		++emIters;
 		if(q0 * HU_EXP_MEPS < q && q < q0 * HU_EXP_PEPS) break; /* |log q - log q0| < BRANCH_EPS */
@@ -194,137 +227,163 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], double cnt, dou
 	return w;
 }
 
-template<int SPT>
-__global__ __launch_bounds__(HU_BLK_THREADS) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+/* DBG: diagnostic build, s_memtime stamps per phase into dbg[block][8] (load, tables, sweeps, EM, total) */
+template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false>
+__global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out) {
-	__shared__ double red[8];
+		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr) {
+	constexpr int THREADS = 64 * NW;
+	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
+	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
+	if(DBG) { t0 = tl = (long long) __builtin_amdgcn_s_memtime(); }
+	__shared__ double red[2 * NW], redc[2 * NW];
 	__shared__ double cst[HU_PC_COUNT];
 	__shared__ double Etab[3 * HU_MAX_DGK * 4];          /* [which][k][m] = exp(lam_m len_which rate_k) */
+	__shared__ double Gtab[16];
 	__shared__ __attribute__((aligned(16))) double tabM[5 * HU_TP];
 	__shared__ __attribute__((aligned(16))) double tabD[6 * 4];             /* sweep (i): row 0 = G_mm; sweep (ii): row b = T^b_mm */
 	const int tid = threadIdx.x;
+	/* the serial table work of a workgroup runs in one or two of its waves: rotate which by workgroup so that
+	 * the workgroups sharing a CU load different SIMDs with it */
+	const int vt = (tid + 64 * (blockIdx.x % NW)) % THREADS;
 	const HuCand cd = cands[blockIdx.x];
-	const int read = cd.read, u = cd.node;
+	const int read = cd.read, un = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
 	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
 	const double rKc = 1.0 / (double) Kc;
 	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;
-	const int64_t mOff = ((int64_t) u * db.winLen + (start - db.winStart)) * 4;
+	const int64_t mOff = ((int64_t) un * db.winLen + (start - db.winStart)) * 4;
 	const double* __restrict__ Ub = db.up + mOff;
 	const double* __restrict__ Vb = db.down + mOff;
-	/* the candidate's two messages (already in the eigenbasis), once from HBM */
-	double aU[SPT][4], aV[SPT][4]; int bo[SPT];
+	double u[SPT][3], v[SPT][3]; unsigned long long bop = 0;
+	{
+		double aU[SPT][4], aV[SPT][4];
 #pragma unroll
-	for(int t = 0; t < SPT; ++t) {
-		const int j = tid + HU_BLK_THREADS * t, jj = j < n ? j : 0;
-		load4(Ub + (size_t) jj * 4, aU[t]); load4(Vb + (size_t) jj * 4, aV[t]);
-		const int b = cdr[jj];
-		bo[t] = (b >= 0 ? b : 4);
+		for(int t = 0; t < SPT; ++t) {
+			const int j = tid + THREADS * t, jj = j < n ? j : 0;
+			load4(Ub + (size_t) jj * 4, aU[t]); load4(Vb + (size_t) jj * 4, aV[t]);
+			const int b = cdr[jj];
+			bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
+		}
+#pragma unroll
+		for(int t = 0; t < SPT; ++t) {
+			const double iu = 1.0 / aU[t][0], iv = 1.0 / aV[t][0];
+#pragma unroll
+			for(int m = 0; m < 3; ++m) { u[t][m] = aU[t][m + 1] * iu; v[t][m] = aV[t][m + 1] * iv; }
+		}
 	}
-	for(int i = tid; i < HU_PC_COUNT; i += HU_BLK_THREADS) cst[i] = db.placeConst[i];
+	for(int i = tid; i < HU_PC_COUNT; i += THREADS) cst[i] = db.placeConst[i];
 	lds_barrier();
 	const double* clam = cst + HU_PC_LAM; const double* crate = cst + HU_PC_RATE; const double* cW = cst + HU_PC_W;
 	const double* cC = cst + HU_PC_C; const double* ccb = cst + HU_PC_CB;
-	{
-		const double s0 = cst[HU_PC_S + 0], s1 = cst[HU_PC_S + 1], s2 = cst[HU_PC_S + 2], s3 = cst[HU_PC_S + 3];
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) { /* pi . e_U = 1 from here on: both ratios are invariant under a scaling of a_U */
-			const double piU = (s0 * aU[t][0] + s2 * aU[t][2]) + (s1 * aU[t][1] + s3 * aU[t][3]);
-			const double inv = 1.0 / piU;
-#pragma unroll
-			for(int m = 0; m < 4; ++m) aU[t][m] *= inv;
-		}
-	}
-	const double w0 = db.blen[u];
+	const double w0 = db.blen[un];
 	double lenUR = w0 * cd.ratio0, lenVR = w0 * (1 - cd.ratio0), lenNR = cd.wnr0;
 	double wur0 = lenUR, wnr0 = lenNR;
 	const double w0j = lenUR + lenVR;
 	double wur = wur0, wnr = wnr0;
 	int iter = 0, emIters = 0, phase = 0;
 	double rho[SPT];
+	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + v[t][2]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
+	stamp(0);
 	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
-		if(tid < 8 * Kc) {
-			const int which = tid / (4 * Kc), k = (tid >> 2) % Kc, m = tid & 3;
+		if(vt < 8 * Kc) {
+			const int which = vt / (4 * Kc), k = (vt >> 2) % Kc, m = vt & 3;
 			Etab[(which * HU_MAX_DGK + k) * 4 + m] = exp(clam[m] * ((which ? lenVR : lenUR) * crate[k]));
 		}
 		lds_barrier();
-		if(tid < 84) { /* G_mn = mean_k exp(lam_m w_ur r_k) exp(lam_n w_vr r_k) */
-			const int b = tid >> 4, m = tid < 80 ? (tid >> 2) & 3 : tid - 80, nn = tid < 80 ? tid & 3 : tid - 80;
+		if(vt < 16) { /* G_mn = mean_k exp(lam_m w_ur r_k) exp(lam_n w_vr r_k) */
+			const int m = vt >> 2, nn = vt & 3;
 			double g = 0;
 			for(int k = 0; k < Kc; ++k) g += Etab[k * 4 + m] * Etab[(HU_MAX_DGK + k) * 4 + nn];
-			g *= rKc;
-			if(tid < 80) tabM[b * HU_TP + m * 4 + nn] = cW[b * 16 + m * 4 + nn] * g;
-			else tabD[m] = g;
+			Gtab[vt] = g * rKc;
 		}
 		lds_barrier();
+		if(vt < 80) tabM[(vt >> 4) * HU_TP + (vt & 15)] = cW[vt] * Gtab[vt & 15];
+		else if(vt < 84) tabD[vt - 80] = Gtab[(vt - 80) * 5];
+		lds_barrier();
+		stamp(1);
 		/* (i) message r->n from children u, v against the read's leaf message; EM on the n-r branch */
-		double cnt = 0;
+		int nv = 0;
 		{
+			unsigned long long bq = bop;
+			asm volatile("" : "+v"(bq));  /* the per-site table addresses are recomputed per sweep, not kept live */
 			const double g0 = tabD[0], g1 = tabD[1], g2 = tabD[2], g3 = tabD[3];
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
-				const double* M = tabM + bo[t] * HU_TP;
-				double num = 0;
+				const double* M = tabM + (unsigned)((bq >> (3 * t)) & 7u) * HU_TP;
+				double num = fma(M[3], v[t][2], fma(M[2], v[t][1], fma(M[1], v[t][0], M[0])));
 #pragma unroll
-				for(int nn = 0; nn < 4; ++nn) {
-					const double tn = (aU[t][0] * M[0 * 4 + nn] + aU[t][2] * M[2 * 4 + nn]) + (aU[t][1] * M[1 * 4 + nn] + aU[t][3] * M[3 * 4 + nn]);
-					num = fma(tn, aV[t][nn], num);
+				for(int m = 1; m < 4; ++m) {
+					const double tm = fma(M[m * 4 + 3], v[t][2], fma(M[m * 4 + 2], v[t][1], fma(M[m * 4 + 1], v[t][0], M[m * 4 + 0])));
+					num = fma(tm, u[t][m - 1], num);
 				}
-				const double den = (g0 * aU[t][0] * aV[t][0] + g2 * aU[t][2] * aV[t][2]) + (g1 * aU[t][1] * aV[t][1] + g3 * aU[t][3] * aV[t][3]);
-				double r = fast_div(num, den);
-				const bool ok = tid + HU_BLK_THREADS * t < n && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
+				const double den = fma(g3 * u[t][2], v[t][2], fma(g2 * u[t][1], v[t][1], fma(g1 * u[t][0], v[t][0], g0)));
+				const double r = fast_div(num, den);
+				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
 				rho[t] = ok ? r : HU_RHO_SKIP;
-				cnt += ok ? 1.0 : 0.0;
+				nv += __popcll(__ballot(ok));
 			}
 		}
-		cnt = block_sum(cnt, red, phase);
-		wnr = em_branch_blk<SPT>(rho, cnt, lenNR, 1.0, red, phase, emIters);
+		stamp(2);
+		wnr = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenNR, 1.0, red, redc, phase, emIters);
 		lenNR = wnr;
-		if(tid < 4 * Kc) {
-			const int k = tid >> 2, m = tid & 3;
+		stamp(3);
+		if(vt < 4 * Kc) {
+			const int k = vt >> 2, m = vt & 3;
 			Etab[(2 * HU_MAX_DGK + k) * 4 + m] = exp(clam[m] * (lenNR * crate[k]));
 		}
 		lds_barrier();
-		if(tid < 100) { /* G'_mn = mean_k exp(lam_m w_vr r_k) exp(lam_n w_nr r_k); T^b_mn = c^b_n G'_mn */
-			const int b = tid < 80 ? tid >> 4 : (tid - 80) >> 2, m = tid < 80 ? (tid >> 2) & 3 : (tid - 80) & 3, kk = tid & 3;
-			double z = 0, tmm = 0;
-#pragma unroll
-			for(int nn = 0; nn < 4; ++nn) {
-				double g = 0;
-				for(int k = 0; k < Kc; ++k) g += Etab[(HU_MAX_DGK + k) * 4 + m] * Etab[(2 * HU_MAX_DGK + k) * 4 + nn];
-				const double T = ccb[b * 4 + nn] * (g * rKc);
-				z = fma(T, cC[(m * 4 + nn) * 4 + kk], z);
-				if(nn == m) tmm = T;
-			}
-			if(tid < 80) tabM[b * HU_TP + m * 4 + kk] = z;
-			else tabD[b * 4 + m] = tmm;
+		if(vt < 16) { /* G'_mn = mean_k exp(lam_m w_vr r_k) exp(lam_n w_nr r_k) */
+			const int m = vt >> 2, nn = vt & 3;
+			double g = 0;
+			for(int k = 0; k < Kc; ++k) g += Etab[(HU_MAX_DGK + k) * 4 + m] * Etab[(2 * HU_MAX_DGK + k) * 4 + nn];
+			Gtab[vt] = g * rKc;
 		}
 		lds_barrier();
-		/* (ii) message r->u from children v, n against u's own message; EM on the u-r branch */
-		cnt = 0;
+		if(vt < 80) { /* T^b_mn = c^b_n G'_mn; Z^b_mk = sum_n T^b_mn C_mnk */
+			const int b = vt >> 4, m = (vt >> 2) & 3, kk = vt & 3;
+			double z = 0;
 #pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			const double* M = tabM + bo[t] * HU_TP;
-			const double* D = tabD + bo[t] * 4;
-			double A = 0;
-#pragma unroll
-			for(int m = 0; m < 4; ++m) {
-				const double tm = (M[m * 4 + 0] * aU[t][0] + M[m * 4 + 2] * aU[t][2]) + (M[m * 4 + 1] * aU[t][1] + M[m * 4 + 3] * aU[t][3]);
-				A = fma(tm, aV[t][m], A);
-			}
-			const double piX = (D[0] * aV[t][0] + D[2] * aV[t][2]) + (D[1] * aV[t][1] + D[3] * aV[t][3]);
-			double r = fast_div(A, piX);
-			const bool ok = tid + HU_BLK_THREADS * t < n && fabs(r) < HU_RHO_SKIP;
-			rho[t] = ok ? r : HU_RHO_SKIP;
-			cnt += ok ? 1.0 : 0.0;
+			for(int nn = 0; nn < 4; ++nn) z = fma(ccb[b * 4 + nn] * Gtab[m * 4 + nn], cC[(m * 4 + nn) * 4 + kk], z);
+			tabM[b * HU_TP + m * 4 + kk] = z;
 		}
-		cnt = block_sum(cnt, red, phase);
-		wur = em_branch_blk<SPT>(rho, cnt, lenUR, w0j, red, phase, emIters);
+		else if(vt < 100) { const int b = (vt - 80) >> 2, m = (vt - 80) & 3; tabD[b * 4 + m] = ccb[b * 4 + m] * Gtab[m * 5]; }
+		lds_barrier();
+		stamp(1);
+		/* (ii) message r->u from children v, n against u's own message; EM on the u-r branch */
+		nv = 0;
+		{
+			unsigned long long bq = bop;
+			asm volatile("" : "+v"(bq));
+#pragma unroll
+			for(int t = 0; t < SPT; ++t) {
+				const unsigned bi = (unsigned)((bq >> (3 * t)) & 7u);
+				const double* M = tabM + bi * HU_TP;
+				const double* D = tabD + bi * 4;
+				double A = fma(M[3], u[t][2], fma(M[2], u[t][1], fma(M[1], u[t][0], M[0])));
+#pragma unroll
+				for(int m = 1; m < 4; ++m) {
+					const double tm = fma(M[m * 4 + 3], u[t][2], fma(M[m * 4 + 2], u[t][1], fma(M[m * 4 + 1], u[t][0], M[m * 4 + 0])));
+					A = fma(tm, v[t][m - 1], A);
+				}
+				const double piX = fma(D[3], v[t][2], fma(D[2], v[t][1], fma(D[1], v[t][0], D[0])));
+				const double r = fast_div(A, piX);
+				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP;
+				rho[t] = ok ? r : HU_RHO_SKIP;
+				nv += __popcll(__ballot(ok));
+			}
+		}
+		stamp(2);
+		wur = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenUR, w0j, red, redc, phase, emIters);
 		lenUR = wur;
 		lenVR = w0j - wur;
+		stamp(3);
 		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
 		wur0 = wur; wnr0 = wnr;
 	}
 	if(tid == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
+	if(DBG && tid == 0) {
+		tk[4] = (long long) __builtin_amdgcn_s_memtime() - t0; tk[5] = iter; tk[6] = emIters;
+		for(int i = 0; i < 8; ++i) dbg[(size_t) blockIdx.x * 8 + i] = tk[i];
+	}
 }

@@ -243,11 +243,18 @@ __device__ inline double dpp_add(double v) {
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
 	return v + __hiloint2double(hi, lo);
 }
+/* all lanes of the source are valid for the permutations within a row: no old value to keep (bound_ctrl) */
+template<int CTRL>
+__device__ inline double dpp_add_full(double v) {
+	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+	return v + __hiloint2double(hi, lo);
+}
 __device__ inline double wave_sum_uniform(double v) {
-	v = dpp_add<0xB1, 0xf>(v);   /* quad_perm:[1,0,3,2] */
-	v = dpp_add<0x4E, 0xf>(v);   /* quad_perm:[2,3,0,1] */
-	v = dpp_add<0x141, 0xf>(v);  /* row_half_mirror */
-	v = dpp_add<0x140, 0xf>(v);  /* row_mirror */
+	v = dpp_add_full<0xB1>(v);   /* quad_perm:[1,0,3,2] */
+	v = dpp_add_full<0x4E>(v);   /* quad_perm:[2,3,0,1] */
+	v = dpp_add_full<0x141>(v);  /* row_half_mirror */
+	v = dpp_add_full<0x140>(v);  /* row_mirror */
 	v = dpp_add<0x142, 0xa>(v);  /* row_bcast:15 into rows 1,3 */
 	v = dpp_add<0x143, 0xc>(v);  /* row_bcast:31 into rows 2,3 */
 	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
