@@ -846,8 +846,8 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 	if(nc) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
-		const int spt = (maxR + HU_BLK_THREADS - 1) / HU_BLK_THREADS;
-		const bool stream = getenv("HU_STREAMING_SEP") != nullptr || spt > 12;
+		const int spt2 = (maxR + 127) / 128, spt4 = (maxR + 255) / 256;  /* sites per thread with 2 / 4 waves per candidate */
+		const bool stream = getenv("HU_STREAMING_SEP") != nullptr || spt4 > 12;
 		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
 		#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
 		if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
@@ -857,43 +857,33 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			Timer t(b, HU_T_PLACE);
 			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(PL_ARGS);
 		}
-		else { /* one workgroup per candidate, messages and per-site ratios register-resident */
+		else { /* one workgroup per candidate, messages and per-site ratios register-resident.  Measured on MI355X
+		        * (8192 reads, R = 1363, 25.6 candidates per read): 4 waves x 6 sites 11.9 ms, 2 waves x 12 sites with two
+		        * workgroups per SIMD pair 9.5 ms (fewer reduction / exchange / loop instructions per candidate) */
 			Timer t(b, HU_T_PLACE);
 			const char* ev = getenv("HU_PLACE_VAR");
 			const int var = ev ? atoi(ev) : 0;
 			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS)
-			if(spt <= 2) PL_GO(2, 4, 2, 1, 1);
-			else if(spt <= 4) PL_GO(4, 4, 2, 1, 1);
-			else if(spt <= 6) {
-				switch(var) {
-				case 99: { /* diagnostic: per-phase s_memtime stamps, summed over the candidates, to stderr */
-					long long* dd = nullptr;
-					HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
-					k_place_blk<6, 4, 1, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
-					std::vector<long long> hd(nc * 8);
-					HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
-					HIPCHK(hipStreamSynchronize(b->stream));
-					(void) hipFree(dd);
-					double acc[8] = {0};
-					for(size_t c = 0; c < nc; ++c) for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i];
-					fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
-							acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
-					break;
-				}
-				case 1: PL_GO(6, 4, 1, 1, 1); break;
-				case 2: PL_GO(6, 4, 2, 0, 1); break;
-				case 3: PL_GO(6, 4, 1, 0, 1); break;
-				case 10: PL_GO(6, 4, 2, 1, 3); break;
-				case 11: PL_GO(6, 4, 1, 1, 3); break;
-				case 20: PL_GO(12, 2, 2, 1, 1); break;
-				case 21: PL_GO(12, 2, 1, 1, 1); break;
-				case 22: PL_GO(12, 2, 1, 1, 2); break;
-				case 23: PL_GO(12, 2, 1, 0, 2); break;
-				default: PL_GO(6, 4, 2, 1, 1); break;
-				}
+			if(var == 99 && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
+				long long* dd = nullptr;
+				HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
+				k_place_blk<6, 4, 1, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
+				std::vector<long long> hd(nc * 8);
+				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+				HIPCHK(hipStreamSynchronize(b->stream));
+				(void) hipFree(dd);
+				double acc[8] = {0};
+				for(size_t c = 0; c < nc; ++c) for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i];
+				fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
+						acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
 			}
-			else if(spt <= 8) PL_GO(8, 4, 2, 1, 1);
-			else PL_GO(12, 4, 2, 1, 1);
+			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
+			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
+			else if(spt2 <= 4) PL_GO(4, 2, 1, 0, 2);
+			else if(spt2 <= 8) PL_GO(8, 2, 1, 0, 2);
+			else if(spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
+			else if(spt4 <= 8) PL_GO(8, 4, 1, 0, 1);
+			else PL_GO(12, 4, 1, 0, 1);
 			#undef PL_GO
 		}
 		#undef PL_ARGS
