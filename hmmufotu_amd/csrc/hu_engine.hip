@@ -765,12 +765,22 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
 		 * streaming 12.3 ms with twice the HBM traffic. */
 		const int spt = (maxR + 255) / 256;
+		const char* ev = getenv("HU_EST_VAR");
+		const int var = ev ? atoi(ev) : 0;
 		if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 4) k_estimate_blk<4, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 6) k_estimate_blk<6, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(var == 2) { /* the per-site log() form, kept for comparison */
+			if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+			else if(spt <= 4) k_estimate_blk<4, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+			else if(spt <= 6) k_estimate_blk<6, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+			else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+			else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		}
+		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<eg, 128, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 2) k_estimate_prod<2, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 4) k_estimate_prod<4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 6) k_estimate_prod<6, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(spt <= 8) k_estimate_prod<8, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else k_estimate_prod<12, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
 		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());

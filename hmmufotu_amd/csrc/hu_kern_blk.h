@@ -11,6 +11,9 @@
 
 #define HU_BLK_THREADS 256
 
+/* orders a wave's own LDS writes before its own later LDS reads (a wave's LDS queue is in order; this waits for
+ * the returns and keeps the compiler from moving accesses across) */
+__device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* sum over the workgroup, identical in every thread; `red` is a [2][4] LDS scratch, `phase` toggles */
@@ -129,6 +132,185 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
 	const long long kt = block_sum_ll<NW>(ksum, redl, lphase);
 	ll += (double) kt * HU_LN2;
 	if(tid == 0) { HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = ll; out[(size_t) read * HU_MAX_SEEDS + s] = o; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * k_estimate_prod: estimateSeq (src/PhyloTreeUnrooted.cpp:849-877) with the per-site logarithm removed.
+ *
+ * sum_j log x_j = log prod_j x_j: each site contributes its mantissa to a running product and its binary
+ * exponent to an integer sum (v_frexp_mant_f64, v_frexp_exp_i32_f64, v_mul_f64, v_add_i32: 4 instructions
+ * instead of the ~50 of log()); products are renormalised per thread, multiplied across the wave on the DPP
+ * network and across the waves through LDS, and ONE log() per (read, seed) closes the sum, together with the
+ * integer exponents of the packed messages (k of 2^-k).  Relative error of the product of R mantissas is
+ * <= R 2^-53, i.e. an absolute error of ~1.5e-13 on a log-likelihood of ~-1e3.
+ * Pass 2 is table-driven: x_j = sum_i Q^b_i z_i with Q^b_i = pi_i (P(wnr) e_b)_i for a base b and
+ * pi_i (P(wnr) pi)_i for a gap; every wave builds its own copy of the 5 x 4 table (no workgroup barrier).
+ * Component 0 of a message in the eigenbasis is pi . e and U(i,0) = 1, lam_0 = 0 (hu_model_prepare):
+ * (P(t) e)_i = a_0 + sum_{m>0} U_im exp(lam_m t) a_m. */
+template<int CTRL>
+__device__ inline double dpp_mul_full(double v) {
+	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+	return v * __hiloint2double(hi, lo);
+}
+/* product over the 64 lanes (in every lane): butterfly of xor-shuffles where DPP has no pattern */
+__device__ inline double wave_prod(double v) {
+	v = dpp_mul_full<0xB1>(v);   /* quad_perm:[1,0,3,2] */
+	v = dpp_mul_full<0x4E>(v);   /* quad_perm:[2,3,0,1] */
+	v = dpp_mul_full<0x141>(v);  /* row_half_mirror */
+	v = dpp_mul_full<0x140>(v);  /* row_mirror */
+	v *= __shfl_xor(v, 16);
+	v *= __shfl_xor(v, 32);
+	return v;
+}
+__device__ inline int wave_sum_i32(int v) {
+	for(int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+	return v;
+}
+
+template<int SPT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
+		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
+		int weighted, HuEstOut* __restrict__ out) {
+	constexpr int THREADS = 64 * NW;
+	__shared__ double redd[2 * NW];
+	__shared__ int redi[2 * NW];
+	__shared__ __attribute__((aligned(16))) double Qtab[NW][24];   /* [wave][0..3] = exp(lam_m wnr), [4 + b * 4 + i] = Q^b_i */
+	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if(s >= seedCnt[read]) return;
+	const int un = seedId[(size_t) read * HU_MAX_SEEDS + s];
+	const int vn = db.parent[un];
+	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
+	const uint32_t pv = pairs[(size_t) read * db.nNodesPad + vn];
+	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
+	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
+	double ratio = cDist / (cDist + pDist);
+	if(isnan(ratio)) ratio = 0.5;
+	const double w0 = db.blen[un];
+	const double wur = w0 * ratio, wvr = w0 - wur;
+	double Eu[3], Ev[3];
+#pragma unroll
+	for(int k = 0; k < 3; ++k) { Eu[k] = exp(mdl.lam[k + 1] * wur); Ev[k] = exp(mdl.lam[k + 1] * wvr); }
+	const int start = rstart[read], end = rend[read], n = end - start + 1;
+	const int8_t* __restrict__ cd = codes + (size_t) read * db.csLen + start;
+	const int64_t sOff = (int64_t) un * db.winLen + (start - db.winStart);
+	const int piMax = argmax4d(mdl.logpi);
+	/* one pass over HBM: z_i = (P(wur) e^U)_i (P(wvr) e^V)_i of the thread's sites stays in registers */
+	double z[SPT][4]; unsigned long long bop = 0; int ksum = 0;
+	{
+		double aU[SPT][4], aV[SPT][4];
+#pragma unroll
+		for(int t = 0; t < SPT; ++t) {
+			const int j = tid + THREADS * t;
+			const int jj = j < n ? j : 0;
+			load4(db.up + (sOff + jj) * 4, aU[t]); load4(db.down + (sOff + jj) * 4, aV[t]);
+			const int b = cd[jj];
+			bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
+			if(j < n) ksum += db.upK[sOff + jj] + db.downK[sOff + jj];
+		}
+#pragma unroll
+		for(int t = 0; t < SPT; ++t) {
+			const double su1 = Eu[0] * aU[t][1], su2 = Eu[1] * aU[t][2], su3 = Eu[2] * aU[t][3];
+			const double sv1 = Ev[0] * aV[t][1], sv2 = Ev[1] * aV[t][2], sv3 = Ev[2] * aV[t][3];
+#pragma unroll
+			for(int i = 0; i < 4; ++i) {
+				const double cu = fmax(fma(mdl.U[i*4+3], su3, fma(mdl.U[i*4+2], su2, fma(mdl.U[i*4+1], su1, aU[t][0]))), 0.0);
+				const double cv = fmax(fma(mdl.U[i*4+3], sv3, fma(mdl.U[i*4+2], sv2, fma(mdl.U[i*4+1], sv1, aV[t][0]))), 0.0);
+				z[t][i] = cu * cv;
+			}
+		}
+	}
+	/* wnr: fraction of sites whose inferred state differs from the read's (method "unweighted"), or the
+	 * weighted form of src/PhyloTreeUnrooted.cpp:1034-1052 */
+	double wnr;
+	if(!weighted) {
+		int nd = 0;
+#pragma unroll
+		for(int t = 0; t < SPT; ++t) {
+			const int bi = (int)((bop >> (3 * t)) & 7u);
+			const int b1 = argmax4_tied_lin(z[t]), b2 = bi < 4 ? bi : piMax;
+			nd += __popcll(__ballot(tid + THREADS * t < n && b1 != b2));
+		}
+		if(lane == 0) redi[wave] = nd;
+		lds_barrier();
+		int tot = redi[0];
+#pragma unroll
+		for(int w = 1; w < NW; ++w) tot += redi[w];
+		wnr = (double) tot / (double) n;
+	}
+	else {
+		double piw[4];
+		{ double mx = max4d(mdl.logpi), sm; for(int i = 0; i < 4; ++i) piw[i] = exp(mdl.logpi[i] - mx); sm = (piw[0] + piw[2]) + (piw[1] + piw[3]); for(int i = 0; i < 4; ++i) piw[i] /= sm; }
+		double dsum = 0, nsum = 0;
+#pragma unroll
+		for(int t = 0; t < SPT; ++t) {
+			if(tid + THREADS * t >= n) continue;
+			const int bi = (int)((bop >> (3 * t)) & 7u);
+			const int b1 = argmax4_tied_lin(z[t]), b2 = bi < 4 ? bi : piMax;
+			const double w1 = sel4(z[t], b1) / ((z[t][0] + z[t][2]) + (z[t][1] + z[t][3]));
+			const double w2 = bi < 4 ? 1.0 : piw[b2];
+			if(b1 != b2) dsum += w1 * w2;
+			nsum += w1 * w2;
+		}
+		dsum = wave_sum(dsum); nsum = wave_sum(nsum);
+		if(lane == 0) { redd[wave] = dsum; redd[NW + wave] = nsum; }
+		lds_barrier();
+		double a = redd[0], c = redd[NW];
+#pragma unroll
+		for(int w = 1; w < NW; ++w) { a += redd[w]; c += redd[NW + w]; }
+		wnr = a / c;
+		lds_barrier();   /* redd is reused below */
+	}
+	/* Q^b_i = pi_i (P(wnr) c^b)_i, c^b = e_b or pi; this wave's own copy */
+	double* Q = Qtab[wave];
+	if(lane < 3) Q[1 + lane] = exp((lane == 0 ? mdl.lam[1] : lane == 1 ? mdl.lam[2] : mdl.lam[3]) * wnr);
+	lds_wave_sync();
+	if(lane < 20) {
+		const int b = lane >> 2, i = lane & 3;
+		const double pii = sel4(mdl.pi, i);
+		double c;
+		if(wnr == 0) c = b < 4 ? (i == b ? 1.0 : 0.0) : pii;
+		else {
+			/* a = U^-1 c^b: column b of U1, or U1 . pi */
+			double a0, a1, a2, a3;
+			if(b < 4) { a0 = sel4(mdl.U1 + 0, b); a1 = sel4(mdl.U1 + 4, b); a2 = sel4(mdl.U1 + 8, b); a3 = sel4(mdl.U1 + 12, b); }
+			else {
+				a0 = (mdl.U1[0] * mdl.pi[0] + mdl.U1[1] * mdl.pi[1]) + (mdl.U1[2] * mdl.pi[2] + mdl.U1[3] * mdl.pi[3]);
+				a1 = (mdl.U1[4] * mdl.pi[0] + mdl.U1[5] * mdl.pi[1]) + (mdl.U1[6] * mdl.pi[2] + mdl.U1[7] * mdl.pi[3]);
+				a2 = (mdl.U1[8] * mdl.pi[0] + mdl.U1[9] * mdl.pi[1]) + (mdl.U1[10] * mdl.pi[2] + mdl.U1[11] * mdl.pi[3]);
+				a3 = (mdl.U1[12] * mdl.pi[0] + mdl.U1[13] * mdl.pi[1]) + (mdl.U1[14] * mdl.pi[2] + mdl.U1[15] * mdl.pi[3]);
+			}
+			const double Ui1 = i == 0 ? mdl.U[1] : i == 1 ? mdl.U[5] : i == 2 ? mdl.U[9] : mdl.U[13];
+			const double Ui2 = i == 0 ? mdl.U[2] : i == 1 ? mdl.U[6] : i == 2 ? mdl.U[10] : mdl.U[14];
+			const double Ui3 = i == 0 ? mdl.U[3] : i == 1 ? mdl.U[7] : i == 2 ? mdl.U[11] : mdl.U[15];
+			c = fmax(fma(Ui3, Q[3] * a3, fma(Ui2, Q[2] * a2, fma(Ui1, Q[1] * a1, a0))), 0.0);
+		}
+		Q[4 + b * 4 + i] = pii * c;
+	}
+	lds_wave_sync();
+	/* log-likelihood: product of the mantissas, sum of the exponents */
+	double mant = 1.0; int esum = ksum;
+#pragma unroll
+	for(int t = 0; t < SPT; ++t) {
+		const double* q = Q + 4 + ((bop >> (3 * t)) & 7u) * 4;
+		double x = fmax(fma(q[3], z[t][3], fma(q[2], z[t][2], fma(q[1], z[t][1], q[0] * z[t][0]))), 0.0);
+		if(tid + THREADS * t >= n) x = 1.0;
+		mant *= __builtin_amdgcn_frexp_mant(x);
+		esum += x == 0.0 ? 0 : __builtin_amdgcn_frexp_exp(x);
+	}
+	esum += __builtin_amdgcn_frexp_exp(mant); mant = __builtin_amdgcn_frexp_mant(mant);   /* in [0.5, 1): 64 of them stay normal */
+	mant = wave_prod(mant);
+	esum = wave_sum_i32(esum);
+	if(lane == 0) { redd[wave] = mant; redi[NW + wave] = esum; }
+	lds_barrier();
+	if(tid == 0) {
+		double m = redd[0]; long long e = redi[NW];
+#pragma unroll
+		for(int w = 1; w < NW; ++w) { m *= redd[w]; e += redi[NW + w]; }
+		HuEstOut o; o.ratio = ratio; o.wnr = wnr; o.loglik = log(m) + (double) e * HU_LN2;
+		out[(size_t) read * HU_MAX_SEEDS + s] = o;
+	}
 }
 
 /* ------------------------------------------------------------------------------------------------
