@@ -53,6 +53,12 @@ struct HuDbDev {
 	const double* entryC;
 	const double* exitC;
 	const int32_t* p2cs;       /* [K+2] */
+	/* the same profile, one array per field ([7][K+1], [4][K+1], [4][K+1]): along an anti-diagonal of the DP
+	 * consecutive lanes sit in consecutive columns, so these loads coalesce (the [K+1][8] rows above put every
+	 * lane on its own cache line: k_viterbi_lds was bound by L1 tag throughput and by its 24-B-per-cell stores) */
+	const double* Tt;
+	const double* EMt;
+	const double* EIt;
 	const double* placeConst;  /* [HU_PC_COUNT] */
 };
 
@@ -63,8 +69,12 @@ struct HuRegion {
 	int32_t band;              /* 1: only cells with -nDel <= (i-from)-(j-start) <= nIns           */
 	int32_t from, start, nIns, nDel;
 	int64_t off;               /* first cell of this region in the read's scratch                 */
+	int64_t doff;              /* first byte of this region in the read's decision scratch: one byte per cell in
+	                            * anti-diagonal order, [dg][q] with pitch (i1 - i0 + 1)                        */
 };
 #define HU_MAX_REGIONS 6
+#define HU_READ_NEEDS_VALUES 8   /* internal: the decision-byte traceback met a cell whose predecessor a later phase
+                                  * rewrote (or left the computed cells): redone with the value-filing kernels */
 
 struct HuReadDesc {
 	int64_t baseOff;           /* offset of the read's codes in the batch's code buffer          */
@@ -72,6 +82,7 @@ struct HuReadDesc {
 	int32_t nRegions;
 	int64_t scratchOff;        /* first cell of the read in the DP scratch                        */
 	int64_t traceOff;
+	int64_t decOff;            /* first byte of the read in the decision scratch                  */
 	HuRegion reg[HU_MAX_REGIONS];
 };
 

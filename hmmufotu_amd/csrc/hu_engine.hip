@@ -210,6 +210,17 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		if((rc = dev_upload(db, &q, db->prof.entryC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.entryC = q;
 		if((rc = dev_upload(db, &q, db->prof.exitC.data(), (size_t) K + 1)) != HU_OK) return fail(rc); d.exitC = q;
 		if((rc = dev_upload(db, &p, p2.data(), p2.size())) != HU_OK) return fail(rc); d.p2cs = p;
+		{
+			const size_t K1 = (size_t) K + 1;
+			std::vector<double> Tt(7 * K1), EMt(4 * K1), EIt(4 * K1);
+			for(int k = 0; k <= K; ++k) {
+				for(int t = 0; t < 7; ++t) Tt[t * K1 + k] = db->prof.T7[(size_t) k * 7 + t];
+				for(int c = 0; c < 4; ++c) { EMt[c * K1 + k] = db->prof.EM[(size_t) k * 4 + c]; EIt[c * K1 + k] = db->prof.EI[(size_t) k * 4 + c]; }
+			}
+			if((rc = dev_upload(db, &q, Tt.data(), Tt.size())) != HU_OK) return fail(rc); d.Tt = q;
+			if((rc = dev_upload(db, &q, EMt.data(), EMt.size())) != HU_OK) return fail(rc); d.EMt = q;
+			if((rc = dev_upload(db, &q, EIt.data(), EIt.size())) != HU_OK) return fail(rc); d.EIt = q;
+		}
 		double pc[HU_PC_COUNT];
 		hu_place_consts(db->mdl, pc);
 		if((rc = dev_upload(db, &q, pc, (size_t) HU_PC_COUNT)) != HU_OK) return fail(rc); d.placeConst = q;
@@ -429,6 +440,7 @@ struct hu_batch {
 	DBuf<char> dBases, dTraces, dRows;
 	DBuf<HuReadDesc> dDescs;
 	DBuf<double> dScratch;
+	DBuf<uint8_t> dDec;
 	DBuf<HuVitOut> dVit;
 	DBuf<HuAlnDev> dAlns;
 	DBuf<int8_t> dCodes;
@@ -444,6 +456,7 @@ struct hu_batch {
 	std::vector<HuReadDesc> hDescs;
 	std::vector<char> hBases;
 	std::vector<HuVitOut> hVit;
+	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
 	std::vector<HuAlnDev> hAlns;
 	std::vector<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
 	std::vector<uint32_t> hSeedDN;
@@ -477,7 +490,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	if(!b) return;
 	(void) hipSetDevice(b->db->device);
 	(void) hipStreamSynchronize(b->stream);
-	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dVit.free_(); b->dAlns.free_();
+	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
 	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
@@ -509,13 +522,16 @@ static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */
 		if(valid && x.end <= K && x.to <= L) v[nv++] = x;
 	}
 	rd.nRegions = 0;
-	int64_t off = 0;
+	int64_t off = 0, doff = 0;
 	auto add = [&](int j0, int j1, int i0, int i1, int withB, int band, const VP* bp) {
 		HuRegion& g = rd.reg[rd.nRegions++];
 		g.j0 = j0; g.j1 = j1; g.i0 = i0; g.i1 = i1; g.withB = withB; g.band = band;
 		g.from = bp ? bp->from : 0; g.start = bp ? bp->start : 0; g.nIns = bp ? bp->nIns : 0; g.nDel = bp ? bp->nDel : 0;
-		g.off = off;
-		if(j1 >= j0 && i1 >= i0) off += (int64_t)(j1 - j0 + 1) * (i1 - i0 + 1);
+		g.off = off; g.doff = doff;
+		if(j1 >= j0 && i1 >= i0) {
+			off += (int64_t)(j1 - j0 + 1) * (i1 - i0 + 1);
+			doff += (int64_t)((j1 - j0 + 1) + (i1 - i0 + 1) - 1) * (i1 - i0 + 1);
+		}
 	};
 	if(nv == 0) add(1, K, 1, L, 1, 0, nullptr); /* full Viterbi (src/BandedHMMP7.cpp:748-771) */
 	else {
@@ -538,6 +554,7 @@ static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */
 		add(last.end, down_end, last.to, down_to, 0, 0, nullptr);
 	}
 	rd.scratchOff = off; /* total cells for now; turned into an offset by the caller */
+	rd.decOff = doff;    /* likewise: total decision bytes */
 }
 
 static int upload_descs(hu_batch* b) {
@@ -555,7 +572,7 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 	b->n = n; b->paired = mates != nullptr; b->nSeq = b->paired ? 2 * n : n; b->fromCodes = false;
 	b->hDescs.assign(b->nSeq, HuReadDesc());
 	b->hBases.clear();
-	int64_t cells = 0, tr = 0;
+	int64_t cells = 0, tr = 0, decs = 0;
 	for(int s = 0; s < b->nSeq; ++s) {
 		const bool isMate = s >= n;
 		const int r = isMate ? s - n : s;
@@ -571,8 +588,9 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 			b->hBases.insert(b->hBases.end(), src, src + len64);
 			const int32_t* vp = isMate ? (mvpaths ? mvpaths + (size_t) r * 12 : nullptr) : (vpaths ? vpaths + (size_t) r * 12 : nullptr);
 			build_regions(b->db, rd.len, vp, rd);
-			const int64_t c = rd.scratchOff;
+			const int64_t c = rd.scratchOff, dc = rd.decOff;
 			rd.scratchOff = cells; cells += c;
+			rd.decOff = decs; decs += dc;
 		}
 		else { rd.len = 0; rd.nRegions = 0; }
 		rd.traceOff = tr;
@@ -581,6 +599,7 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 	int rc;
 	if((rc = b->dBases.ensure(b->hBases.size() + 1)) != HU_OK) return rc;
 	if((rc = b->dScratch.ensure((size_t) cells * 3 + 1)) != HU_OK) return rc;
+	if((rc = b->dDec.ensure((size_t) decs + 1)) != HU_OK) return rc;
 	if((rc = b->dTraces.ensure((size_t) tr + 1)) != HU_OK) return rc;
 	if((rc = b->dVit.ensure(b->nSeq)) != HU_OK) return rc;
 	if(!b->hBases.empty()) HIPCHK(hipMemcpyAsync(b->dBases.p, b->hBases.data(), b->hBases.size(), hipMemcpyHostToDevice, b->stream));
@@ -653,19 +672,41 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 		int maxLen = 1;
 		for(int s = 0; s < b->nSeq; ++s) maxLen = std::max(maxLen, (int) b->hDescs[s].len);
 		const int ldsRows = maxLen + 1;
+		bool usedDec = false;
 		const size_t vlds = (size_t) 9 * ldsRows * sizeof(double);
 		{
 			Timer t(b, HU_T_VITERBI);
 			if(vlds <= 96 * 1024 && !getenv("HU_VITERBI_HBM")) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
-				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
-				k_viterbi_lds<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
-				k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
+				if(!getenv("HU_VITERBI_VALUES")) { /* one decision byte per cell; (M, I, D) only where a later phase looks */
+					if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+					k_viterbi_dec<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
+					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, getenv("HU_VITERBI_FORCE_REDO") != nullptr);
+					usedDec = true;
+				}
+				else {
+					if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+					k_viterbi_lds<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows, 0);
+					k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
+				}
 			}
 			else k_viterbi<<<b->nSeq, 64, 0, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p);
 		}
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
+		if(usedDec) { /* sequences whose traceback cannot trust the fill-time decisions: redo with every value filed */
+			int nRedo = 0;
+			for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_VALUES) nRedo++;
+			b->nVitRedo = nRedo;
+			if(nRedo) {
+				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+				k_viterbi_lds<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows, HU_READ_NEEDS_VALUES);
+				k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
+				HIPCHK(hipGetLastError());
+				HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
+				HIPCHK(hipStreamSynchronize(b->stream));
+			}
+		}
 		/* banded version failed -> regular HMM (src/HmmUFOtu_main.cpp:89-93), one sequence at a time */
 		std::vector<int> redo;
 		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL && !(b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) redo.push_back(s);

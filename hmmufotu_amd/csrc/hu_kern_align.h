@@ -285,11 +285,12 @@ __device__ inline void vit_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\
 
 __global__ __launch_bounds__(HU_VIT_THREADS) void k_viterbi_lds(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
 		double* __restrict__ scratch, char* __restrict__ traces, double tNN, double tNB, double tEC, double tCC,
-		HuVitOut* __restrict__ outs, int ldsRows) {
+		HuVitOut* __restrict__ outs, int ldsRows, int onlyStatus) {
 	extern __shared__ double vsh[];
 	__shared__ double redS[HU_VIT_THREADS / 64];
 	__shared__ int redC[HU_VIT_THREADS / 64], redR[HU_VIT_THREADS / 64];
 	const int s = blockIdx.x, tid = threadIdx.x;
+	if(onlyStatus && outs[s].status != onlyStatus) return;   /* redo pass: only the sequences flagged by k_viterbi_trace_dec */
 	const HuReadDesc& rd = descs[s];
 	const int L = rd.len, K = db.K;
 	if(rd.nRegions <= 0) { if(tid == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
@@ -373,11 +374,174 @@ __global__ __launch_bounds__(64) void k_viterbi_trace(HuDbDev db, const HuReadDe
 	const int s = blockIdx.x * 64 + threadIdx.x;
 	if(s >= nSeq) return;
 	HuVitOut o = outs[s];
-	if(o.traceLen != -1) return; /* invalid read, or already traced */
+	if(o.traceLen != -1 || o.status == HU_READ_NEEDS_VALUES) return; /* invalid read, already traced, or waiting for the redo pass */
 	const HuReadDesc& rd = descs[s];
 	VitCtx ctx = { &rd, scratch + rd.scratchOff * 3, tNN, tNB };
 	const double bestS = o.minScore; const int bestCol = o.alnEnd, bestRow = o.alnTo;
 	vit_trace(db, ctx, rd, traces, bestS, bestCol, bestRow, o);
+	outs[s] = o;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Decision-byte variant of the LDS wavefront.  The reference's traceback re-evaluates, at every cell of
+ * the path, the candidate sums of its predecessor on the FINAL matrices (whichMin, first strict minimum
+ * in the order B, M, I, D).  Those sums are known when the cell is filled, and they are the final ones
+ * unless a LATER phase rewrites the predecessor — which the traceback checks per step from the region
+ * descriptors.  So the fill kernel files ONE byte per cell (what the traceback would choose in state M, I
+ * and D at that cell) instead of three doubles, in anti-diagonal order so that a step's stores are
+ * consecutive bytes, and the (M, I, D) values only of the cells inside the boxes of later phases (their
+ * perimeter look-ups).  k_viterbi_lds wrote 21 GB per 8192 reads of 250 bp and ran at the speed of those
+ * stores; this one writes 0.4 GB.  A sequence whose traceback meets a rewritten predecessor, or leaves the
+ * computed cells, is flagged HU_READ_NEEDS_VALUES and redone by the value-filing kernels.
+ * Profile fields come from the per-field arrays (HuDbDev::Tt/EMt/EIt): consecutive lanes, consecutive columns. */
+__global__ __launch_bounds__(HU_VIT_THREADS) void k_viterbi_dec(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		double* __restrict__ scratch, uint8_t* __restrict__ dec, double tNN, double tNB, double tEC, double tCC,
+		HuVitOut* __restrict__ outs, int ldsRows) {
+	extern __shared__ double vsh[];
+	__shared__ double redS[HU_VIT_THREADS / 64];
+	__shared__ int redC[HU_VIT_THREADS / 64], redR[HU_VIT_THREADS / 64];
+	const int s = blockIdx.x, tid = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const int L = rd.len, K = db.K;
+	const size_t K1 = (size_t) K + 1;
+	if(rd.nRegions <= 0) { if(tid == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	const char* __restrict__ x = bases + rd.baseOff;
+	double* scr = scratch + rd.scratchOff * 3;
+	uint8_t* dcs = dec + rd.decOff;
+	VitCtx ctx = { &rd, scr, tNN, tNB };
+	double bestS = INFINITY; int bestCol = 0x7fffffff, bestRow = 0x7fffffff;
+	const int nR = rd.nRegions;
+	for(int r = 0; r < nR; ++r) {
+		const HuRegion g = rd.reg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		for(int dg = 0; dg <= ni + nj - 2; ++dg) {
+			double* cur = vsh + (size_t)(dg % 3) * 3 * ldsRows;
+			const double* p1 = vsh + (size_t)((dg + 2) % 3) * 3 * ldsRows;
+			const double* p2 = vsh + (size_t)((dg + 1) % 3) * 3 * ldsRows;
+			const int lo = dg - (nj - 1) > 0 ? dg - (nj - 1) : 0, hi = dg < ni - 1 ? dg : ni - 1;
+			for(int q = lo + tid; q <= hi; q += HU_VIT_THREADS) {
+				const int i = g.i0 + q, j = g.j0 + dg - q;
+				const int dist = (i - g.from) - (j - g.start);
+				if(g.band && !(dist <= g.nIns && dist >= -g.nDel)) continue;
+				const int b = c_sym_map[(int) x[i - 1] & 127];
+				double mD, iD, dD, mU, iU, dU, mL, iL, dL;
+				if(q >= 1 && j - 1 >= g.j0) { mD = p2[q - 1]; iD = p2[ldsRows + q - 1]; dD = p2[2 * ldsRows + q - 1]; }
+				else vit_lookup(ctx, r, i - 1, j - 1, mD, iD, dD);
+				if(q >= 1 && (!g.band || dist - 1 >= -g.nDel)) { mU = p1[q - 1]; iU = p1[ldsRows + q - 1]; }
+				else vit_lookup(ctx, r, i - 1, j, mU, iU, dU);
+				if(j - 1 >= g.j0 && (!g.band || dist + 1 <= g.nIns)) { mL = p1[q]; dL = p1[2 * ldsRows + q]; }
+				else vit_lookup(ctx, r, i, j - 1, mL, iL, dL);
+				const double* tp = db.Tt + (j - 1);   /* field f of column j - 1: tp[f * K1] */
+				const double* tj = db.Tt + j;
+				const double pB = vit_bcol(ctx, i) + db.entryC[j];
+				const double pM = mD + tp[0], pI = iD + tp[3 * K1], pD = dD + tp[5 * K1];
+				double best = fmin(pM, fmin(pI, pD));
+				if(g.withB) best = fmin(pB, best);
+				const double uM = mU + tj[1 * K1], uI = iU + tj[4 * K1];
+				const double lM = mL + tp[2 * K1], lD = dL + tp[6 * K1];
+				const double M = db.EMt[(size_t) b * K1 + j] + best;
+				const double I = db.EIt[(size_t) b * K1 + j] + fmin(uM, uI);
+				const double D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
+				cur[q] = M; cur[ldsRows + q] = I; cur[2 * ldsRows + q] = D;
+				/* what buildViterbiTrace (src/BandedHMMP7.cpp:956-1000) chooses at this cell: B is a candidate in
+				 * every phase there, and column 1 has no M / D predecessor */
+				int dM = 0;
+				{
+					double mn = INFINITY;
+					if(pB < mn) { dM = 0; mn = pB; }
+					if(j > 1 && pM < mn) { dM = 1; mn = pM; }
+					if(pI < mn) { dM = 2; mn = pI; }
+					if(j > 1 && pD < mn) { dM = 3; mn = pD; }
+				}
+				const int dI = uI < uM ? 1 : 0, dDd = lD < lM ? 1 : 0;
+				dcs[g.doff + (int64_t) dg * ni + q] = (uint8_t)(dM | (dI << 2) | (dDd << 3));
+				bool later = false, near = false;
+				for(int r2 = r + 1; r2 < nR; ++r2) {
+					const HuRegion& g2 = rd.reg[r2];
+					if(reg_contains(g2, i, j)) later = true;
+					if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
+				}
+				if(near) { /* a later phase may look this cell up */
+					const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + q) * 3;
+					scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+				}
+				if(!later) {
+					const double cc = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+					double sv = __dadd_rn(__dadd_rn(M, db.exitC[j]), tEC);
+					if(i < L) sv = __dadd_rn(sv, cc);
+					if(sv < bestS || (sv == bestS && (j < bestCol || (j == bestCol && i < bestRow)))) { bestS = sv; bestCol = j; bestRow = i; }
+					if(j == K) {
+						double s2 = __dadd_rn(__dadd_rn(I, db.T[(size_t) K * 8 + 3]), tEC);
+						if(i < L) s2 = __dadd_rn(s2, cc);
+						if(s2 < bestS || (s2 == bestS && (K + 1 < bestCol || (K + 1 == bestCol && i < bestRow)))) { bestS = s2; bestCol = K + 1; bestRow = i; }
+					}
+				}
+			}
+			vit_lds_barrier();
+		}
+		/* the values filed for later phases must have left this CU's write path before they are looked up */
+		__syncthreads();
+	}
+	for(int m = 32; m > 0; m >>= 1) {
+		const double os = __shfl_xor(bestS, m); const int oc = __shfl_xor(bestCol, m), orow = __shfl_xor(bestRow, m);
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	if((tid & 63) == 0) { redS[tid >> 6] = bestS; redC[tid >> 6] = bestCol; redR[tid >> 6] = bestRow; }
+	__syncthreads();
+	if(tid != 0) return;
+	for(int wv = 1; wv < HU_VIT_THREADS / 64; ++wv) {
+		const double os = redS[wv]; const int oc = redC[wv], orow = redR[wv];
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	HuVitOut o;
+	o.minScore = bestS; o.alnEnd = bestCol; o.alnTo = bestRow; o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
+	outs[s] = o;
+}
+
+/* traceback on the decision bytes, one lane per sequence */
+__global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuReadDesc* __restrict__ descs, const uint8_t* __restrict__ dec,
+		char* __restrict__ traces, HuVitOut* __restrict__ outs, int nSeq, int forceRedo) {
+	const int s = blockIdx.x * 64 + threadIdx.x;
+	if(s >= nSeq) return;
+	HuVitOut o = outs[s];
+	if(o.traceLen != -1) return; /* invalid read */
+	const HuReadDesc& rd = descs[s];
+	const int K = db.K, R = rd.nRegions;
+	const double bestS = o.minScore; const int bestCol = o.alnEnd, bestRow = o.alnTo;
+	o.traceLen = 0; o.alnStart = o.alnEnd = o.alnFrom = o.alnTo = 0;
+	if(!(bestS < INFINITY)) { o.status = HU_READ_NEEDS_FULL; outs[s] = o; return; }
+	const uint8_t* dcs = dec + rd.decOff;
+	char* tr = traces + rd.traceOff;
+	int n = 0;
+	char st = bestCol <= K ? 'M' : 'I';
+	int i = bestRow, j = bestCol <= K ? bestCol : K;
+	o.alnEnd = j; o.alnTo = bestRow;
+	tr[n++] = 'E';
+	bool redo = forceRedo != 0; /* test hook: exercise the redo pass */
+	while(i >= 1 && j >= 0 && !redo) {
+		tr[n++] = st;
+		if(st != 'M' && st != 'I' && st != 'D') break;
+		int rc = -1;
+		for(int r = R - 1; r >= 0; --r) if(reg_contains(rd.reg[r], i, j)) { rc = r; break; }
+		const int pi = st == 'D' ? i : i - 1, pj = st == 'I' ? j : j - 1;
+		if(rc < 0) { redo = true; break; }
+		for(int r2 = rc + 1; r2 < R; ++r2) if(reg_contains(rd.reg[r2], pi, pj)) redo = true;
+		if(redo) break;
+		const HuRegion& g = rd.reg[rc];
+		const int ni = g.i1 - g.i0 + 1;
+		const int by = dcs[g.doff + (int64_t)((i - g.i0) + (j - g.j0)) * ni + (i - g.i0)];
+		if(st == 'M') { const int d = by & 3; st = d == 0 ? 'B' : d == 1 ? 'M' : d == 2 ? 'I' : 'D'; }
+		else if(st == 'I') st = (by >> 2) & 1 ? 'I' : 'M';
+		else st = (by >> 3) & 1 ? 'D' : 'M';
+		i = pi; j = pj;
+	}
+	if(redo) { o.status = HU_READ_NEEDS_VALUES; o.traceLen = -1; o.minScore = bestS; o.alnEnd = bestCol; o.alnTo = bestRow; outs[s] = o; return; }
+	o.alnStart = j + 1; o.alnFrom = i + 1;
+	if(tr[n - 1] != 'B') tr[n++] = 'B';
+	for(int a = 0, b = n - 1; a < b; ++a, --b) { char t = tr[a]; tr[a] = tr[b]; tr[b] = t; }
+	o.traceLen = n;
+	o.status = (o.alnStart > 0 && o.alnFrom > 0) ? HU_READ_OK : HU_READ_INVALID;
 	outs[s] = o;
 }
 
