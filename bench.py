@@ -71,7 +71,7 @@ def main():
     t0 = time.time()
     db, up, down = synth_gpu.make_db_gpu(args.leaves, args.cs_len, "GTR", dg_k=args.dg_k, seed=97, win=win, device=dev, log=log)
     # reads are drawn from the log-space messages BEFORE the engine adopts (and repacks) them
-    nb = 2
+    nb = int(os.environ.get("HU_BENCH_INFLIGHT", 2))    # batches in flight per GPU (one host thread + one HIP stream each)
     all_reads, all_vps = [], []
     for i in range(nb):
         reads = synth_gpu.simulate_reads_gpu(db, up, down, args.batch, args.read_len, seed=1 + 1000 * rank + i,

@@ -70,7 +70,7 @@ struct HuRegion {
 	int32_t from, start, nIns, nDel;
 	int64_t off;               /* first cell of this region in the read's scratch                 */
 	int64_t doff;              /* first byte of this region in the read's decision scratch: one byte per cell in
-	                            * anti-diagonal order, [dg][q] with pitch (i1 - i0 + 1)                        */
+	                            * anti-diagonal order, [dg][q] with pitch (i1 - i0 + 1) rounded up to 16                        */
 };
 #define HU_MAX_REGIONS 6
 #define HU_READ_NEEDS_VALUES 8   /* internal: the decision-byte traceback met a cell whose predecessor a later phase

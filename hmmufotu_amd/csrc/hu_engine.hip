@@ -530,7 +530,7 @@ static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */
 		g.off = off; g.doff = doff;
 		if(j1 >= j0 && i1 >= i0) {
 			off += (int64_t)(j1 - j0 + 1) * (i1 - i0 + 1);
-			doff += (int64_t)((j1 - j0 + 1) + (i1 - i0 + 1) - 1) * (i1 - i0 + 1);
+			doff += (int64_t)((j1 - j0 + 1) + (i1 - i0 + 1) - 1) * (((i1 - i0 + 1) + 15) & ~15);
 		}
 	};
 	if(nv == 0) add(1, K, 1, L, 1, 0, nullptr); /* full Viterbi (src/BandedHMMP7.cpp:748-771) */
@@ -679,7 +679,21 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			if(vlds <= 96 * 1024 && !getenv("HU_VITERBI_HBM")) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
 				if(!getenv("HU_VITERBI_VALUES")) { /* one decision byte per cell; (M, I, D) only where a later phase looks */
 					if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
-					k_viterbi_dec<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows);
+					#define VD_ARGS d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows
+					int haloW = 2;
+					for(int s = 0; s < b->nSeq; ++s) for(int r = 0; r < b->hDescs[s].nRegions; ++r)
+						haloW = std::max(haloW, b->hDescs[s].reg[r].j1 - b->hDescs[s].reg[r].j0 + 3);
+					const size_t vlds2 = vlds + (size_t) 3 * haloW * sizeof(double) + 32 * (maxLen <= 256 ? 256 : 512);
+					if(maxLen <= 256 && vlds2 <= 96 * 1024 && !getenv("HU_VITERBI_DEC1")) { /* one DP row per thread, nothing global inside the wavefront */
+						if(vlds2 > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds2));
+						k_viterbi_dec2<256><<<b->nSeq, 256, vlds2, b->stream>>>(VD_ARGS, haloW);
+					}
+					else if(maxLen <= 512 && vlds2 <= 96 * 1024 && !getenv("HU_VITERBI_DEC1")) {
+						if(vlds2 > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds2));
+						k_viterbi_dec2<512><<<b->nSeq, 512, vlds2, b->stream>>>(VD_ARGS, haloW);
+					}
+					else k_viterbi_dec<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(VD_ARGS);
+					#undef VD_ARGS
 					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, getenv("HU_VITERBI_FORCE_REDO") != nullptr);
 					usedDec = true;
 				}

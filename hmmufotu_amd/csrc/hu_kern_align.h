@@ -455,7 +455,7 @@ __global__ __launch_bounds__(HU_VIT_THREADS) void k_viterbi_dec(HuDbDev db, cons
 					if(j > 1 && pD < mn) { dM = 3; mn = pD; }
 				}
 				const int dI = uI < uM ? 1 : 0, dDd = lD < lM ? 1 : 0;
-				dcs[g.doff + (int64_t) dg * ni + q] = (uint8_t)(dM | (dI << 2) | (dDd << 3));
+				dcs[g.doff + (int64_t) dg * ((ni + 15) & ~15) + q] = (uint8_t)(dM | (dI << 2) | (dDd << 3));
 				bool later = false, near = false;
 				for(int r2 = r + 1; r2 < nR; ++r2) {
 					const HuRegion& g2 = rd.reg[r2];
@@ -499,6 +499,190 @@ __global__ __launch_bounds__(HU_VIT_THREADS) void k_viterbi_dec(HuDbDev db, cons
 	outs[s] = o;
 }
 
+/* The same with one DP row per thread (reads of at most THREADS bases): the row's base, B-column term and C-loop
+ * term are per-phase constants, the profile column advances by one per step, so the eleven profile values of the
+ * NEXT step's cell are requested while the current cell is computed (no load sits between two barriers), and the
+ * later-phase bookkeeping is skipped for cells outside the bounding corner of all later phases. */
+template<int THREADS>
+__global__ __launch_bounds__(THREADS) void k_viterbi_dec2(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		double* __restrict__ scratch, uint8_t* __restrict__ dec, double tNN, double tNB, double tEC, double tCC,
+		HuVitOut* __restrict__ outs, int ldsRows, int haloW) {
+	extern __shared__ double vsh[];
+	double* halo = vsh + (size_t) 9 * ldsRows;   /* [3][haloW]: (M, I, D) of row i0 - 1, columns j0 - 1 .. j1 */
+	/* decision bytes of the last 32 anti-diagonals, [slot][row]; 16 at a time leave for HBM as 16-byte stores.
+	 * vmcnt retires in issue order, so a store per step would put its round trip to L2 in front of the next
+	 * step's prefetched profile values: one store per 16 steps instead */
+	uint8_t* ring = reinterpret_cast<uint8_t*>(halo + (size_t) 3 * haloW);
+	__shared__ double redS[THREADS / 64];
+	__shared__ int redC[THREADS / 64], redR[THREADS / 64];
+	__shared__ HuRegion sreg[HU_MAX_REGIONS];
+	const int s = blockIdx.x, tid = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const int L = rd.len, K = db.K;
+	const size_t K1 = (size_t) K + 1;
+	const int nR = rd.nRegions;
+	if(nR <= 0) { if(tid == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	if(tid < nR) sreg[tid] = rd.reg[tid];
+	__syncthreads();
+	const char* __restrict__ x = bases + rd.baseOff;
+	double* scr = scratch + rd.scratchOff * 3;
+	uint8_t* dcs = dec + rd.decOff;
+	VitCtx ctx = { &rd, scr, tNN, tNB };
+	/* vit_lookup on the LDS copy of the descriptor */
+	auto look = [&](int upto, int ii, int jj, double& m, double& iv, double& d) {
+		for(int rr = upto - 1; rr >= 0; --rr) {
+			const HuRegion& gg = sreg[rr];
+			if(reg_contains(gg, ii, jj)) {
+				const int64_t idx = (gg.off + (int64_t)(jj - gg.j0) * (gg.i1 - gg.i0 + 1) + (ii - gg.i0)) * 3;
+				m = scr[idx]; iv = scr[idx + 1]; d = scr[idx + 2];
+				return;
+			}
+		}
+		if(jj == 0 && ii >= 1) { const double vv = vit_bcol(ctx, ii); m = vv; iv = vv; d = INFINITY; return; }
+		m = iv = d = INFINITY;
+	};
+	double bestS = INFINITY; int bestCol = 0x7fffffff, bestRow = 0x7fffffff;
+	const double tKIM = db.T[(size_t) K * 8 + 3];
+	for(int r = 0; r < nR; ++r) {
+		const HuRegion g = sreg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		const int P = (ni + 15) & ~15;
+		/* cells with i < nearI or j < nearJ are neither inside nor next to any later phase */
+		int nearI = 0x7fffffff, nearJ = 0x7fffffff;
+		for(int r2 = r + 1; r2 < nR; ++r2) {
+			const int a = sreg[r2].i0 - 1, c = sreg[r2].j0 - 1;
+			if(sreg[r2].i1 >= sreg[r2].i0 && sreg[r2].j1 >= sreg[r2].j0) { nearI = a < nearI ? a : nearI; nearJ = c < nearJ ? c : nearJ; }
+		}
+		const int q = tid, i = g.i0 + q;
+		const bool row = q < ni;
+		const int b = row ? c_sym_map[(int) x[i - 1] & 127] : 0;
+		const double bcol = vit_bcol(ctx, i);
+		const double cc = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+		const double* __restrict__ emb = db.EMt + (size_t) b * K1;
+		const double* __restrict__ eib = db.EIt + (size_t) b * K1;
+		/* profile values of the cell this thread computes next: column jc */
+		double nT0, nT3, nT5, nT2, nT6, nJ1, nJ4, nEM, nEI, nEN, nEX;
+		auto fetch = [&](int jc) {
+			const double* tp = db.Tt + (jc - 1);
+			nT0 = tp[0]; nT3 = tp[3 * K1]; nT5 = tp[5 * K1]; nT2 = tp[2 * K1]; nT6 = tp[6 * K1];
+			nJ1 = tp[1 * K1 + 1]; nJ4 = tp[4 * K1 + 1];
+			nEM = emb[jc]; nEI = eib[jc]; nEN = db.entryC[jc]; nEX = db.exitC[jc];
+		};
+		nT0 = nT3 = nT5 = nT2 = nT6 = nJ1 = nJ4 = nEM = nEI = nEN = nEX = 0;
+		if(row && q == 0) fetch(g.j0);
+		/* every value of an earlier phase that this phase will look at, fetched now and in parallel: the first
+		 * column's neighbours and the band's outer neighbours of this thread's row into registers, row i0 - 1 into
+		 * LDS.  Inside the wavefront no step waits on global memory. */
+		double cDm = INFINITY, cDi = INFINITY, cDd = INFINITY, cLm = INFINITY, cLd = INFINITY;
+		double eUm = INFINITY, eUi = INFINITY, eLm = INFINITY, eLd = INFINITY, tmp;
+		if(row) {
+			look(r, i - 1, g.j0 - 1, cDm, cDi, cDd);
+			look(r, i, g.j0 - 1, cLm, tmp, cLd);
+			if(g.band) {
+				const int jU = (i - g.from) + g.nDel + g.start, jL = (i - g.from) - g.nIns + g.start;
+				if(jU >= g.j0 && jU <= g.j1) look(r, i - 1, jU, eUm, eUi, tmp);
+				if(jL >= g.j0 && jL <= g.j1) look(r, i, jL - 1, eLm, tmp, eLd);
+			}
+		}
+		for(int c = tid; c <= nj; c += THREADS) {
+			double hm, hi2, hd;
+			look(r, g.i0 - 1, g.j0 - 1 + c, hm, hi2, hd);
+			halo[c] = hm; halo[haloW + c] = hi2; halo[2 * haloW + c] = hd;
+		}
+		__syncthreads();
+		for(int dg = 0; dg <= ni + nj - 2; ++dg) {
+			double* cur = vsh + (size_t)(dg % 3) * 3 * ldsRows;
+			const double* p1 = vsh + (size_t)((dg + 2) % 3) * 3 * ldsRows;
+			const double* p2 = vsh + (size_t)((dg + 1) % 3) * 3 * ldsRows;
+			const int j = g.j0 + dg - q;
+			const bool cell = row && j >= g.j0 && j <= g.j1;
+			const double T0 = nT0, T3 = nT3, T5 = nT5, T2 = nT2, T6 = nT6, J1 = nJ1, J4 = nJ4, EMv = nEM, EIv = nEI, ENv = nEN, EXv = nEX;
+			if(row && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1);
+			const int dist = (i - g.from) - (j - g.start);
+			if(cell && !(g.band && !(dist <= g.nIns && dist >= -g.nDel))) {
+				double mD, iD, dD, mU, iU, mL, dL;
+				if(q >= 1 && j - 1 >= g.j0) { mD = p2[q - 1]; iD = p2[ldsRows + q - 1]; dD = p2[2 * ldsRows + q - 1]; }
+				else if(q == 0) { mD = halo[j - g.j0]; iD = halo[haloW + j - g.j0]; dD = halo[2 * haloW + j - g.j0]; }   /* (i0 - 1, j - 1) */
+				else { mD = cDm; iD = cDi; dD = cDd; }                                                            /* (i - 1, j0 - 1) */
+				if(q >= 1 && (!g.band || dist - 1 >= -g.nDel)) { mU = p1[q - 1]; iU = p1[ldsRows + q - 1]; }
+				else if(q == 0) { mU = halo[j - g.j0 + 1]; iU = halo[haloW + j - g.j0 + 1]; }                   /* (i0 - 1, j) */
+				else { mU = eUm; iU = eUi; }                                                                     /* above the band */
+				if(j - 1 >= g.j0 && (!g.band || dist + 1 <= g.nIns)) { mL = p1[q]; dL = p1[2 * ldsRows + q]; }
+				else if(j == g.j0) { mL = cLm; dL = cLd; }                                                       /* (i, j0 - 1) */
+				else { mL = eLm; dL = eLd; }                                                                     /* left of the band */
+				const double pB = bcol + ENv;
+				const double pM = mD + T0, pI = iD + T3, pD = dD + T5;
+				double best = fmin(pM, fmin(pI, pD));
+				if(g.withB) best = fmin(pB, best);
+				const double uM = mU + J1, uI = iU + J4;
+				const double lM = mL + T2, lD = dL + T6;
+				const double M = EMv + best;
+				const double I = EIv + fmin(uM, uI);
+				const double D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
+				cur[q] = M; cur[ldsRows + q] = I; cur[2 * ldsRows + q] = D;
+				int dM = 0;
+				{
+					double mn = INFINITY;
+					if(pB < mn) { dM = 0; mn = pB; }
+					if(j > 1 && pM < mn) { dM = 1; mn = pM; }
+					if(pI < mn) { dM = 2; mn = pI; }
+					if(j > 1 && pD < mn) { dM = 3; mn = pD; }
+				}
+				const int dI = uI < uM ? 1 : 0, dDd = lD < lM ? 1 : 0;
+				ring[(dg & 31) * THREADS + q] = (uint8_t)(dM | (dI << 2) | (dDd << 3));
+				bool later = false;
+				if(i >= nearI && j >= nearJ) {
+					bool near = false;
+					for(int r2 = r + 1; r2 < nR; ++r2) {
+						const HuRegion& g2 = sreg[r2];
+						if(reg_contains(g2, i, j)) later = true;
+						if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
+					}
+					if(near) { /* a later phase may look this cell up */
+						const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + q) * 3;
+						scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+					}
+				}
+				if(!later) {
+					double sv = __dadd_rn(__dadd_rn(M, EXv), tEC);
+					if(i < L) sv = __dadd_rn(sv, cc);
+					if(sv < bestS || (sv == bestS && (j < bestCol || (j == bestCol && i < bestRow)))) { bestS = sv; bestCol = j; bestRow = i; }
+					if(j == K) {
+						double s2 = __dadd_rn(__dadd_rn(I, tKIM), tEC);
+						if(i < L) s2 = __dadd_rn(s2, cc);
+						if(s2 < bestS || (s2 == bestS && (K + 1 < bestCol || (K + 1 == bestCol && i < bestRow)))) { bestS = s2; bestCol = K + 1; bestRow = i; }
+					}
+				}
+			}
+			vit_lds_barrier();
+			if((dg & 15) == 15 || dg == ni + nj - 2) { /* file the diagonals dg0 .. dg: pitch P bytes, P / 16 units of 16 bytes each */
+				const int dg0 = dg & ~15, units = P >> 4, cnt = (dg - dg0 + 1) * units;
+				if(tid < cnt) {
+					const int dd = tid / units, c = tid - dd * units;
+					const uint4 v = *reinterpret_cast<const uint4*>(ring + ((dg0 + dd) & 31) * THREADS + c * 16);
+					*reinterpret_cast<uint4*>(dcs + g.doff + (int64_t)(dg0 + dd) * P + c * 16) = v;
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for(int m = 32; m > 0; m >>= 1) {
+		const double os = __shfl_xor(bestS, m); const int oc = __shfl_xor(bestCol, m), orow = __shfl_xor(bestRow, m);
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	if((tid & 63) == 0) { redS[tid >> 6] = bestS; redC[tid >> 6] = bestCol; redR[tid >> 6] = bestRow; }
+	__syncthreads();
+	if(tid != 0) return;
+	for(int wv = 1; wv < THREADS / 64; ++wv) {
+		const double os = redS[wv]; const int oc = redC[wv], orow = redR[wv];
+		if(os < bestS || (os == bestS && (oc < bestCol || (oc == bestCol && orow < bestRow)))) { bestS = os; bestCol = oc; bestRow = orow; }
+	}
+	HuVitOut o;
+	o.minScore = bestS; o.alnEnd = bestCol; o.alnTo = bestRow; o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
+	outs[s] = o;
+}
+
 /* traceback on the decision bytes, one lane per sequence */
 __global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuReadDesc* __restrict__ descs, const uint8_t* __restrict__ dec,
 		char* __restrict__ traces, HuVitOut* __restrict__ outs, int nSeq, int forceRedo) {
@@ -530,7 +714,7 @@ __global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuRe
 		if(redo) break;
 		const HuRegion& g = rd.reg[rc];
 		const int ni = g.i1 - g.i0 + 1;
-		const int by = dcs[g.doff + (int64_t)((i - g.i0) + (j - g.j0)) * ni + (i - g.i0)];
+		const int by = dcs[g.doff + (int64_t)((i - g.i0) + (j - g.j0)) * ((ni + 15) & ~15) + (i - g.i0)];
 		if(st == 'M') { const int d = by & 3; st = d == 0 ? 'B' : d == 1 ? 'M' : d == 2 ? 'I' : 'D'; }
 		else if(st == 'I') st = (by >> 2) & 1 ? 'I' : 'M';
 		else st = (by >> 3) & 1 ? 'D' : 'M';
