@@ -178,7 +178,9 @@ def main():
     # algorithmic bytes per launch (SURVEY.md §8d per-unit figures x units of one launch)
     alg = dict(viterbi=nread * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum, seed_topk=4.0 * D.n_nodes * nread,
                estimate=S * 65.0 * Rsum, place=C * 64.0 * Rsum)
-    pmc_name = dict(viterbi="k_viterbi_lds", seed_pdist="k_seed_pdist<16>", seed_topk="k_seed_topk", estimate="k_estimate_blk<6, 256>", place="k_place")
+    # kernel of each stage as rocprofv3 names it (prefix match: template arguments vary with the read length)
+    pmc_prefix = dict(viterbi=("k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_pdist",), seed_topk=("k_seed_topk",),
+                      estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place"))
     pmc = {}
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile):
@@ -186,11 +188,20 @@ def main():
             pmc = json.load(open(tfile))["kernels"]
         except Exception:
             pmc = {}
+
+    def pmc_entry(stage):
+        for pre in pmc_prefix[stage]:
+            for name in sorted(pmc):
+                if name.startswith(pre) and not name.startswith(pre + "_"):
+                    return name, pmc[name]
+        return pmc_prefix[stage][0], {}
+
     kern = []
     for k in ("viterbi", "seed_pdist", "seed_topk", "estimate", "place"):
         ms = acc[k]
-        tr = pmc.get(pmc_name[k], {}).get("hbm_bytes_per_launch") if args.batch == 8192 and args.leaves == 99322 else None
-        kern.append(dict(kernel=pmc_name[k], ms=round(ms, 3), algorithmic_bytes=alg[k], achieved=alg[k] / (ms * 1e-3) / 1e9, unit="GB/s",
+        name, ent = pmc_entry(k)
+        tr = ent.get("hbm_bytes_per_launch") if args.batch == 8192 and args.leaves == 99322 else None
+        kern.append(dict(kernel=name, ms=round(ms, 3), algorithmic_bytes=alg[k], achieved=alg[k] / (ms * 1e-3) / 1e9, unit="GB/s",
                          frac=alg[k] / (ms * 1e-3) / 1e9 / peak, traffic=tr, traffic_gbps=(tr / (ms * 1e-3) / 1e9 if tr else None)))
     dom = max(kern, key=lambda x: x["ms"])
     roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], traffic=dom["traffic"])

@@ -793,7 +793,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);
+			const char* fm = getenv("HU_TOPK_FAST_MIN");   /* trees smaller than this take the exact two-pass histogram (test hook) */
+			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, fm ? atoi(fm) : 16384);
 		}
 		HIPCHK(hipGetLastError());
 	}

@@ -111,6 +111,25 @@ def test_hbm_staged_viterbi_kernel(monkeypatch):
     test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
 
 
+def test_value_filing_viterbi_kernels(monkeypatch):
+    """the LDS wavefront that files (M, I, D) of every cell (the redo pass of the decision-byte kernel): same results"""
+    monkeypatch.setenv("HU_VITERBI_VALUES", "1")
+    test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
+
+
+def test_viterbi_redo_pass(monkeypatch):
+    """every traceback flagged 'cannot trust the fill-time decisions': all sequences are redone by the value-filing
+    kernels and must come out identical"""
+    monkeypatch.setenv("HU_VITERBI_FORCE_REDO", "1")
+    test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
+
+
+def test_generic_decision_byte_viterbi(monkeypatch):
+    """the decision-byte kernel for reads longer than one row per thread"""
+    monkeypatch.setenv("HU_VITERBI_DEC1", "1")
+    test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
+
+
 def test_align_modes_and_bad_reads():
     E = _engine()
     db = get_db(120, 700, "GTR", dg_k=4)
@@ -465,6 +484,26 @@ def test_edge_cases_small_tree_short_reads_and_window():
     with pytest.raises(E.EngineError, match="outside the resident message window"):
         B.assign(opts)
     B.close(); Dfull.close(); Dwin.close(); Dtiny.close()
+
+
+def test_topk_sampled_threshold_path(monkeypatch):
+    """k_seed_topk's fast path (threshold bin estimated from one eighth of the pairs) on trees far below its
+    default size limit: seed ids, order and (d, N) stay bit-exact, whether the estimate suffices or the exact
+    two-pass path has to take over"""
+    monkeypatch.setenv("HU_TOPK_FAST_MIN", "1")
+    test_sep_parity(dict(model="GTR", dg_k=4, n_leaves=1500, cs_len=700, read_len=150))
+    test_sep_parity(dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100))
+    test_topk_degenerate_tie_mass()
+
+
+def test_streaming_sep_kernels(monkeypatch):
+    """the one-wave-per-unit streaming estimate / place kernels (regions beyond 3,072 columns) and the per-site
+    log() estimate kernel give the same placements as the table-driven workgroup kernels"""
+    monkeypatch.setenv("HU_STREAMING_SEP", "1")
+    test_sep_parity(dict(model="GTR", dg_k=4, n_leaves=150, cs_len=700, read_len=150))
+    monkeypatch.delenv("HU_STREAMING_SEP")
+    monkeypatch.setenv("HU_EST_VAR", "2")
+    test_sep_parity(dict(model="HKY85", dg_k=4, n_leaves=100, cs_len=700, read_len=100))
 
 
 def test_topk_degenerate_tie_mass():
