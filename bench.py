@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=int(os.environ.get("HU_BENCH_LEAVES", 99322)))
     ap.add_argument("--cs-len", type=int, default=7682)
     ap.add_argument("--read-len", type=int, default=250)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("HU_BENCH_BATCH", 8192)))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("HU_BENCH_BATCH", 16384)))
     ap.add_argument("--dg-k", type=int, default=4)
     ap.add_argument("--win", type=int, default=int(os.environ.get("HU_BENCH_WIN", 0)), help="message window columns (0 = all)")
     ap.add_argument("--cpu-sample", type=int, default=-1)

@@ -530,7 +530,14 @@ static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */
 		g.off = off; g.doff = doff;
 		if(j1 >= j0 && i1 >= i0) {
 			off += (int64_t)(j1 - j0 + 1) * (i1 - i0 + 1);
-			doff += (int64_t)((j1 - j0 + 1) + (i1 - i0 + 1) - 1) * (((i1 - i0 + 1) + 15) & ~15);
+			/* room for the layout of whichever decision-byte kernel runs: anti-diagonals with a pitch of ni rounded
+			 * up to 16 (k_viterbi_dec, _dec2), steps of 64 lanes x 4 or 8 rows or x 1 row (k_viterbi_wave) */
+			const int64_t ni = i1 - i0 + 1, nj = j1 - j0 + 1;
+			int64_t sz = (ni + nj - 1) * ((ni + 15) & ~15);
+			sz = std::max(sz, (ni + nj - 1) * 64);
+			sz = std::max(sz, (nj + (ni + 3) / 4 - 1) * 256);
+			sz = std::max(sz, (nj + (ni + 7) / 8 - 1) * 512);
+			doff += (sz + 15) & ~(int64_t) 15;
 		}
 	};
 	if(nv == 0) add(1, K, 1, L, 1, 0, nullptr); /* full Viterbi (src/BandedHMMP7.cpp:748-771) */
@@ -673,6 +680,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 		for(int s = 0; s < b->nSeq; ++s) maxLen = std::max(maxLen, (int) b->hDescs[s].len);
 		const int ldsRows = maxLen + 1;
 		bool usedDec = false;
+		int decRpl = 0;
 		const size_t vlds = (size_t) 9 * ldsRows * sizeof(double);
 		{
 			Timer t(b, HU_T_VITERBI);
@@ -684,17 +692,25 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 					for(int s = 0; s < b->nSeq; ++s) for(int r = 0; r < b->hDescs[s].nRegions; ++r)
 						haloW = std::max(haloW, b->hDescs[s].reg[r].j1 - b->hDescs[s].reg[r].j0 + 3);
 					const size_t vlds2 = vlds + (size_t) 3 * haloW * sizeof(double) + 32 * (maxLen <= 256 ? 256 : 512);
-					if(maxLen <= 256 && vlds2 <= 96 * 1024 && !getenv("HU_VITERBI_DEC1")) { /* one DP row per thread, nothing global inside the wavefront */
+					const char* vm = getenv("HU_VITERBI_MODE");     /* test hook: 1 = generic workgroup kernel, 2 = row-per-thread workgroup kernel */
+					const int mode = vm ? atoi(vm) : (getenv("HU_VITERBI_DEC1") ? 1 : 0);
+					const int haloWw = std::min(haloW, 512);
+					if(mode == 0 && maxLen <= 512) { /* one wave per sequence, no barrier */
+						const size_t wl = (size_t) 3 * haloWw * sizeof(double);
+						if(maxLen <= 256) { k_viterbi_wave<4><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						else { k_viterbi_wave<8><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 8; }
+					}
+					else if(mode != 1 && maxLen <= 256 && vlds2 <= 96 * 1024) { /* one DP row per thread, nothing global inside the wavefront */
 						if(vlds2 > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds2));
 						k_viterbi_dec2<256><<<b->nSeq, 256, vlds2, b->stream>>>(VD_ARGS, haloW);
 					}
-					else if(maxLen <= 512 && vlds2 <= 96 * 1024 && !getenv("HU_VITERBI_DEC1")) {
+					else if(mode != 1 && maxLen <= 512 && vlds2 <= 96 * 1024) {
 						if(vlds2 > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds2));
 						k_viterbi_dec2<512><<<b->nSeq, 512, vlds2, b->stream>>>(VD_ARGS, haloW);
 					}
 					else k_viterbi_dec<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(VD_ARGS);
 					#undef VD_ARGS
-					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, getenv("HU_VITERBI_FORCE_REDO") != nullptr);
+					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, getenv("HU_VITERBI_FORCE_REDO") != nullptr, decRpl);
 					usedDec = true;
 				}
 				else {

@@ -683,9 +683,287 @@ __global__ __launch_bounds__(THREADS) void k_viterbi_dec2(HuDbDev db, const HuRe
 	outs[s] = o;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * k_viterbi_wave: the decision-byte DP with ONE WAVE per sequence and no barrier.
+ *
+ * Rectangular phases: lane l owns the RPL consecutive rows i0 + l RPL .. of the phase and walks the columns;
+ * at step t it is at column j0 + t - l, so the lanes form a wavefront over blocks of RPL x 1 cells.  Inside a
+ * lane the column's cells are computed top to bottom from registers: the left neighbour of a cell is the
+ * lane's own value of the previous step, its upper neighbour the cell just computed, its diagonal neighbour the
+ * previous-step value of the row above.  Only row 0 of a lane looks outside: its upper and diagonal
+ * neighbours are the last row of lane l - 1 one resp. two steps ago — ONE triple of doubles moved down a
+ * lane per step over DPP (wave_shr:1), used as "up" now and as "diagonal" at the next step.  Lane 0 takes
+ * that triple from the row above the phase (values of earlier phases, put into LDS when the phase starts),
+ * and every row starts from the column left of the phase.
+ * Band phases (a seed: <= 64 rows) run one row per lane on anti-diagonals with the same triple; the cells
+ * just outside the band (one above and one left of the band per row) are looked up when the phase starts.
+ * Per step a lane asks for the profile values of its NEXT column (9 + 2 RPL doubles from the per-field
+ * arrays: consecutive lanes, consecutive columns) and files RPL decision bytes as one 32/64-bit store.
+ * k_viterbi_dec2 (a workgroup per sequence, a barrier per anti-diagonal) spent ~300 wave-instructions per
+ * anti-diagonal and wave; this kernel spends ~60 per cell and has nothing to wait for but its own loads. */
+template<int RPL> struct HuDecWord { typedef uint32_t type; };
+template<> struct HuDecWord<8> { typedef unsigned long long type; };
+
+__device__ inline double dpp_wave_shr1(double v, double lane0) { /* value of lane l - 1; lane 0 gets `lane0` */
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+struct VwBest { double s; int col, row; };
+__device__ inline void vw_cand(VwBest& b, double sv, int j, int i) {
+	if(sv < b.s || (sv == b.s && (j < b.col || (j == b.col && i < b.row)))) { b.s = sv; b.col = j; b.row = i; }
+}
+
+template<int RPL>
+__global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
+		double* __restrict__ scratch, uint8_t* __restrict__ dec, double tNN, double tNB, double tEC, double tCC,
+		HuVitOut* __restrict__ outs, int haloW) {
+	extern __shared__ double halo[];                 /* [3][haloW]: (M, I, D) of row i0 - 1, columns j0 - 1 .. j1 */
+	__shared__ HuRegion sreg[HU_MAX_REGIONS];
+	typedef typename HuDecWord<RPL>::type dword_t;
+	const int s = blockIdx.x, lane = threadIdx.x;
+	const HuReadDesc& rd = descs[s];
+	const int L = rd.len, K = db.K;
+	const size_t K1 = (size_t) K + 1;
+	const int nR = rd.nRegions;
+	if(nR <= 0) { if(lane == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
+	if(lane < nR) sreg[lane] = rd.reg[lane];
+	__syncthreads();
+	const char* __restrict__ x = bases + rd.baseOff;
+	double* scr = scratch + rd.scratchOff * 3;
+	uint8_t* dcs = dec + rd.decOff;
+	VitCtx ctx = { &rd, scr, tNN, tNB };
+	auto look = [&](int upto, int ii, int jj, double& m, double& iv, double& d) {
+		for(int rr = upto - 1; rr >= 0; --rr) {
+			const HuRegion& gg = sreg[rr];
+			if(reg_contains(gg, ii, jj)) {
+				const int64_t idx = (gg.off + (int64_t)(jj - gg.j0) * (gg.i1 - gg.i0 + 1) + (ii - gg.i0)) * 3;
+				m = scr[idx]; iv = scr[idx + 1]; d = scr[idx + 2];
+				return;
+			}
+		}
+		if(jj == 0 && ii >= 1) { const double vv = vit_bcol(ctx, ii); m = vv; iv = vv; d = INFINITY; return; }
+		m = iv = d = INFINITY;
+	};
+	VwBest best = { INFINITY, 0x7fffffff, 0x7fffffff };
+	const double tKIM = db.T[(size_t) K * 8 + 3];
+	for(int r = 0; r < nR; ++r) {
+		const HuRegion g = sreg[r];
+		const int ni = g.i1 - g.i0 + 1, nj = g.j1 - g.j0 + 1;
+		if(ni <= 0 || nj <= 0) continue;
+		int nearI = 0x7fffffff, nearJ = 0x7fffffff;
+		for(int r2 = r + 1; r2 < nR; ++r2) {
+			const int a = sreg[r2].i0 - 1, c = sreg[r2].j0 - 1;
+			if(sreg[r2].i1 >= sreg[r2].i0 && sreg[r2].j1 >= sreg[r2].j0) { nearI = a < nearI ? a : nearI; nearJ = c < nearJ ? c : nearJ; }
+		}
+		/* row i0 - 1 of the earlier phases: column j0 - 1 + c at halo[c] */
+		const bool useHalo = nj + 2 <= haloW;
+		if(useHalo) for(int c = lane; c <= nj; c += 64) {
+			double hm, hi2, hd;
+			look(r, g.i0 - 1, g.j0 - 1 + c, hm, hi2, hd);
+			halo[c] = hm; halo[haloW + c] = hi2; halo[2 * haloW + c] = hd;
+		}
+		__syncthreads();
+		/* what a cell files and offers: decision byte, values for later phases, S candidates */
+		auto finish = [&](int i, int j, double M, double I, double D, double pB, double pM, double pI, double pD,
+				double uM, double uI, double lM, double lD, double EXv, double ccv) -> int {
+			int dM = 0;
+			{
+				double mn = INFINITY;
+				if(pB < mn) { dM = 0; mn = pB; }
+				if(j > 1 && pM < mn) { dM = 1; mn = pM; }
+				if(pI < mn) { dM = 2; mn = pI; }
+				if(j > 1 && pD < mn) { dM = 3; mn = pD; }
+			}
+			const int by = dM | ((uI < uM ? 1 : 0) << 2) | ((lD < lM ? 1 : 0) << 3);
+			bool later = false;
+			if(i >= nearI && j >= nearJ) {
+				bool near = false;
+				for(int r2 = r + 1; r2 < nR; ++r2) {
+					const HuRegion& g2 = sreg[r2];
+					if(reg_contains(g2, i, j)) later = true;
+					if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
+				}
+				if(near) {
+					const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + (i - g.i0)) * 3;
+					scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+				}
+			}
+			if(!later) {
+				double sv = __dadd_rn(__dadd_rn(M, EXv), tEC);
+				if(i < L) sv = __dadd_rn(sv, ccv);
+				vw_cand(best, sv, j, i);
+				if(j == K) {
+					double s2 = __dadd_rn(__dadd_rn(I, tKIM), tEC);
+					if(i < L) s2 = __dadd_rn(s2, ccv);
+					vw_cand(best, s2, K + 1, i);
+				}
+			}
+			return by;
+		};
+		if(g.band && ni <= 64) {
+			/* ---- band phase: one row per lane, anti-diagonal t: column j0 + t - lane */
+			const int i = g.i0 + lane;
+			const bool row = lane < ni;
+			const int b = row ? c_sym_map[(int) x[i - 1] & 127] : 0;
+			const double bcol = vit_bcol(ctx, i);
+			const double ccv = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+			const double* __restrict__ emb = db.EMt + (size_t) b * K1;
+			const double* __restrict__ eib = db.EIt + (size_t) b * K1;
+			double pm = INFINITY, pi = INFINITY, pd = INFINITY;            /* (i, column - 1): starts as (i, j0 - 1) */
+			double eUm = INFINITY, eUi = INFINITY, eLm = INFINITY, eLd = INFINITY, tmp;
+			const int jU = (i - g.from) + g.nDel + g.start, jL = (i - g.from) - g.nIns + g.start;
+			if(row) {
+				look(r, i, g.j0 - 1, pm, pi, pd);
+				if(jU >= g.j0 && jU <= g.j1) look(r, i - 1, jU, eUm, eUi, tmp);
+				if(jL >= g.j0 && jL <= g.j1) look(r, i, jL - 1, eLm, tmp, eLd);
+			}
+			double fm, fi, fd;                                             /* (i - 1, column) of this step's column */
+			double gm, gi, gd;                                             /* the same one step ago = (i - 1, column - 1) */
+			look(r, i - 1, g.j0 - 1, gm, gi, gd);
+			for(int t = 0; t <= ni + nj - 2; ++t) {
+				const int j = g.j0 + t - lane;
+				const bool cell = row && j >= g.j0 && j <= g.j1;
+				const int dist = (i - g.from) - (j - g.start);
+				const bool in = cell && dist <= g.nIns && dist >= -g.nDel;
+				/* the triple of the lane above: its (M, I, D) at its previous column = this lane's column */
+				double hm = INFINITY, hi2 = INFINITY, hd = INFINITY;
+				if(lane == 0 && j >= g.j0 - 1 && j <= g.j1) {
+					if(useHalo) { hm = halo[j - g.j0 + 1]; hi2 = halo[haloW + j - g.j0 + 1]; hd = halo[2 * haloW + j - g.j0 + 1]; }
+					else look(r, g.i0 - 1, j, hm, hi2, hd);
+				}
+				fm = dpp_wave_shr1(pm, hm); fi = dpp_wave_shr1(pi, hi2); fd = dpp_wave_shr1(pd, hd);
+				double M = INFINITY, I = INFINITY, D = INFINITY;
+				if(in) {
+					const double* tp = db.Tt + (j - 1);
+					const double T0 = tp[0], T3 = tp[3 * K1], T5 = tp[5 * K1], T2 = tp[2 * K1], T6 = tp[6 * K1];
+					const double J1 = tp[1 * K1 + 1], J4 = tp[4 * K1 + 1];
+					const double ENv = db.entryC[j], EXv = db.exitC[j];
+					/* up: above the band -> looked up at the start; left: left of the band likewise */
+					const double mU = dist - 1 >= -g.nDel || lane == 0 ? fm : eUm, iU = dist - 1 >= -g.nDel || lane == 0 ? fi : eUi;
+					const double mL = dist + 1 <= g.nIns || j == g.j0 ? pm : eLm, dL = dist + 1 <= g.nIns || j == g.j0 ? pd : eLd;
+					const double pB = bcol + ENv;
+					const double pM = gm + T0, pI = gi + T3, pD = gd + T5;
+					double bst = fmin(pM, fmin(pI, pD));
+					if(g.withB) bst = fmin(pB, bst);
+					const double uM = mU + J1, uI = iU + J4;
+					const double lM = mL + T2, lD = dL + T6;
+					M = emb[j] + bst;
+					I = eib[j] + fmin(uM, uI);
+					D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
+					const int by = finish(i, j, M, I, D, pB, pM, pI, pD, uM, uI, lM, lD, EXv, ccv);
+					dcs[g.doff + (int64_t) t * 64 + lane] = (uint8_t) by;
+				}
+				/* the lane's (i, column) becomes (i, column - 1); a cell outside the band leaves what a look-up of it
+				 * would have given (it is only ever read through eU / eL, never through these registers) */
+				gm = fm; gi = fi; gd = fd;
+				if(cell) { pm = M; pi = I; pd = D; }
+			}
+		}
+		else {
+			/* ---- rectangular phase (or a band wider than a wave: masked): RPL rows per lane, step t: column j0 + t - lane */
+			const int nL = (ni + RPL - 1) / RPL;
+			const int ib = g.i0 + lane * RPL;
+			int bk[RPL]; double bcol[RPL], ccv[RPL];
+			double pm[RPL], pi[RPL], pd[RPL];                              /* (i_k, column - 1) */
+#pragma unroll
+			for(int k = 0; k < RPL; ++k) {
+				const int i = ib + k;
+				const bool row = lane * RPL + k < ni;
+				bk[k] = row ? c_sym_map[(int) x[i - 1] & 127] : 0;
+				bcol[k] = vit_bcol(ctx, i);
+				ccv[k] = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
+				pm[k] = pi[k] = pd[k] = INFINITY;
+				if(row) look(r, i, g.j0 - 1, pm[k], pi[k], pd[k]);
+			}
+			double gm, gi, gd;                                             /* (ib - 1, column - 1) */
+			look(r, ib - 1, g.j0 - 1, gm, gi, gd);
+			/* profile values of the column this lane computes next */
+			double nT0 = 0, nT3 = 0, nT5 = 0, nT2 = 0, nT6 = 0, nJ1 = 0, nJ4 = 0, nEN = 0, nEX = 0, nEM[RPL], nEI[RPL];
+#pragma unroll
+			for(int k = 0; k < RPL; ++k) nEM[k] = nEI[k] = 0;
+			auto fetch = [&](int jc) {
+				const double* tp = db.Tt + (jc - 1);
+				nT0 = tp[0]; nT3 = tp[3 * K1]; nT5 = tp[5 * K1]; nT2 = tp[2 * K1]; nT6 = tp[6 * K1];
+				nJ1 = tp[1 * K1 + 1]; nJ4 = tp[4 * K1 + 1];
+				nEN = db.entryC[jc]; nEX = db.exitC[jc];
+#pragma unroll
+				for(int k = 0; k < RPL; ++k) { nEM[k] = db.EMt[(size_t) bk[k] * K1 + jc]; nEI[k] = db.EIt[(size_t) bk[k] * K1 + jc]; }
+			};
+			if(lane == 0) fetch(g.j0);
+			for(int t = 0; t <= nj + nL - 2; ++t) {
+				const int j = g.j0 + t - lane;
+				const bool col = lane < nL && j >= g.j0 && j <= g.j1;
+				const double T0 = nT0, T3 = nT3, T5 = nT5, T2 = nT2, T6 = nT6, J1 = nJ1, J4 = nJ4, ENv = nEN, EXv = nEX;
+				double EMv[RPL], EIv[RPL];
+#pragma unroll
+				for(int k = 0; k < RPL; ++k) { EMv[k] = nEM[k]; EIv[k] = nEI[k]; }
+				if(lane < nL && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1);
+				double hm = INFINITY, hi2 = INFINITY, hd = INFINITY;
+				if(lane == 0 && j >= g.j0 - 1 && j <= g.j1) {
+					if(useHalo) { hm = halo[j - g.j0 + 1]; hi2 = halo[haloW + j - g.j0 + 1]; hd = halo[2 * haloW + j - g.j0 + 1]; }
+					else look(r, g.i0 - 1, j, hm, hi2, hd);
+				}
+				/* (ib - 1, j): last row of the lane above at ITS previous column */
+				const double fm = dpp_wave_shr1(pm[RPL - 1], hm), fi = dpp_wave_shr1(pi[RPL - 1], hi2), fd = dpp_wave_shr1(pd[RPL - 1], hd);
+				if(col) {
+					dword_t word = 0;
+					double dm = gm, di = gi, dd = gd;          /* diagonal neighbour of row k: (i_k - 1, j - 1) */
+					double um = fm, ui = fi;                    /* upper neighbour of row k: (i_k - 1, j) */
+#pragma unroll
+					for(int k = 0; k < RPL; ++k) {
+						const int i = ib + k;
+						const double om = pm[k], oi = pi[k], od = pd[k];   /* (i_k, j - 1): left neighbour, and the next row's diagonal */
+						bool in = lane * RPL + k < ni;
+						double mU = um, iU = ui, mL = om, dL = od, dM_ = dm, dI_ = di, dD_ = dd;
+						if(g.band) { /* a band wider than a wave: cells outside are skipped, their neighbours looked up */
+							const int dist = (i - g.from) - (j - g.start);
+							in = in && dist <= g.nIns && dist >= -g.nDel;
+							if(in) {
+								double tmp;
+								if(dist - 1 < -g.nDel && !(lane == 0 && k == 0)) look(r, i - 1, j, mU, iU, tmp);
+								if(dist + 1 > g.nIns && j != g.j0) look(r, i, j - 1, mL, tmp, dL);
+							}
+						}
+						double M = INFINITY, I = INFINITY, D = INFINITY;
+						if(in) {
+							const double pB = bcol[k] + ENv;
+							const double pM = dM_ + T0, pI = dI_ + T3, pD = dD_ + T5;
+							double bst = fmin(pM, fmin(pI, pD));
+							if(g.withB) bst = fmin(pB, bst);
+							const double uM = mU + J1, uI = iU + J4;
+							const double lM = mL + T2, lD = dL + T6;
+							M = EMv[k] + bst;
+							I = EIv[k] + fmin(uM, uI);
+							D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
+							const int by = finish(i, j, M, I, D, pB, pM, pI, pD, uM, uI, lM, lD, EXv, ccv[k]);
+							word |= (dword_t) by << (8 * k);
+						}
+						if(lane * RPL + k < ni) { pm[k] = M; pi[k] = I; pd[k] = D; }
+						dm = om; di = oi; dd = od;
+						um = M; ui = I;
+					}
+					*reinterpret_cast<dword_t*>(dcs + g.doff + ((int64_t) t * 64 + lane) * RPL) = word;
+				}
+				gm = fm; gi = fi; gd = fd;
+			}
+		}
+		__syncthreads();   /* values filed for later phases are looked up by other lanes */
+	}
+	for(int m = 32; m > 0; m >>= 1) {
+		const double os = __shfl_xor(best.s, m); const int oc = __shfl_xor(best.col, m), orow = __shfl_xor(best.row, m);
+		if(os < best.s || (os == best.s && (oc < best.col || (oc == best.col && orow < best.row)))) { best.s = os; best.col = oc; best.row = orow; }
+	}
+	if(lane != 0) return;
+	HuVitOut o;
+	o.minScore = best.s; o.alnEnd = best.col; o.alnTo = best.row; o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
+	outs[s] = o;
+}
+
 /* traceback on the decision bytes, one lane per sequence */
 __global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuReadDesc* __restrict__ descs, const uint8_t* __restrict__ dec,
-		char* __restrict__ traces, HuVitOut* __restrict__ outs, int nSeq, int forceRedo) {
+		char* __restrict__ traces, HuVitOut* __restrict__ outs, int nSeq, int forceRedo, int rpl) {
 	const int s = blockIdx.x * 64 + threadIdx.x;
 	if(s >= nSeq) return;
 	HuVitOut o = outs[s];
@@ -714,7 +992,11 @@ __global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuRe
 		if(redo) break;
 		const HuRegion& g = rd.reg[rc];
 		const int ni = g.i1 - g.i0 + 1;
-		const int by = dcs[g.doff + (int64_t)((i - g.i0) + (j - g.j0)) * ((ni + 15) & ~15) + (i - g.i0)];
+		int64_t at;                                   /* the layout of the fill kernel that ran: rpl = 0 anti-diagonals of a workgroup, */
+		if(rpl == 0) at = (int64_t)((i - g.i0) + (j - g.j0)) * ((ni + 15) & ~15) + (i - g.i0);      /* else steps of k_viterbi_wave<rpl> */
+		else if(g.band && ni <= 64) at = (int64_t)((i - g.i0) + (j - g.j0)) * 64 + (i - g.i0);
+		else { const int ln = (i - g.i0) / rpl, k = (i - g.i0) % rpl; at = ((int64_t)((j - g.j0) + ln) * 64 + ln) * rpl + k; }
+		const int by = dcs[g.doff + at];
 		if(st == 'M') { const int d = by & 3; st = d == 0 ? 'B' : d == 1 ? 'M' : d == 2 ? 'I' : 'D'; }
 		else if(st == 'I') st = (by >> 2) & 1 ? 'I' : 'M';
 		else st = (by >> 3) & 1 ? 'D' : 'M';
