@@ -730,6 +730,10 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 	if(nR <= 0) { if(lane == 0) { HuVitOut o = {0, 0, 0, 0, 0, HU_READ_INVALID, INFINITY}; outs[s] = o; } return; }
 	if(lane < nR) sreg[lane] = rd.reg[lane];
 	__syncthreads();
+	for(int r = 0; r < nR; ++r) if(sreg[r].band && sreg[r].i1 - sreg[r].i0 + 1 > 64) { /* a band wider than a wave: the value-filing kernels take the sequence */
+		if(lane == 0) { HuVitOut o = {0, 0, 0, 0, -1, HU_READ_NEEDS_VALUES, INFINITY}; outs[s] = o; }
+		return;
+	}
 	const char* __restrict__ x = bases + rd.baseOff;
 	double* scr = scratch + rd.scratchOff * 3;
 	uint8_t* dcs = dec + rd.decOff;
@@ -765,9 +769,11 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 			halo[c] = hm; halo[haloW + c] = hi2; halo[2 * haloW + c] = hd;
 		}
 		__syncthreads();
-		/* what a cell files and offers: decision byte, values for later phases, S candidates */
-		auto finish = [&](int i, int j, double M, double I, double D, double pB, double pM, double pI, double pD,
-				double uM, double uI, double lM, double lD, double EXv, double ccv) -> int {
+		/* what a cell files and offers: decision byte and S candidates.  Cells in the bounding corner of the later
+		 * phases (i >= nearI and j >= nearJ: a handful per phase) are left to corner(): they may belong to a later
+		 * phase (no S candidate) or be looked up by one (values filed). */
+		auto finish = [&](int i, int j, double M, double I, double pB, double pM, double pI, double pD,
+				double uM, double uI, double lM, double lD, double EXv) -> int {
 			int dM = 0;
 			{
 				double mn = INFINITY;
@@ -776,21 +782,8 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				if(pI < mn) { dM = 2; mn = pI; }
 				if(j > 1 && pD < mn) { dM = 3; mn = pD; }
 			}
-			const int by = dM | ((uI < uM ? 1 : 0) << 2) | ((lD < lM ? 1 : 0) << 3);
-			bool later = false;
-			if(i >= nearI && j >= nearJ) {
-				bool near = false;
-				for(int r2 = r + 1; r2 < nR; ++r2) {
-					const HuRegion& g2 = sreg[r2];
-					if(reg_contains(g2, i, j)) later = true;
-					if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
-				}
-				if(near) {
-					const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + (i - g.i0)) * 3;
-					scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
-				}
-			}
-			if(!later) {
+			if(!(i >= nearI && j >= nearJ)) {
+				const double ccv = __dmul_rn(tCC, (double)(L - i));
 				double sv = __dadd_rn(__dadd_rn(M, EXv), tEC);
 				if(i < L) sv = __dadd_rn(sv, ccv);
 				vw_cand(best, sv, j, i);
@@ -800,7 +793,30 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 					vw_cand(best, s2, K + 1, i);
 				}
 			}
-			return by;
+			return dM | ((uI < uM ? 1 : 0) << 2) | ((lD < lM ? 1 : 0) << 3);
+		};
+		auto corner = [&](int i, int j, double M, double I, double D) {
+			bool later = false, near = false;
+			for(int r2 = r + 1; r2 < nR; ++r2) {
+				const HuRegion& g2 = sreg[r2];
+				if(reg_contains(g2, i, j)) later = true;
+				if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
+			}
+			if(near) {
+				const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + (i - g.i0)) * 3;
+				scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+			}
+			if(!later) {
+				const double ccv = __dmul_rn(tCC, (double)(L - i));
+				double sv = __dadd_rn(__dadd_rn(M, db.exitC[j]), tEC);
+				if(i < L) sv = __dadd_rn(sv, ccv);
+				vw_cand(best, sv, j, i);
+				if(j == K) {
+					double s2 = __dadd_rn(__dadd_rn(I, tKIM), tEC);
+					if(i < L) s2 = __dadd_rn(s2, ccv);
+					vw_cand(best, s2, K + 1, i);
+				}
+			}
 		};
 		if(g.band && ni <= 64) {
 			/* ---- band phase: one row per lane, anti-diagonal t: column j0 + t - lane */
@@ -808,7 +824,6 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 			const bool row = lane < ni;
 			const int b = row ? c_sym_map[(int) x[i - 1] & 127] : 0;
 			const double bcol = vit_bcol(ctx, i);
-			const double ccv = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
 			const double* __restrict__ emb = db.EMt + (size_t) b * K1;
 			const double* __restrict__ eib = db.EIt + (size_t) b * K1;
 			double pm = INFINITY, pi = INFINITY, pd = INFINITY;            /* (i, column - 1): starts as (i, j0 - 1) */
@@ -852,8 +867,9 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 					M = emb[j] + bst;
 					I = eib[j] + fmin(uM, uI);
 					D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
-					const int by = finish(i, j, M, I, D, pB, pM, pI, pD, uM, uI, lM, lD, EXv, ccv);
+					const int by = finish(i, j, M, I, pB, pM, pI, pD, uM, uI, lM, lD, EXv);
 					dcs[g.doff + (int64_t) t * 64 + lane] = (uint8_t) by;
+					if(i >= nearI && j >= nearJ) corner(i, j, M, I, D);
 				}
 				/* the lane's (i, column) becomes (i, column - 1); a cell outside the band leaves what a look-up of it
 				 * would have given (it is only ever read through eU / eL, never through these registers) */
@@ -862,18 +878,16 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 			}
 		}
 		else {
-			/* ---- rectangular phase (or a band wider than a wave: masked): RPL rows per lane, step t: column j0 + t - lane */
+			/* ---- rectangular phase: RPL rows per lane, step t: column j0 + t - lane */
 			const int nL = (ni + RPL - 1) / RPL;
 			const int ib = g.i0 + lane * RPL;
-			int bk[RPL]; double bcol[RPL], ccv[RPL];
+			int bk[RPL];
 			double pm[RPL], pi[RPL], pd[RPL];                              /* (i_k, column - 1) */
 #pragma unroll
 			for(int k = 0; k < RPL; ++k) {
 				const int i = ib + k;
 				const bool row = lane * RPL + k < ni;
 				bk[k] = row ? c_sym_map[(int) x[i - 1] & 127] : 0;
-				bcol[k] = vit_bcol(ctx, i);
-				ccv[k] = (i < L) ? __dmul_rn(tCC, (double)(L - i)) : 0.0;
 				pm[k] = pi[k] = pd[k] = INFINITY;
 				if(row) look(r, i, g.j0 - 1, pm[k], pi[k], pd[k]);
 			}
@@ -915,20 +929,11 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 					for(int k = 0; k < RPL; ++k) {
 						const int i = ib + k;
 						const double om = pm[k], oi = pi[k], od = pd[k];   /* (i_k, j - 1): left neighbour, and the next row's diagonal */
-						bool in = lane * RPL + k < ni;
-						double mU = um, iU = ui, mL = om, dL = od, dM_ = dm, dI_ = di, dD_ = dd;
-						if(g.band) { /* a band wider than a wave: cells outside are skipped, their neighbours looked up */
-							const int dist = (i - g.from) - (j - g.start);
-							in = in && dist <= g.nIns && dist >= -g.nDel;
-							if(in) {
-								double tmp;
-								if(dist - 1 < -g.nDel && !(lane == 0 && k == 0)) look(r, i - 1, j, mU, iU, tmp);
-								if(dist + 1 > g.nIns && j != g.j0) look(r, i, j - 1, mL, tmp, dL);
-							}
-						}
+						const bool in = lane * RPL + k < ni;
+						const double mU = um, iU = ui, mL = om, dL = od, dM_ = dm, dI_ = di, dD_ = dd;
 						double M = INFINITY, I = INFINITY, D = INFINITY;
 						if(in) {
-							const double pB = bcol[k] + ENv;
+							const double pB = vit_bcol(ctx, i) + ENv;
 							const double pM = dM_ + T0, pI = dI_ + T3, pD = dD_ + T5;
 							double bst = fmin(pM, fmin(pI, pD));
 							if(g.withB) bst = fmin(pB, bst);
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 							M = EMv[k] + bst;
 							I = EIv[k] + fmin(uM, uI);
 							D = (j > 1 && j < K) ? fmin(lM, lD) : INFINITY;
-							const int by = finish(i, j, M, I, D, pB, pM, pI, pD, uM, uI, lM, lD, EXv, ccv[k]);
+							const int by = finish(i, j, M, I, pB, pM, pI, pD, uM, uI, lM, lD, EXv);
 							word |= (dword_t) by << (8 * k);
 						}
 						if(lane * RPL + k < ni) { pm[k] = M; pi[k] = I; pd[k] = D; }
@@ -945,6 +950,10 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 						um = M; ui = I;
 					}
 					*reinterpret_cast<dword_t*>(dcs + g.doff + ((int64_t) t * 64 + lane) * RPL) = word;
+					if(j >= nearJ && ib + RPL - 1 >= nearI) {
+#pragma unroll
+						for(int k = 0; k < RPL; ++k) if(lane * RPL + k < ni && ib + k >= nearI) corner(ib + k, j, pm[k], pi[k], pd[k]);
+					}
 				}
 				gm = fm; gi = fi; gd = fd;
 			}
@@ -967,7 +976,7 @@ __global__ __launch_bounds__(64) void k_viterbi_trace_dec(HuDbDev db, const HuRe
 	const int s = blockIdx.x * 64 + threadIdx.x;
 	if(s >= nSeq) return;
 	HuVitOut o = outs[s];
-	if(o.traceLen != -1) return; /* invalid read */
+	if(o.traceLen != -1 || o.status == HU_READ_NEEDS_VALUES) return; /* invalid read, or left to the value-filing kernels by the fill kernel */
 	const HuReadDesc& rd = descs[s];
 	const int K = db.K, R = rd.nRegions;
 	const double bestS = o.minScore; const int bestCol = o.alnEnd, bestRow = o.alnTo;
