@@ -697,7 +697,10 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 					const int haloWw = std::min(haloW, 512);
 					if(mode == 0 && maxLen <= 512) { /* one wave per sequence, no barrier */
 						const size_t wl = (size_t) 3 * haloWw * sizeof(double);
-						if(maxLen <= 256) { k_viterbi_wave<4><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						const char* dgv = getenv("HU_VW_DIAG");
+						if(maxLen <= 256 && dgv && atoi(dgv) == 1) { k_viterbi_wave<4, 1><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						else if(maxLen <= 256 && dgv && atoi(dgv) == 2) { k_viterbi_wave<4, 2><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						else if(maxLen <= 256) { k_viterbi_wave<4><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
 						else { k_viterbi_wave<8><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 8; }
 					}
 					else if(mode != 1 && maxLen <= 256 && vlds2 <= 96 * 1024) { /* one DP row per thread, nothing global inside the wavefront */

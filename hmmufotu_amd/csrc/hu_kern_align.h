@@ -710,12 +710,17 @@ __device__ inline double dpp_wave_shr1(double v, double lane0) { /* value of lan
 	return __hiloint2double(hi, lo);
 }
 
-struct VwBest { double s; int col, row; };
-__device__ inline void vw_cand(VwBest& b, double sv, int j, int i) {
-	if(sv < b.s || (sv == b.s && (j < b.col || (j == b.col && i < b.row)))) { b.s = sv; b.col = j; b.row = i; }
+/* running minimum of S with Eigen's column-major first-minimum rule as one unsigned key (column - 1) 2^16 + row
+ * (columns 1 .. K + 1 <= 65536, rows <= 65535); branch-free.  A candidate of +inf never displaces anything: when
+ * every candidate is +inf the sequence has no path and its position is not used. */
+struct VwBest { double s; uint32_t key; };
+__device__ inline void vw_cand(VwBest& b, double sv, int j, int i, bool ok) {
+	const uint32_t key = ((uint32_t)(j - 1) << 16) + (uint32_t) i;
+	const bool better = ok & ((sv < b.s) | ((sv == b.s) & (sv < INFINITY) & (key < b.key)));
+	b.s = better ? sv : b.s; b.key = better ? key : b.key;
 }
 
-template<int RPL>
+template<int RPL, int DIAG = 0>
 __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDesc* __restrict__ descs, const char* __restrict__ bases,
 		double* __restrict__ scratch, uint8_t* __restrict__ dec, double tNN, double tNB, double tEC, double tCC,
 		HuVitOut* __restrict__ outs, int haloW) {
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 		if(jj == 0 && ii >= 1) { const double vv = vit_bcol(ctx, ii); m = vv; iv = vv; d = INFINITY; return; }
 		m = iv = d = INFINITY;
 	};
-	VwBest best = { INFINITY, 0x7fffffff, 0x7fffffff };
+	VwBest best = { INFINITY, 0xffffffffu };
 	const double tKIM = db.T[(size_t) K * 8 + 3];
 	for(int r = 0; r < nR; ++r) {
 		const HuRegion g = sreg[r];
@@ -782,15 +787,15 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				if(pI < mn) { dM = 2; mn = pI; }
 				if(j > 1 && pD < mn) { dM = 3; mn = pD; }
 			}
-			if(!(i >= nearI && j >= nearJ)) {
+			{
+				const bool notCorner = !(i >= nearI && j >= nearJ);
 				const double ccv = __dmul_rn(tCC, (double)(L - i));
-				double sv = __dadd_rn(__dadd_rn(M, EXv), tEC);
-				if(i < L) sv = __dadd_rn(sv, ccv);
-				vw_cand(best, sv, j, i);
+				const double s0 = __dadd_rn(__dadd_rn(M, EXv), tEC), s1 = __dadd_rn(s0, ccv);
+				vw_cand(best, i < L ? s1 : s0, j, i, notCorner);
 				if(j == K) {
 					double s2 = __dadd_rn(__dadd_rn(I, tKIM), tEC);
 					if(i < L) s2 = __dadd_rn(s2, ccv);
-					vw_cand(best, s2, K + 1, i);
+					vw_cand(best, s2, K + 1, i, notCorner);
 				}
 			}
 			return dM | ((uI < uM ? 1 : 0) << 2) | ((lD < lM ? 1 : 0) << 3);
@@ -810,11 +815,11 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				const double ccv = __dmul_rn(tCC, (double)(L - i));
 				double sv = __dadd_rn(__dadd_rn(M, db.exitC[j]), tEC);
 				if(i < L) sv = __dadd_rn(sv, ccv);
-				vw_cand(best, sv, j, i);
+				vw_cand(best, sv, j, i, true);
 				if(j == K) {
 					double s2 = __dadd_rn(__dadd_rn(I, tKIM), tEC);
 					if(i < L) s2 = __dadd_rn(s2, ccv);
-					vw_cand(best, s2, K + 1, i);
+					vw_cand(best, s2, K + 1, i, true);
 				}
 			}
 		};
@@ -913,7 +918,8 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				double EMv[RPL], EIv[RPL];
 #pragma unroll
 				for(int k = 0; k < RPL; ++k) { EMv[k] = nEM[k]; EIv[k] = nEI[k]; }
-				if(lane < nL && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1);
+				if(DIAG != 2) { if(lane < nL && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1); }
+				else if(t == 0) fetch(g.j0 + lane % nj);
 				double hm = INFINITY, hi2 = INFINITY, hd = INFINITY;
 				if(lane == 0 && j >= g.j0 - 1 && j <= g.j1) {
 					if(useHalo) { hm = halo[j - g.j0 + 1]; hi2 = halo[haloW + j - g.j0 + 1]; hd = halo[2 * haloW + j - g.j0 + 1]; }
@@ -949,7 +955,8 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 						dm = om; di = oi; dd = od;
 						um = M; ui = I;
 					}
-					*reinterpret_cast<dword_t*>(dcs + g.doff + ((int64_t) t * 64 + lane) * RPL) = word;
+					if(DIAG != 1) *reinterpret_cast<dword_t*>(dcs + g.doff + ((int64_t) t * 64 + lane) * RPL) = word;
+					else if(word == 0x7fffffffu) dcs[0] = 1;
 					if(j >= nearJ && ib + RPL - 1 >= nearI) {
 #pragma unroll
 						for(int k = 0; k < RPL; ++k) if(lane * RPL + k < ni && ib + k >= nearI) corner(ib + k, j, pm[k], pi[k], pd[k]);
@@ -961,12 +968,12 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 		__syncthreads();   /* values filed for later phases are looked up by other lanes */
 	}
 	for(int m = 32; m > 0; m >>= 1) {
-		const double os = __shfl_xor(best.s, m); const int oc = __shfl_xor(best.col, m), orow = __shfl_xor(best.row, m);
-		if(os < best.s || (os == best.s && (oc < best.col || (oc == best.col && orow < best.row)))) { best.s = os; best.col = oc; best.row = orow; }
+		const double os = __shfl_xor(best.s, m); const uint32_t ok = (uint32_t) __shfl_xor((int) best.key, m);
+		if(os < best.s || (os == best.s && ok < best.key)) { best.s = os; best.key = ok; }
 	}
 	if(lane != 0) return;
 	HuVitOut o;
-	o.minScore = best.s; o.alnEnd = best.col; o.alnTo = best.row; o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
+	o.minScore = best.s; o.alnEnd = (int)(best.key >> 16) + 1; o.alnTo = (int)(best.key & 0xffffu); o.alnStart = o.alnFrom = 0; o.traceLen = -1; o.status = HU_READ_NEEDS_FULL;
 	outs[s] = o;
 }
 
