@@ -915,11 +915,7 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				const int j = g.j0 + t - lane;
 				const bool col = lane < nL && j >= g.j0 && j <= g.j1;
 				const double T0 = nT0, T3 = nT3, T5 = nT5, T2 = nT2, T6 = nT6, J1 = nJ1, J4 = nJ4, ENv = nEN, EXv = nEX;
-				double EMv[RPL], EIv[RPL];
-#pragma unroll
-				for(int k = 0; k < RPL; ++k) { EMv[k] = nEM[k]; EIv[k] = nEI[k]; }
-				if(DIAG != 2) { if(lane < nL && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1); }
-				else if(t == 0) fetch(g.j0 + lane % nj);
+				double (&EMv)[RPL] = nEM; double (&EIv)[RPL] = nEI;
 				double hm = INFINITY, hi2 = INFINITY, hd = INFINITY;
 				if(lane == 0 && j >= g.j0 - 1 && j <= g.j1) {
 					if(useHalo) { hm = halo[j - g.j0 + 1]; hi2 = halo[haloW + j - g.j0 + 1]; hd = halo[2 * haloW + j - g.j0 + 1]; }
@@ -963,6 +959,9 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 					}
 				}
 				gm = fm; gi = fi; gd = fd;
+				/* the next column's profile values are requested when this column's are dead: their registers are
+				 * reused, and the other waves of the SIMD cover the wait (three or four fit instead of two) */
+				if(DIAG != 2) { if(lane < nL && j + 1 >= g.j0 && j + 1 <= g.j1) fetch(j + 1); }
 			}
 		}
 		__syncthreads();   /* values filed for later phases are looked up by other lanes */
