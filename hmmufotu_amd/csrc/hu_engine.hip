@@ -11,6 +11,7 @@
 #include <map>
 #include <atomic>
 #include <thread>
+#include <mutex>
 #include <chrono>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
@@ -35,6 +36,33 @@ template<class F> static void parallel_for(size_t n, F f) {
 		for(;;) { size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk); for(size_t i = a; i < e; ++i) f(i); } });
 	for(auto& t : th) t.join();
 }
+
+/* page-locked host memory for the buffers that cross PCIe every batch (pageable memory is staged by the runtime:
+ * a third of the rate, and the copy blocks the calling thread) */
+template<class T> struct PinnedAlloc {
+	typedef T value_type;
+	PinnedAlloc() = default;
+	template<class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+	T* allocate(size_t n) {
+		void* p = nullptr;
+		if(hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); p = malloc(n * sizeof(T)); std::lock_guard<std::mutex> lk(mtx()); pageable().push_back(p); }
+		if(!p) throw std::bad_alloc();
+		return (T*) p;
+	}
+	void deallocate(T* p, size_t) {
+		{
+			std::lock_guard<std::mutex> lk(mtx());
+			auto& v = pageable();
+			for(size_t i = 0; i < v.size(); ++i) if(v[i] == (void*) p) { v.erase(v.begin() + i); free(p); return; }
+		}
+		(void) hipHostFree(p);
+	}
+	static std::vector<void*>& pageable() { static std::vector<void*> v; return v; }
+	static std::mutex& mtx() { static std::mutex m; return m; }
+	template<class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+	template<class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template<class T> using PinnedVec = std::vector<T, PinnedAlloc<T>>;
 
 struct hu_db {
 	int device = 0;
@@ -455,14 +483,14 @@ struct hu_batch {
 	/* host */
 	std::vector<HuReadDesc> hDescs;
 	std::vector<char> hBases;
-	std::vector<HuVitOut> hVit;
+	PinnedVec<HuVitOut> hVit;
 	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
-	std::vector<HuAlnDev> hAlns;
-	std::vector<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
-	std::vector<uint32_t> hSeedDN;
-	std::vector<HuEstOut> hEst;
-	std::vector<HuCand> hCands;
-	std::vector<HuPlaceOut> hPlaceOut;
+	PinnedVec<HuAlnDev> hAlns;
+	PinnedVec<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
+	PinnedVec<uint32_t> hSeedDN;
+	PinnedVec<HuEstOut> hEst;
+	PinnedVec<HuCand> hCands;
+	PinnedVec<HuPlaceOut> hPlaceOut;
 	std::vector<int64_t> candOffs;
 	std::vector<HostPlace> places;    /* candidates in filterPlacements order, all reads */
 	std::vector<hu_place_rec> best;
@@ -906,14 +934,16 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 			pl.erase(pl.begin() + g, pl.end());
 		}
 	});
-	for(size_t r = 0; r < n; ++r) {
+	for(size_t r = 0; r < n; ++r) b->candOffs[r + 1] = b->candOffs[r] + (int64_t) per[r].size();
+	b->places.resize((size_t) b->candOffs[n]); b->hCands.resize((size_t) b->candOffs[n]);
+	parallel_for(n, [&](size_t r) {
+		size_t at = (size_t) b->candOffs[r];
 		for(const HostPlace& p : per[r]) {
-			b->places.push_back(p);
+			b->places[at] = p;
 			HuCand c; c.read = (int32_t) r; c.node = p.cNode; c.ratio0 = p.ratio; c.wnr0 = p.wnr;
-			b->hCands.push_back(c);
+			b->hCands[at++] = c;
 		}
-		b->candOffs[r + 1] = (int64_t) b->places.size();
-	}
+	});
 	b->state = ST_FILTERED;
 	return HU_OK;
 }
