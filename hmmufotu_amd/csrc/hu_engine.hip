@@ -994,11 +994,12 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			}
 			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
 			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
-			else if(spt2 <= 4) PL_GO(4, 2, 1, 0, 2);
-			else if(spt2 <= 8) PL_GO(8, 2, 1, 0, 2);
-			else if(spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
-			else if(spt4 <= 8) PL_GO(8, 4, 1, 0, 1);
-			else PL_GO(12, 4, 1, 0, 1);
+			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
+			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
+			else if(spt2 <= 8) PL_GO(8, 2, 3, 0, 2);
+			else if(spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
+			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
+			else PL_GO(12, 4, 3, 0, 1);
 			#undef PL_GO
 		}
 		#undef PL_ARGS

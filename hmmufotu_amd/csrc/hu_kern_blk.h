@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * NW) void k_estimate_prod(HuDbDev db, HuModelDe
  * The five 4x4 tables are rebuilt per sweep by <= 100 threads; a site costs ~21 FMA + one division instead of
  * three 4x4 matvecs per rate category.  The EM step is p0 / (rho_j q0 + p0) summed over the sites: fma,
  * v_rcp_f64, Newton step(s), add. */
-#define HU_RHO_SKIP 1e200        /* sentinel ratio of a site the EM skips (NaN ratio in the reference, padding) */
+#define HU_RHO_SKIP 1e60         /* sentinel ratio of a site the EM skips (NaN ratio in the reference, padding) */
 #define HU_TP 18                 /* doubles per table row block in LDS (16 + 2: rows of different b on different banks) */
 #define HU_EXP_MEPS 0.99999000004999983333   /* exp(-1e-5) */
 #define HU_EXP_PEPS 1.00001000005000016667   /* exp(+1e-5) */
@@ -365,14 +365,27 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 	if(lane == 0) redc[(phase & 1) * NW + wave] = (double) nvalidWave;
 	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
 		double s = 0;
-		const bool fast = q0 >= 1e-30 && p0 >= 1e-30; /* x = rho q0 + p0 in [1e-30, 1e200]; skipped sites add < 1e-170 */
+		const bool fast = q0 >= 1e-30 && p0 >= 1e-30; /* x = rho q0 + p0 in [1e-30, 1e60]; skipped sites add < 1e-30 */
 		if(fast) {
+			if(EMV == 3 && SPT % 4 == 0) { /* one reciprocal per four sites: 1/a + 1/b + 1/c + 1/d = ((a + b) cd + (c + d) ab) / (abcd);
+				                             * a .. d in [1e-30, 1e60] (skipped sites: 1e60 q0 + p0), so the products stay in range */
 #pragma unroll
-			for(int t = 0; t < SPT; ++t) {
-				const double x = fma(rho[t], q0, p0);
-				const double y = __builtin_amdgcn_rcp(x);
-				if(EMV == 1) s = fma(y, fma(-x, y, 2.0), s);
-				else { const double y1 = fma(fma(-x, y, 1.0), y, y); s = fma(y1, fma(-x, y1, 2.0), s); }
+				for(int t = 0; t < SPT; t += 4) {
+					const double a = fma(rho[t], q0, p0), bb = fma(rho[t + 1], q0, p0), c = fma(rho[t + 2], q0, p0), d = fma(rho[t + 3], q0, p0);
+					const double ab = a * bb, cd = c * d, x = ab * cd;
+					const double num = fma(a + bb, cd, (c + d) * ab);
+					const double y = __builtin_amdgcn_rcp(x);
+					s = fma(num * y, fma(-x, y, 2.0), s);
+				}
+			}
+			else {
+#pragma unroll
+				for(int t = 0; t < SPT; ++t) {
+					const double x = fma(rho[t], q0, p0);
+					const double y = __builtin_amdgcn_rcp(x);
+					if(EMV == 1 || EMV == 3) s = fma(y, fma(-x, y, 2.0), s);
+					else { const double y1 = fma(fma(-x, y, 1.0), y, y); s = fma(y1, fma(-x, y1, 2.0), s); }
+				}
 			}
 		}
 		else { /* degenerate branch lengths (p0 = 0, q0 = 0): the reference's expression as written */
