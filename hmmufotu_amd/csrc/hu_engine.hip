@@ -979,10 +979,11 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			const char* ev = getenv("HU_PLACE_VAR");
 			const int var = ev ? atoi(ev) : 0;
 			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS)
-			if(var == 99 && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
+			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				long long* dd = nullptr;
 				HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
-				k_place_blk<6, 4, 1, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
+				if(var == 99) k_place_blk<6, 4, 3, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
+				else k_place_blk<12, 2, 3, 0, 2, true, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, dd);
 				std::vector<long long> hd(nc * 8);
 				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
 				HIPCHK(hipStreamSynchronize(b->stream));
@@ -997,7 +998,8 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
 			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
 			else if(spt2 <= 8) PL_GO(8, 2, 3, 0, 2);
-			else if(spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
+			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
+			else if(spt2 <= 12) k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS);
 			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
 			else PL_GO(12, 4, 3, 0, 1);
 			#undef PL_GO

@@ -423,7 +423,10 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 }
 
 /* DBG: diagnostic build, s_memtime stamps per phase into dbg[block][8] (load, tables, sweeps, EM, total) */
-template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false>
+/* VL = 1: the third component of the normalised v message lives in LDS (SPT x THREADS doubles) instead of
+ * registers: 2 x 12 sites x 7 doubles do not fit 256 VGPRs beside the temporaries, and the spills were reloaded
+ * inside the serial table phases */
+template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
 		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr) {
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	__shared__ double Gtab[16];
 	__shared__ __attribute__((aligned(16))) double tabM[5 * HU_TP];
 	__shared__ __attribute__((aligned(16))) double tabD[6 * 4];             /* sweep (i): row 0 = G_mm; sweep (ii): row b = T^b_mm */
+	__shared__ double vl[VL ? SPT * 64 * NW : 1];
 	const int tid = threadIdx.x;
 	/* the serial table work of a workgroup runs in one or two of its waves: rotate which by workgroup so that
 	 * the workgroups sharing a CU load different SIMDs with it */
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			const double iu = 1.0 / aU[t][0], iv = 1.0 / aV[t][0];
 #pragma unroll
 			for(int m = 0; m < 3; ++m) { u[t][m] = aU[t][m + 1] * iu; v[t][m] = aV[t][m + 1] * iv; }
+			if(VL) { vl[t * THREADS + tid] = v[t][2]; v[t][2] = 0; }
 		}
 	}
 	for(int i = tid; i < HU_PC_COUNT; i += THREADS) cst[i] = db.placeConst[i];
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	double wur = wur0, wnr = wnr0;
 	int iter = 0, emIters = 0, phase = 0;
 	double rho[SPT];
-	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + v[t][2]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
+	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + v[t][1]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
 	stamp(0);
 	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
 		if(vt < 8 * Kc) {
@@ -506,13 +511,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
 				const double* M = tabM + (unsigned)((bq >> (3 * t)) & 7u) * HU_TP;
-				double num = fma(M[3], v[t][2], fma(M[2], v[t][1], fma(M[1], v[t][0], M[0])));
+				const double v2 = VL ? vl[t * THREADS + tid] : v[t][2];
+				double num = fma(M[3], v2, fma(M[2], v[t][1], fma(M[1], v[t][0], M[0])));
 #pragma unroll
 				for(int m = 1; m < 4; ++m) {
-					const double tm = fma(M[m * 4 + 3], v[t][2], fma(M[m * 4 + 2], v[t][1], fma(M[m * 4 + 1], v[t][0], M[m * 4 + 0])));
+					const double tm = fma(M[m * 4 + 3], v2, fma(M[m * 4 + 2], v[t][1], fma(M[m * 4 + 1], v[t][0], M[m * 4 + 0])));
 					num = fma(tm, u[t][m - 1], num);
 				}
-				const double den = fma(g3 * u[t][2], v[t][2], fma(g2 * u[t][1], v[t][1], fma(g1 * u[t][0], v[t][0], g0)));
+				const double den = fma(g3 * u[t][2], v2, fma(g2 * u[t][1], v[t][1], fma(g1 * u[t][0], v[t][0], g0)));
 				const double r = fast_div(num, den);
 				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
 				rho[t] = ok ? r : HU_RHO_SKIP;
@@ -555,13 +561,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 				const unsigned bi = (unsigned)((bq >> (3 * t)) & 7u);
 				const double* M = tabM + bi * HU_TP;
 				const double* D = tabD + bi * 4;
+				const double v2 = VL ? vl[t * THREADS + tid] : v[t][2];
 				double A = fma(M[3], u[t][2], fma(M[2], u[t][1], fma(M[1], u[t][0], M[0])));
 #pragma unroll
 				for(int m = 1; m < 4; ++m) {
 					const double tm = fma(M[m * 4 + 3], u[t][2], fma(M[m * 4 + 2], u[t][1], fma(M[m * 4 + 1], u[t][0], M[m * 4 + 0])));
-					A = fma(tm, v[t][m - 1], A);
+					A = fma(tm, m == 3 ? v2 : v[t][m - 1], A);
 				}
-				const double piX = fma(D[3], v[t][2], fma(D[2], v[t][1], fma(D[1], v[t][0], D[0])));
+				const double piX = fma(D[3], v2, fma(D[2], v[t][1], fma(D[1], v[t][0], D[0])));
 				const double r = fast_div(A, piX);
 				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP;
 				rho[t] = ok ? r : HU_RHO_SKIP;
