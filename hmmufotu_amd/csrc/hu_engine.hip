@@ -11,6 +11,7 @@
 #include <map>
 #include <atomic>
 #include <thread>
+#include <memory>
 #include <mutex>
 #include <chrono>
 #include "hu_common.h"
@@ -24,17 +25,56 @@
 
 static const double kInf = std::numeric_limits<double>::infinity();
 
-/* the <= 50-record host stages (filterPlacements, calcQValues) are independent per read */
+/* the <= 50-record host stages (filterPlacements, calcQValues) are independent per read: a small persistent pool
+ * per calling thread (creating and joining 16 threads per stage cost more than the stage's work) */
+#include <condition_variable>
+#include <functional>
+struct HuPool {
+	std::vector<std::thread> th;
+	std::mutex m;
+	std::condition_variable cvGo, cvDone;
+	std::function<void(size_t)> fn;
+	size_t n = 0, chunk = 64;
+	std::atomic<size_t> next{0};
+	uint64_t gen = 0;
+	int active = 0;
+	bool quit = false;
+	explicit HuPool(unsigned nt) {
+		for(unsigned t = 0; t < nt; ++t) th.emplace_back([this] {
+			uint64_t seen = 0;
+			for(;;) {
+				{
+					std::unique_lock<std::mutex> lk(m);
+					cvGo.wait(lk, [&] { return quit || gen != seen; });
+					if(quit) return;
+					seen = gen;
+				}
+				work();
+				std::lock_guard<std::mutex> lk(m);
+				if(--active == 0) cvDone.notify_all();
+			}
+		});
+	}
+	void work() { for(;;) { size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk); for(size_t i = a; i < e; ++i) fn(i); } }
+	template<class F> void run(size_t count, F f) {
+		{
+			std::lock_guard<std::mutex> lk(m);
+			fn = f; n = count; next = 0; active = (int) th.size(); ++gen;
+		}
+		cvGo.notify_all();
+		work();                                   /* the caller works too */
+		std::unique_lock<std::mutex> lk(m);
+		cvDone.wait(lk, [&] { return active == 0; });
+	}
+	~HuPool() { { std::lock_guard<std::mutex> lk(m); quit = true; } cvGo.notify_all(); for(auto& t : th) t.join(); }
+};
 template<class F> static void parallel_for(size_t n, F f) {
 	unsigned nt = std::thread::hardware_concurrency();
 	if(nt > 16) nt = 16;
 	if(n < 512 || nt <= 1) { for(size_t i = 0; i < n; ++i) f(i); return; }
-	std::atomic<size_t> next{0};
-	const size_t chunk = 64;
-	std::vector<std::thread> th;
-	for(unsigned t = 0; t < nt; ++t) th.emplace_back([&] {
-		for(;;) { size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk); for(size_t i = a; i < e; ++i) f(i); } });
-	for(auto& t : th) t.join();
+	static thread_local std::unique_ptr<HuPool> pool;    /* one pool per driving thread (one per batch in flight) */
+	if(!pool) pool.reset(new HuPool(nt - 1));
+	pool->run(n, f);
 }
 
 /* page-locked host memory for the buffers that cross PCIe every batch (pageable memory is staged by the runtime:
@@ -493,6 +533,7 @@ struct hu_batch {
 	PinnedVec<HuPlaceOut> hPlaceOut;
 	std::vector<int64_t> candOffs;
 	std::vector<HostPlace> places;    /* candidates in filterPlacements order, all reads */
+	std::vector<HostPlace> tmpPlaces;
 	std::vector<hu_place_rec> best;
 	int maxRegion = 0;
 };
@@ -909,14 +950,12 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 		HIPCHK(hipMemcpyAsync(b->hEst.data(), b->dEst.p, n * HU_MAX_SEEDS * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
 	}
-	b->places.clear(); b->hCands.clear();
 	b->candOffs.assign(n + 1, 0);
-	std::vector<std::vector<HostPlace>> per(n);
+	b->tmpPlaces.resize(n * HU_MAX_SEEDS);       /* per read: its <= 64 estimates, sorted in place; the first candOffs-many are kept */
 	const double maxError = o->max_error;
 	parallel_for(n, [&](size_t r) {
-		std::vector<HostPlace>& pl = per[r];
+		HostPlace* pl = b->tmpPlaces.data() + r * HU_MAX_SEEDS;
 		const int cnt = b->hAlns[r].status == HU_READ_OK ? b->hSeedCnt[r] : 0;
-		pl.reserve(cnt);
 		for(int s = 0; s < cnt; ++s) {
 			const HuEstOut& e = b->hEst[r * HU_MAX_SEEDS + s];
 			HostPlace p;
@@ -924,21 +963,24 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 			p.seedIdx = s; p.cNode = b->hSeedId[r * HU_MAX_SEEDS + s]; p.pNode = db->parent[p.cNode];
 			p.ratio = e.ratio; p.wnr = e.wnr; p.loglik = e.loglik; p.estLoglik = e.loglik; p.wuv = db->blen[p.cNode];
 			p.aNode = p.ratio <= 0.5 ? p.cNode : p.pNode;
-			pl.push_back(p);
+			pl[s] = p;
 		}
-		if(!pl.empty()) { /* filterPlacements (src/HmmUFOtu_main.cpp:162-173) */
-			std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
+		size_t g = 0;
+		if(cnt > 0) { /* filterPlacements (src/HmmUFOtu_main.cpp:162-173): the same std::sort call on the same sequence */
+			std::sort(std::reverse_iterator<HostPlace*>(pl + cnt), std::reverse_iterator<HostPlace*>(pl), cmpLoglik);
 			const double bestLL = pl[0].loglik;
-			size_t g = 0;
-			for(; g < pl.size(); ++g) if(bestLL - pl[g].loglik > maxError) break;
-			pl.erase(pl.begin() + g, pl.end());
+			for(; g < (size_t) cnt; ++g) if(bestLL - pl[g].loglik > maxError) break;
 		}
+		b->candOffs[r + 1] = (int64_t) g;
 	});
-	for(size_t r = 0; r < n; ++r) b->candOffs[r + 1] = b->candOffs[r] + (int64_t) per[r].size();
+	for(size_t r = 0; r < n; ++r) b->candOffs[r + 1] += b->candOffs[r];
 	b->places.resize((size_t) b->candOffs[n]); b->hCands.resize((size_t) b->candOffs[n]);
 	parallel_for(n, [&](size_t r) {
 		size_t at = (size_t) b->candOffs[r];
-		for(const HostPlace& p : per[r]) {
+		const HostPlace* pl = b->tmpPlaces.data() + r * HU_MAX_SEEDS;
+		const size_t cnt = (size_t)(b->candOffs[r + 1] - b->candOffs[r]);
+		for(size_t k = 0; k < cnt; ++k) {
+			const HostPlace& p = pl[k];
 			b->places[at] = p;
 			HuCand c; c.read = (int32_t) r; c.node = p.cNode; c.ratio0 = p.ratio; c.wnr0 = p.wnr;
 			b->hCands[at++] = c;
@@ -1028,8 +1070,9 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 	const double e1 = std::exp(1.0);
 	const double siteLL = std::log((db->mdl.pi[0] * e1 + db->mdl.pi[2] * e1) + (db->mdl.pi[1] * e1 + db->mdl.pi[3] * e1));
 	parallel_for(n, [&](size_t r) {
-		std::vector<HostPlace> pl;
-		std::vector<std::pair<int32_t, double>> tax;
+		static thread_local std::vector<HostPlace> pl;
+		static thread_local std::vector<std::pair<int32_t, double>> tax;
+		static thread_local std::vector<double> pp, pr;
 		hu_place_rec& br = b->best[r];
 		br.c_node = br.p_node = br.a_node = -1; br.n_cand = 0;
 		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = NAN;
@@ -1050,7 +1093,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		else { /* calcQValues (src/HmmUFOtu_main.cpp:182-216) */
 			tax.clear();
 			double norm = -kInf;
-			std::vector<double> pp(pl.size());
+			pp.assign(pl.size(), 0.0);
 			for(size_t i = 0; i < pl.size(); ++i) {
 				const HostPlace& p = pl[i];
 				const double logPrior = o->prior == HU_PRIOR_UNIFORM ? -0.0 : -(p.annoDist() - p.wnr + p.height);
@@ -1065,7 +1108,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 			double mx = pp[0];
 			for(double v : pp) mx = std::max(mx, v);
 			double sum = 0;
-			std::vector<double> pr(pl.size());
+			pr.assign(pl.size(), 0.0);
 			for(size_t i = 0; i < pl.size(); ++i) { pr[i] = std::exp(pp[i] - mx); sum += pr[i]; }
 			for(size_t i = 0; i < pl.size(); ++i) { const double q = p2q(1 - pr[i] / sum); pl[i].qPlace = q > 250 ? 250 : q; }
 			for(size_t i = 0; i < pl.size(); ++i) {
