@@ -168,8 +168,8 @@ __device__ inline int wave_sum_i32(int v) {
 	return v;
 }
 
-template<int SPT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+template<int SPT, int NW, int OCC = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
