@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
 	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
 	/* Fast path (large trees, no height filter): the threshold bin is ESTIMATED from a histogram of one eighth
-	 * of the pairs (every thread takes every eighth of its 16-byte groups, phase by thread), aiming at ~200
+	 * of the pairs (every eighth 128-byte line: 32 consecutive nodes, the phase advancing line by line), aiming at ~200
 	 * survivors; the exact pass then collects every pair at or below that bin.  The result is exact whenever
 	 * the survivors number at least max_nseed (they then contain the max_nseed smallest keys, all ties of the
 	 * last bin included); otherwise, or when they overflow the key buffer, the two-pass path below runs.
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 		if(tid == 0) { sh[3] = 0; sh[4] = 0; }
 		__syncthreads();
 		const int nIt = (db.nNodes + 1023) / 1024;
-		for(int it = (8 - (tid & 7)) & 7; it < nIt; it += 8) { /* iterations with (it + tid) % 8 == 0 */
+		for(int it = (8 - ((tid >> 3) & 7)) & 7; it < nIt; it += 8) { /* whole 128-byte lines (32 nodes, 8 lanes): iterations with (it + tid / 8) % 8 == 0 */
 			const int base = it * 1024 + tid * 4;
 			if(base >= db.nNodes) break;
 			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
