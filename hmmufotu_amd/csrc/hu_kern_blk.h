@@ -355,13 +355,19 @@ __device__ inline double wave_sum_mfma(double x) {
 	return d[0];
 }
 
+/* exp / log as real calls: inlined, their ~20 polynomial coefficients are hoisted out of the candidate's outer loop
+ * and sit in ~45 VGPRs for the whole kernel (64-bit literals cannot be VOP3 operands) — the difference between two
+ * and four workgroups per CU.  They run a few times per EM call, never per site. */
+__device__ __attribute__((noinline)) double hu_exp_call(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double hu_log_call(double x) { return log(x); }
+
 /* EMV: Newton steps on v_rcp_f64 (2^-23 or better): 1 -> 2^-46 per term (a 1e-14 relative bias on the branch
  * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: 0 = DPP butterfly, 1 = MFMA. */
 template<int SPT, int NW, int EMV, int RED>
 __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave, double w0, double maxL,
 		double* red, double* redc, int& phase, int& emIters) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	double q0 = exp(-w0), p0 = 1 - q0, p = p0, q = q0, rc = 0;
+	double q0 = hu_exp_call(-w0), p0 = 1 - q0, p = p0, q = q0, rc = 0;
 	if(lane == 0) redc[(phase & 1) * NW + wave] = (double) nvalidWave;
 	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
 		double s = 0;
@@ -417,13 +423,16 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 		if(q0 * HU_EXP_MEPS < q && q < q0 * HU_EXP_PEPS) break; /* |log q - log q0| < BRANCH_EPS */
 		p0 = p; q0 = q;
 	}
-	double w = -log(q);
+	double w = -hu_log_call(q);
 	if(w > maxL) w = maxL;
 	return w;
 }
 
 /* DBG: diagnostic build, s_memtime stamps per phase into dbg[block][8] (load, tables, sweeps, EM, total) */
-/* VL = 1: the third component of the normalised v message lives in LDS (SPT x THREADS doubles) instead of
+/* VL = 3: the whole normalised v message lives in (dynamic) LDS, 3 x SPT x THREADS doubles: with u and the ratios
+ * the per-thread state is 48 registers at SPT = 6, the kernel fits 128 VGPRs and FOUR workgroups of four waves share
+ * a CU — a SIMD needs four waves to issue FP64 at its full rate (one wave alone issues every ~5 cycles, measured).
+ * VL = 1: the third component of the normalised v message lives in LDS (SPT x THREADS doubles) instead of
  * registers: 2 x 12 sites x 7 doubles do not fit 256 VGPRs beside the temporaries, and the spills were reloaded
  * inside the serial table phases */
 template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 0>
@@ -440,7 +449,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	__shared__ double Gtab[16];
 	__shared__ __attribute__((aligned(16))) double tabM[5 * HU_TP];
 	__shared__ __attribute__((aligned(16))) double tabD[6 * 4];             /* sweep (i): row 0 = G_mm; sweep (ii): row b = T^b_mm */
-	__shared__ double vl[VL ? SPT * 64 * NW : 1];
+	__shared__ double vl[VL == 1 ? SPT * 64 * NW : 1];
+	extern __shared__ double vdyn[];                   /* VL == 3: [3][SPT * THREADS] */
 	const int tid = threadIdx.x;
 	/* the serial table work of a workgroup runs in one or two of its waves: rotate which by workgroup so that
 	 * the workgroups sharing a CU load different SIMDs with it */
@@ -469,7 +479,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			const double iu = 1.0 / aU[t][0], iv = 1.0 / aV[t][0];
 #pragma unroll
 			for(int m = 0; m < 3; ++m) { u[t][m] = aU[t][m + 1] * iu; v[t][m] = aV[t][m + 1] * iv; }
-			if(VL) { vl[t * THREADS + tid] = v[t][2]; v[t][2] = 0; }
+			if(VL == 1) { vl[t * THREADS + tid] = v[t][2]; v[t][2] = 0; }
+			if(VL == 3) {
+#pragma unroll
+				for(int m = 0; m < 3; ++m) { vdyn[(m * SPT + t) * THREADS + tid] = v[t][m]; v[t][m] = 0; }
+			}
 		}
 	}
 	for(int i = tid; i < HU_PC_COUNT; i += THREADS) cst[i] = db.placeConst[i];
@@ -483,12 +497,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	double wur = wur0, wnr = wnr0;
 	int iter = 0, emIters = 0, phase = 0;
 	double rho[SPT];
-	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + v[t][1]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
+	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + u[t][1]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
 	stamp(0);
 	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
 		if(vt < 8 * Kc) {
 			const int which = vt / (4 * Kc), k = (vt >> 2) % Kc, m = vt & 3;
-			Etab[(which * HU_MAX_DGK + k) * 4 + m] = exp(clam[m] * ((which ? lenVR : lenUR) * crate[k]));
+			Etab[(which * HU_MAX_DGK + k) * 4 + m] = hu_exp_call(clam[m] * ((which ? lenVR : lenUR) * crate[k]));
 		}
 		lds_barrier();
 		if(vt < 16) { /* G_mn = mean_k exp(lam_m w_ur r_k) exp(lam_n w_vr r_k) */
@@ -511,14 +525,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
 				const double* M = tabM + (unsigned)((bq >> (3 * t)) & 7u) * HU_TP;
-				const double v2 = VL ? vl[t * THREADS + tid] : v[t][2];
-				double num = fma(M[3], v2, fma(M[2], v[t][1], fma(M[1], v[t][0], M[0])));
+				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
+				const double v2 = VL == 3 ? vdyn[(2 * SPT + t) * THREADS + tid] : VL == 1 ? vl[t * THREADS + tid] : v[t][2];
+				double num = fma(M[3], v2, fma(M[2], v1, fma(M[1], v0, M[0])));
 #pragma unroll
 				for(int m = 1; m < 4; ++m) {
-					const double tm = fma(M[m * 4 + 3], v2, fma(M[m * 4 + 2], v[t][1], fma(M[m * 4 + 1], v[t][0], M[m * 4 + 0])));
+					const double tm = fma(M[m * 4 + 3], v2, fma(M[m * 4 + 2], v1, fma(M[m * 4 + 1], v0, M[m * 4 + 0])));
 					num = fma(tm, u[t][m - 1], num);
 				}
-				const double den = fma(g3 * u[t][2], v2, fma(g2 * u[t][1], v[t][1], fma(g1 * u[t][0], v[t][0], g0)));
+				const double den = fma(g3 * u[t][2], v2, fma(g2 * u[t][1], v1, fma(g1 * u[t][0], v0, g0)));
 				const double r = fast_div(num, den);
 				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
 				rho[t] = ok ? r : HU_RHO_SKIP;
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 		stamp(3);
 		if(vt < 4 * Kc) {
 			const int k = vt >> 2, m = vt & 3;
-			Etab[(2 * HU_MAX_DGK + k) * 4 + m] = exp(clam[m] * (lenNR * crate[k]));
+			Etab[(2 * HU_MAX_DGK + k) * 4 + m] = hu_exp_call(clam[m] * (lenNR * crate[k]));
 		}
 		lds_barrier();
 		if(vt < 16) { /* G'_mn = mean_k exp(lam_m w_vr r_k) exp(lam_n w_nr r_k) */
@@ -561,14 +576,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 				const unsigned bi = (unsigned)((bq >> (3 * t)) & 7u);
 				const double* M = tabM + bi * HU_TP;
 				const double* D = tabD + bi * 4;
-				const double v2 = VL ? vl[t * THREADS + tid] : v[t][2];
+				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
+				const double v2 = VL == 3 ? vdyn[(2 * SPT + t) * THREADS + tid] : VL == 1 ? vl[t * THREADS + tid] : v[t][2];
 				double A = fma(M[3], u[t][2], fma(M[2], u[t][1], fma(M[1], u[t][0], M[0])));
 #pragma unroll
 				for(int m = 1; m < 4; ++m) {
 					const double tm = fma(M[m * 4 + 3], u[t][2], fma(M[m * 4 + 2], u[t][1], fma(M[m * 4 + 1], u[t][0], M[m * 4 + 0])));
-					A = fma(tm, m == 3 ? v2 : v[t][m - 1], A);
+					A = fma(tm, m == 3 ? v2 : m == 2 ? v1 : v0, A);
 				}
-				const double piX = fma(D[3], v2, fma(D[2], v[t][1], fma(D[1], v[t][0], D[0])));
+				const double piX = fma(D[3], v2, fma(D[2], v1, fma(D[1], v0, D[0])));
 				const double r = fast_div(A, piX);
 				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP;
 				rho[t] = ok ? r : HU_RHO_SKIP;
