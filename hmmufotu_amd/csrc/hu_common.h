@@ -35,6 +35,11 @@ struct HuDbDev {
 	                            * first, then the others.  A p-distance is a sum over columns in any order;
 	                            * in this order the few hundred bases of a read sit in 2-3 quads of 128 positions
 	                            * plus the quads of its rare inserts, instead of the ~12 quads of its CS window */
+	/* the non-profile scan positions once more, transposed: for position QM*128 + x and plane p one bit per NODE,
+	 * colPlanes[(x * 3 + p) * (nNodesPad / 64) + node / 64] — what a wave of 64 consecutive nodes needs of one insert
+	 * position is three 8-byte words (in `planes` it is 3 KB: a whole quad's lines for one bit per node) */
+	const unsigned long long* colPlanes;
+	int32_t QM, pad0;
 	const int32_t* parent;
 	const double* blen;
 	const double* height;

@@ -238,6 +238,15 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		uint4* dp = nullptr;
 		if((rc = dev_upload(db, &dp, pl.data(), cnt)) != HU_OK) return fail(rc);
 		d.planes = dp;
+		d.QM = (prof->K + 127) / 128;      /* scan positions >= QM * 128 hold non-profile columns only */
+		if(d.WQ > d.QM) {
+			unsigned long long* cp = nullptr;
+			if((rc = dev_alloc(db, &cp, (size_t)(d.WQ - d.QM) * 128 * 3 * (np / 64))) != HU_OK) return fail(rc);
+			k_col_planes<<<dim3((unsigned)(np / 64), (unsigned)(d.WQ - d.QM)), 64>>>(d, cp);
+			hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+			if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("transposing the non-profile planes failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
+			d.colPlanes = cp;
+		}
 	}
 	{
 		int32_t* p; double* q;
@@ -516,7 +525,7 @@ struct hu_batch {
 	DBuf<uint32_t> dRp, dPairs, dSeedDN;
 	DBuf<int32_t> dTileQ;
 	DBuf<uint32_t> dRq;
-	DBuf<int32_t> dIns;
+	DBuf<int32_t> dIns, dTileIns;
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
@@ -561,7 +570,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	(void) hipStreamSynchronize(b->stream);
 	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;
@@ -696,6 +705,7 @@ static int ensure_read_buffers(hu_batch* b) {
 	if((rc = b->dTileQ.ensure(tiles * (d.WQ + 1))) != HU_OK) return rc;
 	if((rc = b->dRq.ensure(std::max<size_t>(n, 1) * ((d.WQ + 31) / 32))) != HU_OK) return rc;
 	if((rc = b->dIns.ensure(std::max<size_t>(n, 1) * (HU_MAX_INS + 1))) != HU_OK) return rc;
+	if((rc = b->dTileIns.ensure(std::max<size_t>(tiles, 1) * (HU_READ_TILE * HU_MAX_INS + 1))) != HU_OK) return rc;
 	return HU_OK;
 }
 
@@ -724,7 +734,7 @@ extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, con
 		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
 		HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
 		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
-		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dTileQ.p);
+		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p);
 		HIPCHK(hipGetLastError());
 	}
 	b->state = ST_ALIGNED;
@@ -840,7 +850,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 			HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
 			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
-			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dTileQ.p);
+			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p);
 		}
 		HIPCHK(hipGetLastError());
 		b->hAlns.resize(b->nSeq);
@@ -877,7 +887,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
+			if(getenv("HU_PDIST_V1")) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
+			else k_seed_pdist2<<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);

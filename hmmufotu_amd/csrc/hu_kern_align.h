@@ -1214,8 +1214,10 @@ __global__ __launch_bounds__(64) void k_planes_from_codes(HuDbDev db, const int8
 	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, lane, rp, rq, ins);
 }
 
-/* per scan tile: the quads in which any of its reads has a base -> tileQ[tile][0] = count, [1..] = quads */
-__global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint32_t* __restrict__ rq, int32_t* __restrict__ tileQ) {
+/* per scan tile: the quads in which any of its reads has a base -> tileQ[tile][0] = count, [1..] = quads; and the
+ * reads' insert lists as one list, tileIns[tile][0] = count, [1..] = read t << 24 | (scan position << 2 | base) */
+__global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint32_t* __restrict__ rq, const int32_t* __restrict__ ins,
+		int32_t* __restrict__ tileQ, int32_t* __restrict__ tileIns) {
 	const int tile = blockIdx.x, lane = threadIdx.x;
 	const int nw32 = (db.WQ + 31) / 32;
 	int32_t* out = tileQ + (size_t) tile * (db.WQ + 1);
@@ -1226,5 +1228,16 @@ __global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint
 		for(int s = 32; s > 0; s >>= 1) m |= __shfl_xor(m, s);
 		if(lane == 0) while(m) { const int b = __ffs(m) - 1; m &= m - 1; out[1 + cnt++] = w * 32 + b; }
 	}
-	if(lane == 0) out[0] = cnt;
+	if(lane == 0) {
+		out[0] = cnt;
+		int32_t* til = tileIns + (size_t) tile * (HU_READ_TILE * HU_MAX_INS + 1);
+		int ne = 0;
+		for(int t = 0; t < HU_READ_TILE; ++t) {
+			const int r = tile * HU_READ_TILE + t;
+			if(r >= n) break;
+			const int32_t* il = ins + (size_t) r * (HU_MAX_INS + 1);
+			for(int e = 0; e < il[0]; ++e) til[1 + ne++] = (t << 24) | il[1 + e];
+		}
+		til[0] = ne;
+	}
 }

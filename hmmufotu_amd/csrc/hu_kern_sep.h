@@ -97,6 +97,79 @@ __global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* 
 	}
 }
 
+/* The scan with the inserts of a whole tile as ONE list (k_tile_lists): entries (read t << 24 | scan position << 2 |
+ * base) read from the TRANSPOSED planes of the non-profile positions (HuDbDev::colPlanes: three wave-uniform
+ * 8-byte words per insert instead of three 1-KB gathers that fetch a whole quad's lines for one bit per node) and added
+ * into an LDS accumulator [read][lane] (`ds_add_u32`, so the read index may be a run-time value) in the packed
+ * (d << 16 | N) form of the output.  In k_seed_pdist the per-read insert loop (scalar count -> scalar entry -> three
+ * dependent gathers, sixteen times per workgroup) took 36 % of the kernel for ~1 insert per read.
+ * (Staging the reads' planes in LDS instead of the scalar cache was measured: no gain.) */
+/* one-time: colPlanes from planes (see HuDbDev); grid (nNodesPad / 64, WQ - QM), one wave */
+__global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long long* __restrict__ col) {
+	const int nb = blockIdx.x, q = db.QM + blockIdx.y, lane = threadIdx.x;
+	const size_t np = (size_t) db.nNodesPad, npw = np / 64;
+	const int node = nb * 64 + lane;
+	for(int p = 0; p < 3; ++p) {
+		const uint4 v = db.planes[((size_t) q * 3 + p) * np + node];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		for(int i = 0; i < 128; ++i) {
+			const unsigned long long m = __ballot((w[i >> 5] >> (i & 31)) & 1u);
+			if(lane == 0) col[(((size_t) blockIdx.y * 128 + i) * 3 + p) * npw + nb] = m;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, uint32_t* __restrict__ pairs, int nReads) {
+	constexpr int T = HU_READ_TILE;
+	__shared__ uint32_t acc[T][256];
+	const int tile = blockIdx.x, tid = threadIdx.x;
+	const int node = blockIdx.y * 256 + tid;
+	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
+	const int32_t* __restrict__ til = tileIns + (size_t) tile * (T * HU_MAX_INS + 1);
+	const int nq = ql[0], ne = til[0];
+	uint32_t d[T], N[T];
+#pragma unroll
+	for(int t = 0; t < T; ++t) { d[t] = 0; N[t] = 0; }
+	if(ne) {
+#pragma unroll
+		for(int t = 0; t < T; ++t) acc[t][tid] = 0;
+	}
+	const size_t np = (size_t) db.nNodesPad;
+	for(int qi = 0; qi < nq; ++qi) {
+		const int q = ql[1 + qi];
+		const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node], n1 = db.planes[((size_t) q * 3 + 1) * np + node], nv = db.planes[((size_t) q * 3 + 2) * np + node];
+		const uint32_t* __restrict__ r = rp + (((size_t) tile * db.WQ + q) * T) * 16;
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const uint32_t* rt = r + t * 16;
+			uint32_t k, x;
+			k = nv.x & rt[8];  x = ((n0.x ^ rt[0]) | (n1.x ^ rt[4])) & k; d[t] += __popc(x); N[t] += __popc(k);
+			k = nv.y & rt[9];  x = ((n0.y ^ rt[1]) | (n1.y ^ rt[5])) & k; d[t] += __popc(x); N[t] += __popc(k);
+			k = nv.z & rt[10]; x = ((n0.z ^ rt[2]) | (n1.z ^ rt[6])) & k; d[t] += __popc(x); N[t] += __popc(k);
+			k = nv.w & rt[11]; x = ((n0.w ^ rt[3]) | (n1.w ^ rt[7])) & k; d[t] += __popc(x); N[t] += __popc(k);
+		}
+	}
+	{ /* inserts: three wave-uniform 8-byte words per position (bit = node within the wave's 64) */
+		const size_t npw = np / 64;
+		const int nb = __builtin_amdgcn_readfirstlane(node >> 6), lane = tid & 63;
+		for(int e = 0; e < ne; ++e) {
+			const int ent = til[1 + e];
+			const int t = ent >> 24, pos = (ent >> 2) & 0x3fffff, code = ent & 3;
+			const unsigned long long* cp = db.colPlanes + ((size_t)(pos - db.QM * 128) * 3) * npw + nb;
+			const unsigned long long W0 = cp[0], W1 = cp[npw], Wv = cp[2 * npw];
+			const uint32_t valid = (uint32_t)(Wv >> lane) & 1u, nc = ((uint32_t)(W0 >> lane) & 1u) | (((uint32_t)(W1 >> lane) & 1u) << 1);
+			const uint32_t add = valid | ((valid & (nc != (uint32_t) code ? 1u : 0u)) << 16);
+			atomicAdd(&acc[t][tid], add);     /* own slot: no contention, a plain ds_add_u32 */
+		}
+	}
+#pragma unroll
+	for(int t = 0; t < T; ++t) {
+		const int read = tile * T + t;
+		if(read < nReads) pairs[(size_t) read * np + node] = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
+	}
+}
+
 /* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
  * fractions differ by more than 2^-32, so floor(d * 2^39 / N) separates them; N == 0 (the
  * reference's 0/0 = NaN) sorts last.  Ties are broken by node id in the low 24 bits. */
