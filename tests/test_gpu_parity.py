@@ -551,3 +551,35 @@ def test_pe_full_pipeline_against_oracle_batch():
     agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
     assert agree >= 0.8, agree                                     # exact-arithmetic ties may swap (see check_order_and_best)
     B.close(); D.close()
+
+
+def test_wide_region_kernels():
+    """paired-end reads whose merged alignment spans ~2,400 CS columns: the 4-wave / 12-sites-per-thread placement
+    kernel and the 8- and 12-sites-per-thread estimate kernels (the 250 bp single-end benchmark uses the 2-wave / 6-site ones)"""
+    E = _engine()
+    from hmmufotu_amd import synth
+    from oracle import oracle_py as O
+    db = get_db(80, 2800, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    rng = np.random.default_rng(21)
+    ins = synth.simulate_reads(db, 12, 100000, rng, amplicon_start=100, amplicon_cols=2400, jitter=20)
+    fw, rv, vf, vr = [], [], [], []
+    for r in ins:
+        n = len(r.seq)
+        f = synth.SimRead(r.seq[:120], r.cols[:120], r.node, r.rc, r.cs_start, r.cs_end)
+        m = synth.SimRead(r.seq[n - 120:], r.cols[n - 120:], r.node, r.rc, r.cs_start, r.cs_end)
+        fw.append(f.seq); rv.append(m.seq); vf.append(synth.read_vpaths(db.hmm, f)); vr.append(synth.read_vpaths(db.hmm, m))
+    opts = E.default_opts()
+    D = E.Database.from_synth(db); B = E.Batch(D, 16)
+    B.set_reads(fw, np.stack(vf), rv, np.stack(vr)); B.assign(opts)
+    best = B.placements(); recs = B.alignments(want_align=False)["recs"]
+    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2)
+    ok = recs["status"] == 1
+    assert ok.sum() >= 8 and (recs["status"] == ref["aln_ints"][:, 7]).all()
+    span = (recs["cs_end"] - recs["cs_start"])[ok]
+    assert span.max() > 1536, span                                 # beyond the 2-wave kernel's 12 x 128 sites
+    assert np.array_equal(recs["cost"], ref["cost"])
+    assert (best["n_cand"] == ref["n_cand"]).all()
+    agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
+    assert agree >= 0.8, agree
+    B.close(); D.close()
