@@ -69,8 +69,10 @@ struct HuPool {
 	~HuPool() { { std::lock_guard<std::mutex> lk(m); quit = true; } cvGo.notify_all(); for(auto& t : th) t.join(); }
 };
 template<class F> static void parallel_for(size_t n, F f) {
+	/* HU_HOST_THREADS (default 8) per driving thread: several batches are in flight per GPU and eight GPUs share a host */
+	static const unsigned cap = [] { const char* e = getenv("HU_HOST_THREADS"); int v = e ? atoi(e) : 8; return (unsigned)(v < 1 ? 1 : v > 64 ? 64 : v); }();
 	unsigned nt = std::thread::hardware_concurrency();
-	if(nt > 16) nt = 16;
+	if(nt > cap) nt = cap;
 	if(n < 512 || nt <= 1) { for(size_t i = 0; i < n; ++i) f(i); return; }
 	static thread_local std::unique_ptr<HuPool> pool;    /* one pool per driving thread (one per batch in flight) */
 	if(!pool) pool.reset(new HuPool(nt - 1));

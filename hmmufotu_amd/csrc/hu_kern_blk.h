@@ -384,12 +384,20 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 					s = fma(num * y, fma(-x, y, 2.0), s);
 				}
 			}
+			else if(EMV == 4 && SPT % 2 == 0) { /* one reciprocal per two sites: 1/a + 1/b = (a + b) / (ab) */
+#pragma unroll
+				for(int t = 0; t < SPT; t += 2) {
+					const double a = fma(rho[t], q0, p0), bb = fma(rho[t + 1], q0, p0);
+					const double x = a * bb, y = __builtin_amdgcn_rcp(x);
+					s = fma((a + bb) * y, fma(-x, y, 2.0), s);
+				}
+			}
 			else {
 #pragma unroll
 				for(int t = 0; t < SPT; ++t) {
 					const double x = fma(rho[t], q0, p0);
 					const double y = __builtin_amdgcn_rcp(x);
-					if(EMV == 1 || EMV == 3) s = fma(y, fma(-x, y, 2.0), s);
+					if(EMV == 1 || EMV == 3 || EMV == 4) s = fma(y, fma(-x, y, 2.0), s);
 					else { const double y1 = fma(fma(-x, y, 1.0), y, y); s = fma(y1, fma(-x, y1, 2.0), s); }
 				}
 			}
