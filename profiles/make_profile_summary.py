@@ -8,7 +8,7 @@ st = glob.glob(d + '/stats/runc/*_kernel_stats.csv')[0]
 rows = list(csv.DictReader(open(st)))
 mine = [r for r in rows if r['Name'].startswith(('k_', 'void k_'))]
 clean = lambda n: n.split('(')[0].replace('void ', '')
-onetime = lambda nm: nm.startswith(('k_pack', 'k_tree', 'k_model'))
+onetime = lambda nm: nm.startswith(('k_pack', 'k_tree', 'k_model', 'k_col'))
 stage = [('k_viterbi', 'viterbi'), ('k_align', 'align_build'), ('k_encode', 'align_build'), ('k_tile', 'align_build'), ('k_merge', 'align_build'),
          ('k_seed_pdist', 'seed_pdist'), ('k_seed_topk', 'seed_topk'), ('k_estimate', 'estimate'), ('k_place', 'place')]
 def stage_of(nm):
