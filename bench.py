@@ -182,7 +182,7 @@ def main():
     alg = dict(viterbi=nread * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum, seed_topk=4.0 * D.n_nodes * nread,
                estimate=S * 65.0 * Rsum, place=C * 64.0 * Rsum)
     # kernel of each stage as rocprofv3 names it (prefix match: template arguments vary with the read length)
-    pmc_prefix = dict(viterbi=("k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_pdist",), seed_topk=("k_seed_topk",),
+    pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_pdist",), seed_topk=("k_seed_topk",),
                       estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place"))
     pmc = {}
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
