@@ -30,8 +30,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--leaves", type=int, default=int(os.environ.get("HU_BENCH_LEAVES", 99322)))
     ap.add_argument("--cs-len", type=int, default=7682)
     ap.add_argument("--read-len", type=int, default=250)
@@ -71,7 +71,7 @@ def main():
     t0 = time.time()
     db, up, down = synth_gpu.make_db_gpu(args.leaves, args.cs_len, "GTR", dg_k=args.dg_k, seed=97, win=win, device=dev, log=log)
     # reads are drawn from the log-space messages BEFORE the engine adopts (and repacks) them
-    nb = int(os.environ.get("HU_BENCH_INFLIGHT", 4))    # batches in flight per GPU (one host thread + one HIP stream each)
+    nb = int(os.environ.get("HU_BENCH_INFLIGHT", 6))    # batches in flight per GPU (one host thread + one HIP stream each)
     all_reads, all_vps = [], []
     for i in range(nb):
         reads = synth_gpu.simulate_reads_gpu(db, up, down, args.batch, args.read_len, seed=1 + 1000 * rank + i,
