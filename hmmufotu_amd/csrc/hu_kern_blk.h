@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	const int64_t mOff = ((int64_t) un * db.winLen + (start - db.winStart)) * 4;
 	const double* __restrict__ Ub = db.up + mOff;
 	const double* __restrict__ Vb = db.down + mOff;
-	double u[SPT][3], v[SPT][3]; unsigned long long bop = 0;
+	double u[SPT][3], v[SPT][3]; unsigned long long bop = 0, bop2 = 0;   /* base / gap code of slot t: 3 bits, slots 21.. in bop2 */
 	{
 		double aU[SPT][4], aV[SPT][4];
 #pragma unroll
@@ -480,7 +480,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			const int j = tid + THREADS * t, jj = j < n ? j : 0;
 			load4(Ub + (size_t) jj * 4, aU[t]); load4(Vb + (size_t) jj * 4, aV[t]);
 			const int b = cdr[jj];
-			bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
+			if(t < 21) bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
+			else bop2 |= (unsigned long long)(b >= 0 ? b : 4) << (3 * (t - 21));
 		}
 #pragma unroll
 		for(int t = 0; t < SPT; ++t) {
@@ -520,19 +521,21 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			Gtab[vt] = g * rKc;
 		}
 		lds_barrier();
-		if(vt < 80) tabM[(vt >> 4) * HU_TP + (vt & 15)] = cW[vt] * Gtab[vt & 15];
-		else if(vt < 84) tabD[vt - 80] = Gtab[(vt - 80) * 5];
+		for(int e = vt; e < 84; e += THREADS) { /* one entry per thread when the workgroup has two or more waves */
+			if(e < 80) tabM[(e >> 4) * HU_TP + (e & 15)] = cW[e] * Gtab[e & 15];
+			else tabD[e - 80] = Gtab[(e - 80) * 5];
+		}
 		lds_barrier();
 		stamp(1);
 		/* (i) message r->n from children u, v against the read's leaf message; EM on the n-r branch */
 		int nv = 0;
 		{
-			unsigned long long bq = bop;
-			asm volatile("" : "+v"(bq));  /* the per-site table addresses are recomputed per sweep, not kept live */
+			unsigned long long bq = bop, bq2 = bop2;
+			asm volatile("" : "+v"(bq), "+v"(bq2));  /* the per-site table addresses are recomputed per sweep, not kept live */
 			const double g0 = tabD[0], g1 = tabD[1], g2 = tabD[2], g3 = tabD[3];
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
-				const double* M = tabM + (unsigned)((bq >> (3 * t)) & 7u) * HU_TP;
+				const double* M = tabM + (unsigned)(((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21)))) & 7u) * HU_TP;
 				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
 				const double v2 = VL == 3 ? vdyn[(2 * SPT + t) * THREADS + tid] : VL == 1 ? vl[t * THREADS + tid] : v[t][2];
 				double num = fma(M[3], v2, fma(M[2], v1, fma(M[1], v0, M[0])));
@@ -564,24 +567,26 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			Gtab[vt] = g * rKc;
 		}
 		lds_barrier();
-		if(vt < 80) { /* T^b_mn = c^b_n G'_mn; Z^b_mk = sum_n T^b_mn C_mnk */
-			const int b = vt >> 4, m = (vt >> 2) & 3, kk = vt & 3;
-			double z = 0;
+		for(int e = vt; e < 100; e += THREADS) {
+			if(e < 80) { /* T^b_mn = c^b_n G'_mn; Z^b_mk = sum_n T^b_mn C_mnk */
+				const int b = e >> 4, m = (e >> 2) & 3, kk = e & 3;
+				double z = 0;
 #pragma unroll
-			for(int nn = 0; nn < 4; ++nn) z = fma(ccb[b * 4 + nn] * Gtab[m * 4 + nn], cC[(m * 4 + nn) * 4 + kk], z);
-			tabM[b * HU_TP + m * 4 + kk] = z;
+				for(int nn = 0; nn < 4; ++nn) z = fma(ccb[b * 4 + nn] * Gtab[m * 4 + nn], cC[(m * 4 + nn) * 4 + kk], z);
+				tabM[b * HU_TP + m * 4 + kk] = z;
+			}
+			else { const int b = (e - 80) >> 2, m = (e - 80) & 3; tabD[b * 4 + m] = ccb[b * 4 + m] * Gtab[m * 5]; }
 		}
-		else if(vt < 100) { const int b = (vt - 80) >> 2, m = (vt - 80) & 3; tabD[b * 4 + m] = ccb[b * 4 + m] * Gtab[m * 5]; }
 		lds_barrier();
 		stamp(1);
 		/* (ii) message r->u from children v, n against u's own message; EM on the u-r branch */
 		nv = 0;
 		{
-			unsigned long long bq = bop;
-			asm volatile("" : "+v"(bq));
+			unsigned long long bq = bop, bq2 = bop2;
+			asm volatile("" : "+v"(bq), "+v"(bq2));
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
-				const unsigned bi = (unsigned)((bq >> (3 * t)) & 7u);
+				const unsigned bi = (unsigned)((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21))) & 7u);
 				const double* M = tabM + bi * HU_TP;
 				const double* D = tabD + bi * 4;
 				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
