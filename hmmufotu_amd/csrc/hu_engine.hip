@@ -19,6 +19,7 @@
 #include "hu_kern_align.h"
 #include "hu_kern_tree.h"
 #include "hu_kern_blk.h"
+#include <hipcub/hipcub.hpp>
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
 	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
@@ -528,6 +529,8 @@ struct hu_batch {
 	DBuf<int32_t> dTileQ;
 	DBuf<uint32_t> dRq;
 	DBuf<int32_t> dIns, dTileIns;
+	DBuf<uint32_t> dSortK, dSortV;
+	DBuf<uint8_t> dSortTmp;
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
@@ -572,7 +575,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	(void) hipStreamSynchronize(b->stream);
 	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;
@@ -903,6 +906,14 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	return HU_OK;
 }
 
+/* (read, seed) slots -> sort key = seed node (invalid slots last) */
+__global__ void k_seed_sortkeys(int n, const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i >= n * HU_MAX_SEEDS) return;
+	key[i] = (i % HU_MAX_SEEDS) < seedCnt[i / HU_MAX_SEEDS] ? (uint32_t) seedId[i] : 0xffffffffu;
+	val[i] = (uint32_t) i;
+}
+
 extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("hu_estimate_batch: no seeds"); return HU_ERR_STATE; }
@@ -918,6 +929,17 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		const bool stream = getenv("HU_STREAMING_SEP") != nullptr;
 		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
 		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
+		/* launch order of the table-driven kernels: by seed node */
+		const uint32_t* order = nullptr;
+		if(!getenv("HU_EST_UNSORTED")) {
+			if((rc = b->dSortK.ensure((size_t) eg * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) eg * 2)) != HU_OK) return rc;
+			size_t tb = 0;
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
+			if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
+			k_seed_sortkeys<<<(eg + 255) / 256, 256, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dSeedId.p, b->dSortK.p, b->dSortV.p);
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
+			order = b->dSortV.p + eg;
+		}
 		/* register-resident variant (messages cross HBM once) while a read's region fits 256 x SPT sites, the
 		 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
 		 * streaming 12.3 ms with twice the HBM traffic. */
@@ -932,13 +954,13 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 			else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
 			else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
 		}
-		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<eg, 128, 0, b->stream>>>(EST_ARGS);
-		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 2) k_estimate_prod<2, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 4) k_estimate_prod<4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
-		else if(spt <= 8) k_estimate_prod<8, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-		else k_estimate_prod<12, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<eg, 128, 0, b->stream>>>(EST_ARGS, order);
+		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
+		else if(spt <= 2) k_estimate_prod<2, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
+		else if(spt <= 4) k_estimate_prod<4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
+		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
+		else if(spt <= 8) k_estimate_prod<8, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
+		else k_estimate_prod<12, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
 		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());

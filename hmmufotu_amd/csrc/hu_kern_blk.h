@@ -172,12 +172,15 @@ template<int SPT, int NW, int OCC = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
-		int weighted, HuEstOut* __restrict__ out) {
+		int weighted, HuEstOut* __restrict__ out, const uint32_t* __restrict__ order) {
 	constexpr int THREADS = 64 * NW;
 	__shared__ double redd[2 * NW];
 	__shared__ int redi[2 * NW];
 	__shared__ __attribute__((aligned(16))) double Qtab[NW][24];   /* [wave][0..3] = exp(lam_m wnr), [4 + b * 4 + i] = Q^b_i */
-	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	/* `order`: the (read, seed) slots sorted by seed NODE, so that the workgroups reading one node's messages run
+	 * together and all but the first find them in the Infinity Cache / L2 (reads of one sample share their seeds) */
+	const uint32_t slot = order ? order[blockIdx.x] : blockIdx.x;
+	const int read = slot / HU_MAX_SEEDS, s = slot % HU_MAX_SEEDS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if(s >= seedCnt[read]) return;
 	const int un = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int vn = db.parent[un];
