@@ -1026,6 +1026,12 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 	return HU_OK;
 }
 
+__global__ void k_cand_sortkeys(int nc, const HuCand* __restrict__ cands, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i >= nc) return;
+	key[i] = (uint32_t) cands[i].node; val[i] = (uint32_t) i;
+}
+
 extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_FILTERED) { hu_set_error("hu_place_batch: candidates are not filtered"); return HU_ERR_STATE; }
@@ -1056,7 +1062,17 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			Timer t(b, HU_T_PLACE);
 			const char* ev = getenv("HU_PLACE_VAR");
 			const int var = ev ? atoi(ev) : 0;
-			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS)
+			const uint32_t* order = nullptr;
+			if(!getenv("HU_PLACE_UNSORTED")) { /* launch order: by candidate node */
+				if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
+				size_t tb = 0;
+				HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
+				if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
+				k_cand_sortkeys<<<(unsigned)((nc + 255) / 256), 256, 0, b->stream>>>((int) nc, b->dCands.p, b->dSortK.p, b->dSortV.p);
+				HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
+				order = b->dSortV.p + nc;
+			}
+			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order)
 			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				long long* dd = nullptr;
 				HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
@@ -1077,7 +1093,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
 			else if(spt2 <= 8) PL_GO(8, 2, 3, 0, 2);
 			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
-			else if(spt2 <= 12) k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS);
+			else if(spt2 <= 12) k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order);
 			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
 			else PL_GO(12, 4, 3, 0, 1);
 			#undef PL_GO

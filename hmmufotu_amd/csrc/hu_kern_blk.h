@@ -449,7 +449,7 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr) {
+		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr, const uint32_t* __restrict__ order = nullptr) {
 	constexpr int THREADS = 64 * NW;
 	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
 	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
@@ -466,7 +466,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	/* the serial table work of a workgroup runs in one or two of its waves: rotate which by workgroup so that
 	 * the workgroups sharing a CU load different SIMDs with it */
 	const int vt = (tid + 64 * (blockIdx.x % NW)) % THREADS;
-	const HuCand cd = cands[blockIdx.x];
+	const uint32_t ci = order ? order[blockIdx.x] : blockIdx.x;     /* candidates in node order: see k_estimate_prod */
+	const HuCand cd = cands[ci];
 	const int read = cd.read, un = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
 	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
 		wur0 = wur; wnr0 = wnr;
 	}
-	if(tid == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
+	if(tid == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[ci] = o; }
 	if(DBG && tid == 0) {
 		tk[4] = (long long) __builtin_amdgcn_s_memtime() - t0; tk[5] = iter; tk[6] = emIters;
 		for(int i = 0; i < 8; ++i) dbg[(size_t) blockIdx.x * 8 + i] = tk[i];
