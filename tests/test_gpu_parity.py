@@ -130,6 +130,34 @@ def test_generic_decision_byte_viterbi(monkeypatch):
     test_align_parity(dict(model="GTR", dg_k=4, read_len=150))
 
 
+def test_seed_band_wider_than_a_wave():
+    """a seed of 90 bases gives a band phase of 90 rows: k_viterbi_wave hands such sequences (bands beyond 64 rows) to the
+    value-filing kernels; a 40-base seed stays on the wave kernel's one-row-per-lane band routine.  Both bit-exact."""
+    E = _engine()
+    from hmmufotu_amd import synth
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, _ = oracle_objects(db)
+    reads, _ = sim_reads(db, 16, 150)
+    cs2p = synth.cs2profile(db.hmm)
+    vps = np.zeros((len(reads), 2, 6), np.int32)
+    for i, r in enumerate(reads):
+        v = synth.seed_vpath(db.hmm, cs2p, r, 5, 90 if i % 2 == 0 else 40)
+        if v[0] > 0 and v[0] <= v[1] and v[2] > 0 and v[2] <= v[3]:
+            vps[i, 0] = v
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    out = B.alignments(want_align=True, want_trace=True, trace_stride=db.hmm.K + 400)
+    n_long = 0
+    for i, r in enumerate(reads):
+        a = H.align(r.seq, vps[i])
+        rec = out["recs"][i]
+        assert a["ok"] and rec["status"] == 1, i
+        assert rec["cost"] == a["cost"] and out["trace"][i] == a["trace"] and out["align"][i] == a["align"], i
+        n_long += int(vps[i, 0, 3] - vps[i, 0, 2] + 1 > 64)
+    assert n_long >= 4
+    B.close(); D.close()
+
+
 def test_align_modes_and_bad_reads():
     E = _engine()
     db = get_db(120, 700, "GTR", dg_k=4)
