@@ -188,9 +188,11 @@ __device__ inline uint32_t seed_bin(uint32_t d, uint32_t N, uint32_t limit) {
 
 __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* __restrict__ pairs, double maxHeight,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes) {
-	__shared__ uint32_t hist[HU_TOPK_BINS + 1];
-	__shared__ uint32_t chunk[256];
 	__shared__ unsigned long long keys[HU_TOPK_CAP];
+	static_assert(sizeof(unsigned long long) * HU_TOPK_CAP >= sizeof(uint32_t) * (HU_TOPK_BINS + 1), "histogram must fit the key buffer");
+	uint32_t* hist = reinterpret_cast<uint32_t*>(keys);   /* the histogram is dead once the threshold bin is known: the keys take its
+	                                                       * place (33 KB instead of 50 KB of LDS: four workgroups per CU) */
+	__shared__ uint32_t chunk[256];
 	__shared__ uint32_t sh[5];
 	const int read = blockIdx.x, tid = threadIdx.x;
 	const uint32_t* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
