@@ -79,6 +79,20 @@ def test_generator_and_engine_spectral_forms_agree_with_oracle(name):
         assert np.abs((U * np.exp(lam * t)[None, :]) @ U1 - Po).max() < 1e-13
 
 
+@pytest.mark.parametrize("name", MODELS)
+def test_spectral_form_invariants_the_placement_kernel_relies_on(name):
+    """k_place_blk / k_estimate_prod assume: eigenvalue 0 first with U(:,0) = 1 and U^-1(0,:) = pi (component 0 of a
+    packed message is pi . e), and U = Pi^-1/2 V with V orthonormal, i.e. sum_i pi_i U_im U_in = delta_mn."""
+    from hmmufotu_amd import engine as E
+    m, _ = _om(name)
+    U, lam, U1 = E.model_spectral(E.model_desc(m.type_id, m.pi, m.par))
+    pi = np.full(4, 0.25) if name in ("K80", "JC69") else np.asarray(m.pi, float)
+    assert lam[0] == 0.0 and (lam[1:] < 0).all()
+    assert (U[:, 0] == 1.0).all() and np.array_equal(U1[0], pi)
+    assert np.abs(U @ U1 - np.eye(4)).max() < 1e-13
+    assert np.abs((U * pi[:, None]).T @ U - np.eye(4)).max() < 1e-13
+
+
 def test_dgamma_rates_sum_to_one():
     b, r = synth.dgamma(4, 0.5)
     assert abs(r.sum() - 1) < 1e-12 and (np.diff(r) > 0).all() and b[0] == 0 and np.isinf(b[-1])   # F6: not multiplied by K
