@@ -1,8 +1,8 @@
 // hmmufotu-amd — command-line driver with the option surface of the reference's `hmmufotu`
 // (src/hmmufotu.cpp:71-110, defaults :37-57) around the batched engine.  Host C++ only: option parsing,
 // FASTA/FASTQ reading, the seed scans (hu_seed_index_*), strand auto-detection (:500-542), batching, TSV.
-// Not implemented (out of scope this round): -C/--chimera*, -a alignment FASTA output,
-// --align-only, gz/bz2 inputs.
+// -C/--chimera* run the segment check of src/hmmufotu.cpp:653-691 in a second batch (hu_chimera_batch).
+// Not implemented: -a alignment FASTA output, --align-only, gz/bz2 inputs.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +49,8 @@ static void usage(const char* p) {
 		"Options:    -o FILE  -L|--seed-len INT [20]  -R INT [50]  --single  -s|--strand INT [0]  -t|--test INT [100]\n"
 		"            -i|--ignore  -N INT [50]  -d|--max-diff DBL  -H|--max-height DBL  -e|--err DBL [20]\n"
 		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
+		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
+		"            --chimera-out FILE  --chimera-info\n"
 		"            --batch INT [8192]  --gpu INT [0]  -v  -h|--help\n";
 }
 #define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
@@ -60,7 +62,8 @@ struct Packed { std::string bases; std::vector<int64_t> offs{0}; std::vector<int
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
 	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, verbose = 0;
-	bool single = false;
+	bool single = false, checkChimera = false, chimeraInfo = false;
+	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
 	hu_opts o; hu_default_opts(&o);
 	std::string cmd;
 	for(int i = 0; i < argc; ++i) { cmd += argv[i]; cmd += i + 1 < argc ? " " : ""; }
@@ -83,6 +86,12 @@ int main(int argc, char** argv) {
 		else if(a == "--ML") o.only_ml = 1;
 		else if(a == "--prior") prior = val();
 		else if(a == "--fmt") fmt = val();
+		else if(a == "-C" || a == "--chimera") checkChimera = true;
+		else if(a == "--num-segment") numSeg = (int) atof(val());
+		else if(a == "--chimera-err") chimeraErr = atof(val());
+		else if(a == "--chimera-lod") chimeraLod = atof(val());
+		else if(a == "--chimera-out") chiOutFn = val();
+		else if(a == "--chimera-info") chimeraInfo = true;
 		else if(a == "--batch") batch = atoi(val());
 		else if(a == "--gpu") gpu = atoi(val());
 		else if(a == "-v") verbose++;
@@ -99,6 +108,14 @@ int main(int argc, char** argv) {
 	if(!(o.max_error >= 0)) { std::cerr << "-e|--err must be non-negative" << std::endl; return EXIT_FAILURE; }
 	if(method != "unweighted" && method != "weighted") { std::cerr << "-m|--method must be either 'unweighted' or 'weighted'" << std::endl; return EXIT_FAILURE; }
 	if(prior != "uniform" && prior != "height") { std::cerr << "--prior must be either 'uniform' or 'height'" << std::endl; return EXIT_FAILURE; }
+	/* the chimera options only count with -C (src/hmmufotu.cpp:248-260); checks of :325-340 */
+	if(!checkChimera) { chimeraInfo = false; chiOutFn.clear(); numSeg = 2; chimeraErr = NAN; chimeraLod = 0; }
+	if(numSeg < 2 || numSeg > 6) { std::cerr << "--num-segment must be in [2, 6]" << std::endl; return EXIT_FAILURE; }
+	if(numSeg % 2) { std::cerr << "--num-segment must be an even number" << std::endl; return EXIT_FAILURE; }
+	if(std::isnan(chimeraErr)) chimeraErr = o.max_error / numSeg;
+	if(!(chimeraErr > 0)) { std::cerr << "--chimera-err must be positive" << std::endl; return EXIT_FAILURE; }
+	if(!(chimeraLod >= 0)) { std::cerr << "--chimera-lod must be non-negative" << std::endl; return EXIT_FAILURE; }
+	hu_chimera_opts co; co.num_seg = numSeg; co.reserved = 0; co.max_chimera_error = chimeraErr; co.min_chimera_lod = chimeraLod;
 	o.weighted = method == "weighted"; o.prior = prior == "height" ? HU_PRIOR_HEIGHT : HU_PRIOR_UNIFORM;
 	const bool paired = pos.size() == 3;
 	o.align_mode = (paired || !single) ? HU_MODE_GLOBAL : HU_MODE_NGCL;               /* src/hmmufotu.cpp:358 */
@@ -116,8 +133,9 @@ int main(int argc, char** argv) {
 	hu_seed_index* ix = nullptr;
 	CHK(hu_seed_index_create(nNodes, L, parent.data(), seq.data(), K, p2cs.data(), seedLen, &ix));
 	if(verbose) std::cerr << "seed index built: " << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers" << std::endl;
-	hu_batch* gb = nullptr;
+	hu_batch* gb = nullptr; hu_batch* wb = nullptr;
 	CHK(hu_batch_create(db, batch, &gb));
+	if(checkChimera) CHK(hu_batch_create(db, batch, &wb));
 
 	/* strand auto-detection on the first nTest reads by alignment cost (src/hmmufotu.cpp:500-542) */
 	if(strand == 0) {
@@ -151,7 +169,16 @@ int main(int argc, char** argv) {
 	if(paired) { rin.open(revFn); if(!rin) { std::cerr << "Unable to open reverse seq file '" << revFn << "'" << std::endl; return EXIT_FAILURE; } }
 	std::ofstream fout; if(!outFn.empty()) { fout.open(outFn); if(!fout) { std::cerr << "Unable to write to '" << outFn << "'" << std::endl; return EXIT_FAILURE; } }
 	std::ostream& out = outFn.empty() ? std::cout : fout;
-	out << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << hu_tsv_header() << "\n";
+	const char* header = chimeraInfo ? hu_tsv_header_chimera() : hu_tsv_header();
+	out << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << header << "\n";
+	std::ofstream chiOut;
+	if(!chiOutFn.empty()) {
+		chiOut.open(chiOutFn);
+		if(!chiOut) { std::cerr << "Unable to write to '" << chiOutFn << "'" << std::endl; return EXIT_FAILURE; }
+		chiOut << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << header << "\n";
+	}
+	std::vector<hu_chimera_rec> chi;
+	long flagged = 0;
 
 	std::vector<const char*> annos(nNodes);
 	for(int i = 0; i < nNodes; ++i) annos[i] = hu_db_get_annotation(db, i);
@@ -166,14 +193,30 @@ int main(int argc, char** argv) {
 		if(paired) { r.vp.assign((size_t) n * 12, 0); if((rc = hu_seed_index_lookup(ix, n, r.bases.data(), r.offs.data(), seedRegion, o.align_mode, r.vp.data())) != HU_OK) return rc; }
 		if((rc = hu_batch_set_reads(gb, n, f.bases.data(), f.offs.data(), f.vp.data(), paired ? r.bases.data() : nullptr, paired ? r.offs.data() : nullptr,
 				paired ? r.vp.data() : nullptr)) != HU_OK) return rc;
-		if((rc = hu_assign_batch(gb, &o)) != HU_OK) return rc;
+		if(checkChimera) { /* common seeds first, the check on them, then the ordinary estimate/filter/place (src/hmmufotu.cpp:643-733) */
+			chi.resize((size_t) n);
+			if((rc = hu_align_batch(gb, &o)) != HU_OK || (rc = hu_seed_batch(gb, &o)) != HU_OK) return rc;
+			if((rc = hu_chimera_batch(gb, wb, &o, &co, chi.data())) != HU_OK) return rc;
+			if((rc = hu_estimate_batch(gb, &o)) != HU_OK || (rc = hu_filter_batch(gb, &o)) != HU_OK || (rc = hu_place_batch(gb, &o)) != HU_OK ||
+					(rc = hu_finish_batch(gb, &o)) != HU_OK) return rc;
+			for(const hu_chimera_rec& c : chi) flagged += c.is_chimera;
+		}
+		else if((rc = hu_assign_batch(gb, &o)) != HU_OK) return rc;
 		std::vector<const char*> pid(n), pdesc(n);
 		for(int i = 0; i < n; ++i) { pid[i] = ids[i].c_str(); pdesc[i] = descs[i].c_str(); }
-		const int64_t need = hu_batch_format_tsv(gb, pid.data(), pdesc.data(), annos.data(), nullptr, 0);
+		const hu_chimera_rec* cp = checkChimera ? chi.data() : nullptr;
+		const int64_t need = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 0, nullptr, 0);
 		if(need < 0) return (int) need;
 		std::string buf((size_t) need, '\0');
-		hu_batch_format_tsv(gb, pid.data(), pdesc.data(), annos.data(), &buf[0], need);
+		hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 0, &buf[0], need);
 		out << buf;
+		if(chiOut.is_open()) {
+			const int64_t cneed = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, nullptr, 0);
+			if(cneed < 0) return (int) cneed;
+			std::string cbuf((size_t) cneed, '\0');
+			hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, &cbuf[0], cneed);
+			chiOut << cbuf;
+		}
 		for(char c : buf) if(c == '\n') placed++;
 		total += n;
 		f.clear(); r.clear(); ids.clear(); descs.clear();
@@ -188,7 +231,8 @@ int main(int argc, char** argv) {
 		if(f.n() == batch) CHK(flush());
 	}
 	CHK(flush());
-	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << std::endl;
+	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << (checkChimera ? ", " + std::to_string(flagged) + " flagged as chimera" : std::string()) << std::endl;
+	if(wb) hu_batch_destroy(wb);
 	hu_batch_destroy(gb); hu_seed_index_destroy(ix); hu_db_destroy(db);
 	return EXIT_SUCCESS;
 }

@@ -524,7 +524,7 @@ struct hu_batch {
 	DBuf<HuVitOut> dVit;
 	DBuf<HuAlnDev> dAlns;
 	DBuf<int8_t> dCodes;
-	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId;
+	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven;
 	DBuf<uint32_t> dRp, dPairs, dSeedDN;
 	DBuf<int32_t> dTileQ;
 	DBuf<uint32_t> dRq;
@@ -575,7 +575,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	(void) hipStreamSynchronize(b->stream);
 	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	b->dSeedDN.free_(); b->dGiven.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;
@@ -714,7 +714,7 @@ static int ensure_read_buffers(hu_batch* b) {
 	return HU_OK;
 }
 
-extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) {
+static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKind kind, const int32_t* start, const int32_t* end) {
 	if(!b || n < 0 || n > b->maxReads || (n > 0 && (!codes || !start || !end))) { hu_set_error("hu_batch_set_aligned: bad argument"); return HU_ERR_ARG; }
 	HIPCHK(hipSetDevice(b->db->device));
 	const HuDbDev& d = b->db->dev;
@@ -733,7 +733,7 @@ extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, con
 	}
 	(void) hipGetLastError();
 	if(n) {
-		HIPCHK(hipMemcpyAsync(b->dCodes.p, codes, (size_t) n * d.csLen, hipMemcpyHostToDevice, b->stream));
+		if((const void*) codes != (const void*) b->dCodes.p) HIPCHK(hipMemcpyAsync(b->dCodes.p, codes, (size_t) n * d.csLen, kind, b->stream));
 		HIPCHK(hipMemcpyAsync(b->dStart.p, b->hStart.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
 		HIPCHK(hipMemcpyAsync(b->dEnd.p, b->hEnd.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
 		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
@@ -744,6 +744,9 @@ extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, con
 	}
 	b->state = ST_ALIGNED;
 	return HU_OK;
+}
+extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) {
+	return set_aligned_impl(b, n, codes, hipMemcpyHostToDevice, start, end);
 }
 
 extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
@@ -901,6 +904,58 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, fm ? atoi(fm) : 16384);
 		}
 		HIPCHK(hipGetLastError());
+	}
+	b->state = ST_SEEDED;
+	return HU_OK;
+}
+
+/* given seed nodes: (d, N) looked up in the pair matrix of the current regions */
+__global__ void k_seed_given(HuDbDev db, int n, const uint32_t* __restrict__ pairs, const int32_t* __restrict__ cnt, const int32_t* __restrict__ ids,
+		const int32_t* __restrict__ distIds, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i >= n * HU_MAX_SEEDS) return;
+	const int r = i / HU_MAX_SEEDS, sl = i % HU_MAX_SEEDS;
+	if(sl == 0) seedCnt[r] = cnt[r];
+	if(sl < cnt[r]) { seedId[i] = ids[i]; seedDN[i] = pairs[(size_t) r * db.nNodesPad + (distIds ? distIds[i] : ids[i])]; }
+}
+
+extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride) {
+	if(!b || (b->n > 0 && (!n_seeds || !ids)) || stride < 1) { hu_set_error("hu_seed_batch_given: bad argument"); return HU_ERR_ARG; }
+	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch_given: reads are not aligned"); return HU_ERR_STATE; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const HuDbDev& d = b->db->dev;
+	const size_t n = (size_t) b->n;
+	/* every id names the child end of a branch: a node other than the root (checked here: the kernels index with them) */
+	std::vector<int32_t> pk((n * 3) * HU_MAX_SEEDS + n, 0);
+	int32_t* pc = pk.data(); int32_t* pi = pc + n; int32_t* pd = pi + n * HU_MAX_SEEDS;
+	for(size_t r = 0; r < n; ++r) {
+		const int c = n_seeds[r];
+		if(c < 0 || c > HU_MAX_SEEDS || c > stride) { hu_set_error("hu_seed_batch_given: read %zu has %d seeds (0..%d)", r, c, std::min(stride, (int) HU_MAX_SEEDS)); return HU_ERR_ARG; }
+		pc[r] = c;
+		for(int k = 0; k < c; ++k) {
+			const int32_t id = ids[r * stride + k], di = dist_ids ? dist_ids[r * stride + k] : id;
+			if(id < 0 || id >= d.nNodes || b->db->parent[id] < 0 || di < 0 || di >= d.nNodes) { hu_set_error("hu_seed_batch_given: read %zu seed %d names node %d / %d", r, k, id, di); return HU_ERR_ARG; }
+			pi[r * HU_MAX_SEEDS + k] = id; pd[r * HU_MAX_SEEDS + k] = di;
+		}
+	}
+	int rc;
+	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad)) != HU_OK) return rc;
+	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
+	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if((rc = b->dGiven.ensure(pk.size())) != HU_OK) return rc;
+	(void) hipGetLastError();
+	if(n) {
+		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
+		HIPCHK(hipMemcpyAsync(b->dGiven.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, b->stream));
+		{
+			Timer t(b, HU_T_SEED_PDIST);
+			k_seed_pdist2<<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
+		}
+		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->dGiven.p, b->dGiven.p + n,
+				dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
 	}
 	b->state = ST_SEEDED;
 	return HU_OK;
@@ -1200,6 +1255,105 @@ extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
 	b->wall[0] = ms(t0, t1); b->wall[1] = ms(t1, t2); b->wall[2] = ms(t2, t3); b->wall[3] = ms(t3, t4);
 	return rc;
 }
+/* ------------------------------------------------------------------------------ chimera check (-C)
+ * src/hmmufotu.cpp:653-691 as batch passes: each of the num_seg segments, then the two alt placements, is one
+ * run of the given-seed / estimate / filter / place stages in the work batch over per-read regions. */
+extern "C" void hu_default_chimera_opts(const hu_opts* o, hu_chimera_opts* co) {
+	if(!co) return;
+	co->num_seg = 2; co->reserved = 0; co->max_chimera_error = (o ? o->max_error : 20.0) / co->num_seg; co->min_chimera_lod = 0;
+}
+static hu_place_rec to_rec(const HostPlace& p, int32_t nCand);
+struct SegPlace { HostPlace p; int32_t start, end; };
+static bool cmpSegLoglik(const SegPlace& l, const SegPlace& r) { return l.p.loglik < r.p.loglik; }
+
+static int segment_pass(hu_batch* w, hu_batch* b, const hu_opts* o, double maxError, const int32_t* st, const int32_t* en,
+		const int32_t* cnt, const int32_t* ids, const int32_t* distIds) {
+	int rc;
+	if((rc = set_aligned_impl(w, b->n, b->dCodes.p, hipMemcpyDeviceToDevice, st, en)) != HU_OK) return rc;
+	if((rc = hu_seed_batch_given(w, cnt, ids, distIds, HU_MAX_SEEDS)) != HU_OK) return rc;
+	hu_opts so = *o; so.max_error = maxError;
+	if((rc = hu_estimate_batch(w, &so)) != HU_OK) return rc;
+	if((rc = hu_filter_batch(w, &so)) != HU_OK) return rc;
+	if((rc = hu_place_batch(w, &so)) != HU_OK) return rc;
+	return hu_finish_batch(w, &so);
+}
+
+extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out) {
+	if(!b || !w || !o || !co || (b->n > 0 && !out) || b == w) { hu_set_error("hu_chimera_batch: bad argument"); return HU_ERR_ARG; }
+	if(w->db != b->db || w->maxReads < b->n) { hu_set_error("hu_chimera_batch: the work batch must sit on the same database and hold %d reads", b->n); return HU_ERR_ARG; }
+	if(b->state < ST_SEEDED) { hu_set_error("hu_chimera_batch: reads are not seeded"); return HU_ERR_STATE; }
+	/* src/hmmufotu.cpp:325-340 */
+	if(co->num_seg < 2 || co->num_seg > 6 || (co->num_seg % 2)) { hu_set_error("num_seg must be an even number in [2, 6]"); return HU_ERR_ARG; }
+	if(!(co->max_chimera_error > 0)) { hu_set_error("max_chimera_error must be positive"); return HU_ERR_ARG; }
+	if(!(co->min_chimera_lod >= 0)) { hu_set_error("min_chimera_lod must be non-negative"); return HU_ERR_ARG; }
+	HIPCHK(hipSetDevice(b->db->device));
+	const size_t n = (size_t) b->n;
+	const int numSeg = co->num_seg;
+	std::vector<int32_t> cnt(n), ids(n * HU_MAX_SEEDS), dist(n * HU_MAX_SEEDS), st(n), en(n), segLen(n), one(n);
+	if(n) {
+		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(ids.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
+	}
+	HIPCHK(hipStreamSynchronize(b->stream)); /* the work batch reads b's codes on its own stream */
+	for(size_t r = 0; r < n; ++r) {
+		hu_chimera_rec& c = out[r];
+		memset(&c, 0, sizeof(c));
+		c.seg5_start = c.seg5_end = c.seg3_start = c.seg3_end = -1;
+		hu_place_rec none; memset(&none, 0, sizeof(none));
+		none.c_node = none.p_node = none.a_node = -1;
+		none.wuv = none.ratio = none.wnr = none.loglik = none.height = none.q_place = none.q_taxon = none.anno_dist = none.est_loglik = NAN;
+		c.seg5 = c.seg3 = none; c.alt5_loglik = c.alt3_loglik = c.lod = NAN;
+		segLen[r] = b->hAlns[r].status == HU_READ_OK ? (b->hEnd[r] - b->hStart[r] + 1) / numSeg : 0;
+		if(segLen[r] < 1 || cnt[r] < 1) { segLen[r] = 0; cnt[r] = 0; }
+	}
+	std::vector<std::vector<SegPlace>> pool5(n), pool3(n);
+	int rc;
+	for(int sg = 0; sg < numSeg; ++sg) {
+		for(size_t r = 0; r < n; ++r) {
+			if(segLen[r]) { st[r] = b->hStart[r] + sg * segLen[r]; en[r] = st[r] + segLen[r] - 1; }
+			else { st[r] = 0; en[r] = -1; }
+		}
+		if((rc = segment_pass(w, b, o, co->max_chimera_error, st.data(), en.data(), cnt.data(), ids.data(), nullptr)) != HU_OK) return rc;
+		for(size_t r = 0; r < n; ++r) {
+			std::vector<SegPlace>& pool = sg < numSeg / 2 ? pool5[r] : pool3[r];
+			for(int64_t c = w->candOffs[r]; c < w->candOffs[r + 1]; ++c) pool.push_back(SegPlace{w->places[c], st[r], en[r]});
+		}
+	}
+	/* the same std::sort call on the same sequence: the placed logliks tie (F4), the order is its tie permutation */
+	parallel_for(n, [&](size_t r) {
+		std::sort(pool5[r].rbegin(), pool5[r].rend(), cmpSegLoglik);
+		std::sort(pool3[r].rbegin(), pool3[r].rend(), cmpSegLoglik);
+	});
+	std::vector<uint8_t> ok(n, 0);
+	for(size_t r = 0; r < n; ++r) ok[r] = segLen[r] && !pool5[r].empty() && !pool3[r].empty();
+	for(int k = 0; k < 2; ++k) { /* k = 0: seg5's region on seg3's branch, distance to seg5's own node; k = 1 the mirror image */
+		for(size_t r = 0; r < n; ++r) {
+			one[r] = 0; st[r] = 0; en[r] = -1;
+			if(!ok[r]) continue;
+			const SegPlace& own = k == 0 ? pool5[r][0] : pool3[r][0];
+			const SegPlace& oth = k == 0 ? pool3[r][0] : pool5[r][0];
+			one[r] = 1; st[r] = own.start; en[r] = own.end;
+			ids[r * HU_MAX_SEEDS] = oth.p.cNode; dist[r * HU_MAX_SEEDS] = own.p.cNode;
+		}
+		if((rc = segment_pass(w, b, o, INFINITY, st.data(), en.data(), one.data(), ids.data(), dist.data())) != HU_OK) return rc;
+		for(size_t r = 0; r < n; ++r) {
+			double& ll = k == 0 ? out[r].alt5_loglik : out[r].alt3_loglik;
+			if(ok[r] && w->candOffs[r + 1] > w->candOffs[r]) ll = w->places[w->candOffs[r]].loglik;
+		}
+	}
+	for(size_t r = 0; r < n; ++r) {
+		if(!ok[r]) continue;
+		hu_chimera_rec& c = out[r];
+		const SegPlace& s5 = pool5[r][0]; const SegPlace& s3 = pool3[r][0];
+		c.checked = 1;
+		c.seg5_start = s5.start; c.seg5_end = s5.end; c.seg3_start = s3.start; c.seg3_end = s3.end;
+		c.n_seg5 = (int32_t) pool5[r].size(); c.n_seg3 = (int32_t) pool3[r].size();
+		c.seg5 = to_rec(s5.p, c.n_seg5); c.seg3 = to_rec(s3.p, c.n_seg3);
+		c.lod = s5.p.loglik - c.alt5_loglik + s3.p.loglik - c.alt3_loglik;
+		c.is_chimera = s5.p.aNode != s3.p.aNode && c.lod > co->min_chimera_lod;
+	}
+	return HU_OK;
+}
 /* host wall-clock of the last hu_assign_batch: align | seed+estimate+filter | place | finish (ms) */
 extern "C" int hu_batch_wall(hu_batch* b, double* ms4) { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; }
 
@@ -1232,10 +1386,12 @@ extern "C" const char* hu_tsv_header(void) {
 /* operator<<(ostream&, double) at default precision == printf("%g") */
 static void put_g(std::string& o, double v) { char t[40]; snprintf(t, sizeof(t), "%g", v); o += t; }
 
-extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
-		char* buf, int64_t cap) {
+/* which = 0: the assignment file (reads that are HU_READ_OK and not flagged); which = 1: --chimera-out (bad PE orientation
+ * or flagged by the check; the placement columns are a default-constructed PTPlacement, src/hmmufotu.cpp:693-706) */
+static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		const hu_chimera_rec* chi, int info, int which, char* buf, int64_t cap) {
 	if(!b || !ids) { hu_set_error("hu_batch_format_tsv: bad argument"); return HU_ERR_ARG; }
-	if(b->state < ST_FINISHED || b->fromCodes) { hu_set_error("hu_batch_format_tsv: batch is not finished"); return HU_ERR_STATE; }
+	if((which == 0 && b->state < ST_FINISHED) || b->state < ST_ALIGNED || b->fromCodes) { hu_set_error("hu_batch_format_tsv: batch is not finished"); return HU_ERR_STATE; }
 	const int L = b->db->dev.csLen;
 	std::vector<char> rows((size_t) b->n * L);
 	if(b->n) {
@@ -1245,13 +1401,25 @@ extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, cons
 	std::string o;
 	for(int r = 0; r < b->n; ++r) {
 		const HuAlnDev& a = b->hAlns[r];
-		if(a.status != HU_READ_OK) continue;
-		const hu_place_rec& p = b->best[r];
+		const bool flagged = chi && a.status == HU_READ_OK && chi[r].is_chimera;
+		if(which == 0 ? (a.status != HU_READ_OK || flagged) : !(a.status == HU_READ_CHIMERA || flagged)) continue;
 		o += ids[r]; o += '\t'; if(descs && descs[r]) o += descs[r]; o += '\t';
 		o += std::to_string(a.seqStart) + "\t" + std::to_string(a.seqEnd) + "\t" + std::to_string(a.hmmStart) + "\t" + std::to_string(a.hmmEnd) + "\t" +
 				std::to_string(a.csStart) + "\t" + std::to_string(a.csEnd) + "\t";
 		put_g(o, a.cost); o += '\t';
 		o.append(&rows[(size_t) r * L], L); o += '\t';
+		if(info) { /* CHIMERA_TSV_HEADER columns (src/hmmufotu.cpp:57, 701-705, 742-746); unchecked reads print default placements */
+			const bool ck = chi && a.status == HU_READ_OK && chi[r].checked;
+			const int32_t t5 = ck ? chi[r].seg5.a_node : -1, t3 = ck ? chi[r].seg3.a_node : -1;
+			o += std::to_string(t5) + "\t" + std::to_string(t3) + "\t";
+			if(t5 >= 0) { if(annos && annos[t5]) o += annos[t5]; } else o += "UNASSIGNED";
+			o += '\t';
+			if(t3 >= 0) { if(annos && annos[t3]) o += annos[t3]; } else o += "UNASSIGNED";
+			o += '\t';
+			put_g(o, ck ? chi[r].lod : NAN); o += '\t';
+		}
+		hu_place_rec none; none.c_node = -1;
+		const hu_place_rec& p = which == 0 ? b->best[r] : none;
 		if(p.c_node >= 0) {
 			o += std::to_string(p.c_node) + "->" + std::to_string(p.p_node) + "\t"; put_g(o, p.ratio); o += '\t';
 			o += std::to_string(p.a_node) + "\t"; if(annos && annos[p.a_node]) o += annos[p.a_node]; o += '\t';
@@ -1262,6 +1430,20 @@ extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, cons
 	}
 	if(buf && cap > 0) { const size_t m = std::min<size_t>((size_t) cap, o.size()); memcpy(buf, o.data(), m); }
 	return (int64_t) o.size();
+}
+extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		char* buf, int64_t cap) {
+	return format_tsv_impl(b, ids, descs, annos, nullptr, 0, 0, buf, cap);
+}
+extern "C" int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap) {
+	if(which != 0 && which != 1) { hu_set_error("hu_batch_format_tsv_chimera: which must be 0 or 1"); return HU_ERR_ARG; }
+	return format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which, buf, cap);
+}
+extern "C" const char* hu_tsv_header_chimera(void) {
+	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"
+	       "seg5_taxon_id\tseg3_taxon_id\tseg5_taxon_anno\tseg3_taxon_anno\tchimera_lod\t"
+	       "branch_id\tbranch_ratio\ttaxon_id\ttaxon_anno\tanno_dist\tloglik\tQ_placement\tQ_taxon";
 }
 
 /* ------------------------------------------------------------------------------ results */
@@ -1362,6 +1544,20 @@ extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_no
 		if(c_node) c_node[c] = p.cNode; if(ratio) ratio[c] = p.ratio; if(wnr) wnr[c] = p.wnr;
 		if(est_loglik) est_loglik[c] = p.estLoglik; if(iters) iters[c] = p.iters;
 	}
+	return HU_OK;
+}
+static hu_place_rec to_rec(const HostPlace& p, int32_t nCand) {
+	hu_place_rec r;
+	r.c_node = p.cNode; r.p_node = p.pNode; r.a_node = p.aNode; r.n_cand = nCand;
+	r.wuv = p.wuv; r.ratio = p.ratio; r.wnr = p.wnr; r.loglik = p.loglik; r.height = p.height;
+	r.q_place = p.qPlace; r.q_taxon = p.qTaxon; r.anno_dist = p.annoDist(); r.est_loglik = p.estLoglik;
+	return r;
+}
+extern "C" int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs) {
+	if(!b || !recs) return HU_ERR_ARG;
+	if(b->state < ST_FINISHED) { hu_set_error("batch is not finished"); return HU_ERR_STATE; }
+	for(size_t r = 0; r + 1 < b->candOffs.size(); ++r)
+		for(int64_t c = b->candOffs[r]; c < b->candOffs[r + 1]; ++c) recs[c] = to_rec(b->places[c], (int32_t)(b->candOffs[r + 1] - b->candOffs[r]));
 	return HU_OK;
 }
 extern "C" int hu_batch_get_placements(hu_batch* b, hu_place_rec* best) {

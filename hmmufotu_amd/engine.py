@@ -67,6 +67,15 @@ PLACE_DTYPE = np.dtype([("c_node", "i4"), ("p_node", "i4"), ("a_node", "i4"), ("
                         ("anno_dist", "f8"), ("est_loglik", "f8")])
 
 
+class ChimeraOpts(C.Structure):
+    _fields_ = [("num_seg", C.c_int32), ("reserved", C.c_int32), ("max_chimera_error", C.c_double), ("min_chimera_lod", C.c_double)]
+
+
+CHIMERA_DTYPE = np.dtype([("checked", "i4"), ("is_chimera", "i4"), ("seg5_start", "i4"), ("seg5_end", "i4"), ("seg3_start", "i4"),
+                          ("seg3_end", "i4"), ("n_seg5", "i4"), ("n_seg3", "i4"), ("seg5", PLACE_DTYPE), ("seg3", PLACE_DTYPE),
+                          ("alt5_loglik", "f8"), ("alt3_loglik", "f8"), ("lod", "f8")])
+
+
 def build_library(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
@@ -83,6 +92,17 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so (same soname as the system one),
+        # and a process that has both mapped sees the GPU from only the first.  Map torch's copy first (without importing
+        # torch) so that the engine binds to it whichever of the two is imported first.
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else ""
+            if hip and os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
         _LIB = C.CDLL(LIB_PATH)
         _LIB.hu_last_error.restype = C.c_char_p
     return _LIB
@@ -385,6 +405,32 @@ class Batch:
         _chk(load_library().hu_batch_get_placements(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def candidate_places(self):
+        """Every candidate's placement record after calc_q_values, in filterPlacements order."""
+        offs = np.zeros(self.n + 1, np.int64)
+        _chk(load_library().hu_batch_get_candidates(self.h, _p(offs, C.c_int64), None, None, None, None, None))
+        out = np.zeros(int(offs[-1]), PLACE_DTYPE)
+        _chk(load_library().hu_batch_get_candidate_places(self.h, out.ctypes.data_as(C.c_void_p)))
+        return offs, out
+
+    def get_seed_given(self, n_seeds, ids, dist_ids=None):
+        """Segment form of the seed stage: given node ids, distances over the current regions (src/hmmufotu.cpp:662-665)."""
+        n_seeds = np.ascontiguousarray(n_seeds, np.int32); ids = np.ascontiguousarray(ids, np.int32)
+        assert ids.ndim == 2 and ids.shape[0] == self.n == len(n_seeds)
+        di = None
+        if dist_ids is not None:
+            di = np.ascontiguousarray(dist_ids, np.int32); assert di.shape == ids.shape
+        _chk(load_library().hu_seed_batch_given(self.h, _p(n_seeds, C.c_int32), _p(ids, C.c_int32), _p(di, C.c_int32) if di is not None else None,
+                                                C.c_int(ids.shape[1])))
+
+    def check_chimera(self, work: "Batch", opts, num_seg=2, max_chimera_error=None, min_chimera_lod=0.0):
+        """-C of the per-read task (src/hmmufotu.cpp:653-691) for a batch that is at least seeded; `work` is a second batch
+        on the same database whose contents are overwritten."""
+        co = ChimeraOpts(num_seg, 0, opts.max_error / num_seg if max_chimera_error is None else max_chimera_error, min_chimera_lod)
+        out = np.zeros(self.n, CHIMERA_DTYPE)
+        _chk(load_library().hu_chimera_batch(self.h, work.h, C.byref(opts), C.byref(co), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def format_tsv(self, ids, descs=None, annos=None) -> str:
         lib = load_library()
         lib.hu_batch_format_tsv.restype = C.c_int64
@@ -395,6 +441,24 @@ class Batch:
             _chk(int(need))
         buf = C.create_string_buffer(int(need) + 1)
         lib.hu_batch_format_tsv(self.h, a_ids, a_desc, a_anno, buf, C.c_int64(need))
+        return buf.raw[:need].decode("latin1")
+
+    def format_tsv_chimera(self, ids, descs=None, annos=None, chimera=None, chimera_info=False, which=0) -> str:
+        """Assignment lines with -C: which=0 the main file, which=1 --chimera-out (src/hmmufotu.cpp:693-747)."""
+        lib = load_library()
+        lib.hu_batch_format_tsv_chimera.restype = C.c_int64
+        arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
+        a_ids, a_desc, a_anno = arr(ids), arr(descs), arr(annos)
+        cp = None
+        if chimera is not None:
+            chimera = np.ascontiguousarray(chimera, CHIMERA_DTYPE); assert len(chimera) == self.n
+            cp = chimera.ctypes.data_as(C.c_void_p)
+        args = (self.h, a_ids, a_desc, a_anno, cp, C.c_int(int(chimera_info)), C.c_int(which))
+        need = lib.hu_batch_format_tsv_chimera(*args, None, C.c_int64(0))
+        if need < 0:
+            _chk(int(need))
+        buf = C.create_string_buffer(int(need) + 1)
+        lib.hu_batch_format_tsv_chimera(*args, buf, C.c_int64(need))
         return buf.raw[:need].decode("latin1")
 
     def close(self):

@@ -195,6 +195,11 @@ int hu_align_batch(hu_batch* b, const hu_opts* o);
 /* getSeed + truncation to max_nseed (src/HmmUFOtu_main.cpp:127-152, src/hmmufotu.cpp:645-647);
  * order is (dist, node id) — the reference's std::sort order is unspecified among ties */
 int hu_seed_batch(hu_batch* b, const hu_opts* o);
+/* the segment form of the seed stage (src/hmmufotu.cpp:662-665, 682, 686): the node ids are GIVEN
+ * (ids [n][stride], n_seeds[r] <= HU max_nseed of them used) and only their distance is measured over the
+ * batch's current regions — against dist_ids[r][s] when dist_ids is not NULL (the alt-placement PTLoc
+ * takes the distance to another node than the branch it names), else against ids[r][s] */
+int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride);
 /* estimateSeq over the seeds (src/HmmUFOtu_main.cpp:154-160, src/PhyloTreeUnrooted.cpp:849-877) */
 int hu_estimate_batch(hu_batch* b, const hu_opts* o);
 /* filterPlacements (src/HmmUFOtu_main.cpp:162-173) — host, literally std::sort */
@@ -205,6 +210,35 @@ int hu_place_batch(hu_batch* b, const hu_opts* o);
 int hu_finish_batch(hu_batch* b, const hu_opts* o);
 /* the whole per-read task body for the batch (src/hmmufotu.cpp:621-733) */
 int hu_assign_batch(hu_batch* b, const hu_opts* o);
+
+/* ---- chimera check (-C; src/hmmufotu.cpp:653-691) ------------------------------------------
+ * hu_chimera_opts mirrors --num-segment / --chimera-err / --chimera-lod (src/hmmufotu.cpp:145-149, 249-256,
+ * 325-340): num_seg even in [2,6]; max_chimera_error > 0 (CLI default max_error / num_seg);
+ * min_chimera_lod >= 0 */
+typedef struct {
+	int32_t num_seg;
+	int32_t reserved;
+	double max_chimera_error;
+	double min_chimera_lod;
+} hu_chimera_opts;
+/* per read: the best 5' and 3' segment placements and the log-odds against each other's branch.
+ * checked = 0 (and ids -1, lod NaN) for reads that are not HU_READ_OK, have no seed, or whose region is
+ * shorter than num_seg columns — the reference indexes an empty vector there */
+typedef struct {
+	int32_t checked, is_chimera;
+	int32_t seg5_start, seg5_end, seg3_start, seg3_end;   /* 0-based inclusive segment of each winner */
+	int32_t n_seg5, n_seg3;                               /* pooled placements per half               */
+	hu_place_rec seg5, seg3;                              /* a_node = getTaxonId()                    */
+	double alt5_loglik, alt3_loglik;
+	double lod;
+} hu_chimera_rec;
+void hu_default_chimera_opts(const hu_opts* o, hu_chimera_opts* co);
+/* b: a batch that is at least seeded (hu_seed_batch done; it is left untouched and can go on to
+ * hu_estimate_batch ... for the reads that are not chimeric).  work: a second batch on the same database
+ * with max_reads >= b's read count; its contents are overwritten (num_seg + 2 passes of the segment
+ * seed/estimate/filter/place stages run in it).  out [n] */
+int hu_chimera_batch(hu_batch* b, hu_batch* work, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out);
+
 /* wait for everything queued on the batch's stream */
 int hu_batch_sync(hu_batch* b);
 
@@ -217,6 +251,8 @@ int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* logl
 /* all candidates after placement, in filterPlacements order: offs [n+1]; arrays sized offs[n] */
 int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters);
 int hu_batch_get_placements(hu_batch* b, hu_place_rec* best /* [n] */);
+/* every candidate's PTPlacement after hu_finish_batch, in filterPlacements order (offs as above) */
+int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs /* [offs[n]] */);
 
 /* One TSV line per read exactly as the main loop prints it (src/hmmufotu.cpp:736-739: id, description,
  * HmmAlignment operator<< src/BandedHMMP7.cpp:1215-1221, PTPlacement::write
@@ -226,6 +262,14 @@ int hu_batch_get_placements(hu_batch* b, hu_place_rec* best /* [n] */);
  * returns the number of bytes needed (call again with a larger buffer if > cap). */
 int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		char* buf, int64_t cap);
+/* the same with -C: which = 0 writes the assignment file's lines (HU_READ_OK reads the check did not flag), which = 1 the
+ * --chimera-out lines (bad PE orientation, or flagged; placement columns of a default PTPlacement, src/hmmufotu.cpp:693-706).
+ * chimera_info != 0 inserts the --chimera-info columns before the placement (src/hmmufotu.cpp:57, 742-746).  chi [n] from
+ * hu_chimera_batch (NULL: nothing was checked) */
+int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap);
+/* header with the --chimera-info columns (src/hmmufotu.cpp:592-594 with CHIMERA_TSV_HEADER) */
+const char* hu_tsv_header_chimera(void);
 /* the header line of the assignment file (src/hmmufotu.cpp:592-594) */
 const char* hu_tsv_header(void);
 

@@ -152,6 +152,31 @@ int orc_assign(void* tr, const int8_t* seq, int start, int end, const OrcOpts* o
 	return (int) pl.size();
 }
 
+/* chimera check of one aligned read (src/hmmufotu.cpp:653-691).  nSeedIn < 0: seeds from getSeed as the per-read task does;
+ * otherwise the given node ids are the common seeds.  oi[16] = checked, isChimera, seg5 (c,p,a,start,end), seg3 (c,p,a,start,end),
+ * pooled counts n5,n3, spare; od[12] = lod, seg5 (ratio,wnr,loglik,estLoglik), seg3 (same), alt5 loglik, alt3 loglik, spare */
+int orc_chimera(void* tr, const int8_t* seq, int start, int end, const OrcOpts* o, int numSeg, double maxChimeraError, double minChimeraLod,
+		int nSeedIn, const long* seedIn, int* oi, double* od) {
+	const Tree& t = *(Tree*) tr;
+	AssignOpts a = to_opts(o);
+	std::vector<PTLoc> seeds;
+	if(nSeedIn < 0) seeds = getSeed(t, seq, start, end, a.maxDiff, a.maxHeight, a.tieMode, (size_t) a.maxNSeed);
+	else for(int i = 0; i < nSeedIn; ++i) { PTLoc l; l.start = start; l.end = end; l.id = seedIn[i]; l.d = l.N = 0; l.dist = 0; seeds.push_back(l); }
+	ChimeraResult r = chimeraCheck(t, seq, start, end, seeds, a, numSeg, maxChimeraError, minChimeraLod);
+	for(int i = 0; i < 16; ++i) oi[i] = -1;
+	for(int i = 0; i < 12; ++i) od[i] = NAN;
+	oi[0] = r.checked; oi[1] = r.isChimera;
+	if(!r.checked) return 0;
+	const Placement* ps[2] = { &r.seg5, &r.seg3 };
+	for(int k = 0; k < 2; ++k) {
+		oi[2 + 5 * k] = ps[k]->cNode; oi[3 + 5 * k] = ps[k]->pNode; oi[4 + 5 * k] = ps[k]->aNode; oi[5 + 5 * k] = ps[k]->start; oi[6 + 5 * k] = ps[k]->end;
+		od[1 + 4 * k] = ps[k]->ratio; od[2 + 4 * k] = ps[k]->wnr; od[3 + 4 * k] = ps[k]->loglik; od[4 + 4 * k] = ps[k]->estLoglik;
+	}
+	oi[12] = (int) r.n5; oi[13] = (int) r.n3;
+	od[0] = r.lod; od[9] = r.alt5.loglik; od[10] = r.alt3.loglik;
+	return 1;
+}
+
 void orc_tree_evaluate(int nNodes, int csLen, const int* parent, const double* blen, int8_t* seq,
 		void* model, int dgK, const double* dgR, double* up, double* down, double* rootMsg, double* height) {
 	treeEvaluate(nNodes, csLen, parent, blen, seq, *(Model*) model, dgK, dgR, up, down, rootMsg, height);

@@ -396,6 +396,53 @@ inline std::vector<Placement> assignSeq(const Tree& t, const int8_t* seq, int st
 	return places;
 }
 
+/* ---- chimera check (-C) of the per-read task (src/hmmufotu.cpp:653-691) ----
+ * The read's region is cut into numSeg equal segments (integer division; trailing columns belong to no
+ * segment); every segment is estimated/filtered/placed on the read's COMMON seeds with the distance
+ * re-measured inside the segment; the 5' and 3' halves pool their placements, each pool is sorted by the
+ * placed loglik with the same std::sort call, and the two winners are re-scored on each other's branch.
+ * Because of F4 every placed loglik is segLen * log(sum pi e), so the pools tie completely (order =
+ * std::sort's tie permutation of the pooled sequence) and the log-odds come out as exactly 0. */
+struct ChimeraResult { bool checked = false, isChimera = false; double lod = NAN; Placement seg5, seg3, alt5, alt3; size_t n5 = 0, n3 = 0; };
+inline ChimeraResult chimeraCheck(const Tree& t, const int8_t* seq, int start, int end, const std::vector<PTLoc>& seeds,
+		const AssignOpts& o, int numSeg, double maxChimeraError, double minChimeraLod) {
+	ChimeraResult res;
+	const int segLen = (end - start + 1) / numSeg;
+	if(seeds.empty() || segLen < 1) return res; /* the reference indexes an empty vector here (undefined); reported as "not checked" */
+	auto byLoglik = [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; };
+	std::vector<Placement> seg5, seg3;
+	for(int n = 0; n < numSeg; ++n) {
+		const int s0 = start + n * segLen, e0 = s0 + segLen - 1;
+		std::vector<Placement> segPlaces;
+		for(const PTLoc& s : seeds) {
+			PTLoc l; l.start = s0; l.end = e0; l.id = s.id;
+			pdist_counts(seq, t.S((int) s.id), s0, e0, l.d, l.N);
+			l.dist = static_cast<double>(l.d) / l.N;
+			segPlaces.push_back(estimateSeq(t, seq, l, o.weighted != 0));
+		}
+		filterPlacements(segPlaces, maxChimeraError);
+		for(Placement& p : segPlaces) placeSeq(t, seq, p, o.maxHeight);
+		std::vector<Placement>& pool = n < numSeg / 2 ? seg5 : seg3;
+		pool.insert(pool.end(), segPlaces.begin(), segPlaces.end());
+	}
+	res.n5 = seg5.size(); res.n3 = seg3.size();
+	std::sort(seg5.rbegin(), seg5.rend(), byLoglik);
+	std::sort(seg3.rbegin(), seg3.rend(), byLoglik);
+	res.seg5 = seg5[0]; res.seg3 = seg3[0];
+	PTLoc a5; a5.start = res.seg5.start; a5.end = res.seg5.end; a5.id = res.seg3.cNode; /* seg3's branch, distance to seg5's own node */
+	pdist_counts(seq, t.S(res.seg5.cNode), a5.start, a5.end, a5.d, a5.N); a5.dist = static_cast<double>(a5.d) / a5.N;
+	res.alt5 = estimateSeq(t, seq, a5, o.weighted != 0);
+	placeSeq(t, seq, res.alt5, o.maxHeight);
+	PTLoc a3; a3.start = res.seg3.start; a3.end = res.seg3.end; a3.id = res.seg5.cNode;
+	pdist_counts(seq, t.S(res.seg3.cNode), a3.start, a3.end, a3.d, a3.N); a3.dist = static_cast<double>(a3.d) / a3.N;
+	res.alt3 = estimateSeq(t, seq, a3, o.weighted != 0);
+	placeSeq(t, seq, res.alt3, o.maxHeight);
+	res.lod = res.seg5.loglik - res.alt5.loglik + res.seg3.loglik - res.alt3.loglik;
+	res.isChimera = res.seg5.aNode != res.seg3.aNode && res.lod > minChimeraLod; /* getTaxonId() = aNode id (src/PhyloTreeUnrooted.h:430-435) */
+	res.checked = true;
+	return res;
+}
+
 /* ---- tree pre-evaluation (what hmmufotu-build stores in .ptu) ----
  * messages for every directed edge by post-order + pre-order passes, equivalent to the
  * reference's "re-root at every node and evaluate" loop (src/hmmufotu-build.cpp:454-459,

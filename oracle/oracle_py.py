@@ -175,6 +175,21 @@ class Tree:
         k = ns.value
         return dict(n=n, nodes=ni[:n], vals=nd[:n], seed_ids=sid[:k], seed_d=sd[:k], seed_N=sn[:k], est=est[:k], filt_order=fo[:n])
 
+    def chimera(self, seq, start, end, opts=None, num_seg=2, max_chimera_error=None, min_chimera_lod=0.0, seeds=None):
+        """Chimera check of one aligned read (src/hmmufotu.cpp:653-691); seeds=None takes getSeed's."""
+        opts = opts or default_opts()
+        if max_chimera_error is None:
+            max_chimera_error = opts.maxError / num_seg      # src/hmmufotu.cpp:147
+        seq = np.ascontiguousarray(seq, np.int8)
+        oi = np.zeros(16, np.int32); od = np.zeros(12)
+        sd = np.ascontiguousarray(seeds if seeds is not None else np.zeros(0), np.int64)
+        lib().orc_chimera(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.byref(opts), C.c_int(num_seg), C.c_double(max_chimera_error),
+                          C.c_double(min_chimera_lod), C.c_int(-1 if seeds is None else len(sd)), _p(sd, C.c_long), _p(oi, C.c_int), _p(od, C.c_double))
+        return dict(checked=bool(oi[0] == 1), is_chimera=bool(oi[1] == 1), lod=od[0],
+                    seg5=dict(c=int(oi[2]), p=int(oi[3]), a=int(oi[4]), start=int(oi[5]), end=int(oi[6]), ratio=od[1], wnr=od[2], loglik=od[3], est_loglik=od[4]),
+                    seg3=dict(c=int(oi[7]), p=int(oi[8]), a=int(oi[9]), start=int(oi[10]), end=int(oi[11]), ratio=od[5], wnr=od[6], loglik=od[7], est_loglik=od[8]),
+                    n5=int(oi[12]), n3=int(oi[13]), alt5_loglik=od[9], alt3_loglik=od[10])
+
     def __del__(self):
         try:
             lib().orc_tree_free(self.h)

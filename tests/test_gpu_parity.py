@@ -211,7 +211,25 @@ def test_pe_merge_parity():
         assert ok and rec["status"] == 1, i
         assert [rec[k] for k in ("seq_start", "seq_end", "hmm_start", "hmm_end", "cs_start", "cs_end")] == list(im[:6]), i
         assert rec["cost"] == cm and out["align"][i] == am.decode("latin1"), i
-    B.close(); D.close()
+    # with -C the badly oriented pair is a chimera without any check: no line in the assignment file, one in --chimera-out
+    # carrying the forward read's alignment and a default placement (src/hmmufotu.cpp:629-637, 693-706)
+    W = E.Batch(D, len(fw))
+    B.get_seed(opts)
+    chi = B.check_chimera(W, opts)
+    assert chi[0]["checked"] == 0 and chi[0]["is_chimera"] == 0 and np.isnan(chi[0]["lod"]) and chi[1:]["checked"].all()
+    B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+    ids = ["p%d" % i for i in range(len(fw))]
+    main = B.format_tsv_chimera(ids, None, db.annos, chi, True, 0).strip("\n").split("\n")
+    side = B.format_tsv_chimera(ids, None, db.annos, chi, True, 1).strip("\n").split("\n")
+    assert [l.split("\t")[0] for l in main] == ids[1:] and len(side) == 1
+    a0 = H.align(fw[0], vf[0])
+    f = side[0].split("\t")
+    assert f[0] == "p0" and [int(x) for x in f[2:8]] == [a0[k] for k in ("seqStart", "seqEnd", "hmmStart", "hmmEnd", "csStart", "csEnd")]
+    assert f[9] == a0["align"] and f[10:15] == ["-1", "-1", "UNASSIGNED", "UNASSIGNED", "nan"]
+    assert f[15:] == ["NULL", "nan", "-1", "UNASSIGNED", "nan", "nan", "nan", "nan"]
+    plain = B.format_tsv(ids, None, db.annos).strip("\n").split("\n")
+    assert [l.split("\t")[:10] + l.split("\t")[15:] for l in main] == [l.split("\t") for l in plain]
+    W.close(); B.close(); D.close()
 
 
 @pytest.mark.parametrize("cfg", [dict(model="GTR", dg_k=4, n_leaves=300, cs_len=1400, read_len=250),
@@ -464,6 +482,26 @@ def test_cli_end_to_end(tmp_path):
     out3 = subprocess.run([cli, pre, rc, "-v"], capture_output=True, text=True, timeout=300)
     assert out3.returncode == 0 and "strand determined as 2" in out3.stderr, out3.stderr
     assert [l for l in out3.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # -C: nothing is flagged (F4 makes the log-odds 0), so the assignment columns are unchanged; --chimera-info adds five
+    # columns between the alignment and the placement, --chimera-out gets a header and no line
+    chi = str(tmp_path / "chimera.tsv")
+    out4 = subprocess.run([cli, pre, fa, "-s", "1", "-C", "--chimera-info", "--chimera-out", chi, "--num-segment", "4", "-v"],
+                          capture_output=True, text=True, timeout=300)
+    assert out4.returncode == 0 and "0 flagged as chimera" in out4.stderr, out4.stderr
+    l4 = [l.split("\t") for l in out4.stdout.split("\n") if l and not l.startswith("#")]
+    assert l4[0][10:15] == ["seg5_taxon_id", "seg3_taxon_id", "seg5_taxon_anno", "seg3_taxon_anno", "chimera_lod"]
+    W = E.Batch(D, 32)
+    B.align(E.default_opts()); B.get_seed(E.default_opts())
+    cres = B.check_chimera(W, E.default_opts(), num_seg=4)
+    for row, w, c in zip(l4[1:], want, cres):
+        assert row[:10] + row[15:] == w.split("\t")
+        assert (int(row[10]), int(row[11])) == (int(c["seg5"]["a_node"]), int(c["seg3"]["a_node"]))
+        assert row[12] == db.annos[int(row[10])] and row[13] == db.annos[int(row[11])] and row[14] == "0"
+    with open(chi) as f:
+        assert [l for l in f.read().split("\n") if l and not l.startswith("#")] == ["\t".join(l4[0])]
+    assert subprocess.run([cli, pre, fa, "-C", "--num-segment", "3"], capture_output=True).returncode != 0
+    assert subprocess.run([cli, pre, fa, "-C", "--chimera-err", "0"], capture_output=True).returncode != 0
+    W.close()
     # bad options fail like the reference's validation
     assert subprocess.run([cli, pre, fa, "-L", "30"], capture_output=True).returncode != 0
     assert subprocess.run([cli, str(tmp_path / "nodb"), fa], capture_output=True).returncode != 0
@@ -610,4 +648,99 @@ def test_wide_region_kernels():
     assert (best["n_cand"] == ref["n_cand"]).all()
     agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
     assert agree >= 0.8, agree
+    B.close(); D.close()
+
+
+@pytest.mark.parametrize("num_seg,model,dg_k", [(2, "GTR", 4), (4, "TN93", 0), (6, "JC69", 0)])
+def test_chimera_check_parity(num_seg, model, dg_k):
+    """-C (src/hmmufotu.cpp:653-691): per-segment estimate/filter/place on the common seeds, pooled 5'/3' winners and
+    the log-odds against each other's branch, vs the oracle on the same codes and seeds.  Half of the inputs are
+    real chimeras spliced from two reads at the middle of the region."""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(150, 700, model, dg_k=dg_k)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 24, 150)
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    cd, st, en = B.codes()
+    cd = cd.copy()
+    for i in range(0, len(reads) - 1, 2):           # splice: 5' half of read i, 3' half of read i+1 over read i's region
+        mid = (int(st[i]) + int(en[i])) // 2
+        cd[i, mid:] = cd[i + 1, mid:]
+    B.set_aligned(cd, st, en)
+    B.get_seed(opts)
+    cnt, ids, _, _ = B.seeds()
+    W = E.Batch(D, len(reads))
+    res = B.check_chimera(W, opts, num_seg=num_seg)
+    # the seeded batch is untouched and goes on to the ordinary placement
+    B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+    best = B.placements()
+    oo = O.default_opts()
+    tie_diff = 0
+    for i in range(len(reads)):
+        o = T.chimera(cd[i], int(st[i]), int(en[i]), oo, num_seg=num_seg, seeds=ids[i, :cnt[i]])
+        g = res[i]
+        assert bool(g["checked"]) == o["checked"] and o["checked"], i
+        assert bool(g["is_chimera"]) == o["is_chimera"], i
+        assert (g["n_seg5"], g["n_seg3"]) == (o["n5"], o["n3"]), i
+        assert g["lod"] == o["lod"] == 0.0, i                       # F4: all placed logliks are segLen * const
+        assert g["alt5_loglik"] == g["seg5"]["loglik"] and g["alt3_loglik"] == g["seg3"]["loglik"]
+        seg_len = (int(en[i]) - int(st[i]) + 1) // num_seg
+        assert g["seg5_end"] - g["seg5_start"] + 1 == seg_len and g["seg3_end"] - g["seg3_start"] + 1 == seg_len
+        for side in ("seg5", "seg3"):
+            gp, op = g[side], o[side]
+            assert _rel(gp["loglik"], op["loglik"]) < 1e-12
+            if int(gp["c_node"]) != op["c"] or int(g[side + "_start"]) != op["start"]:
+                # the winner sits at a fixed position of the pooled sequence; another node there means two candidates
+                # of that segment swapped in filterPlacements order, allowed for exact-arithmetic ties only (check_order_and_best)
+                assert int(g[side + "_start"]) == op["start"], (i, side)
+                assert abs(gp["est_loglik"] - op["est_loglik"]) <= NEAR_TIE * abs(op["est_loglik"]), (i, side, gp["est_loglik"], op["est_loglik"])
+                tie_diff += 1
+                continue
+            assert (int(gp["p_node"]), int(gp["a_node"])) == (op["p"], op["a"]), (i, side)
+            assert int(g[side + "_end"]) == op["end"]
+            assert _rel(gp["est_loglik"], op["est_loglik"]) < REL
+            assert abs(gp["ratio"] - op["ratio"]) <= REL * max(abs(op["ratio"]), 1e-3)
+            assert abs(gp["wnr"] - op["wnr"]) <= REL * max(abs(op["wnr"]), 1e-3)
+        assert best[i]["n_cand"] >= 1
+    assert tie_diff <= len(reads) // 2, tie_diff
+    print("chimera parity: tie-order differences", tie_diff, "of", 2 * len(reads))
+    # argument checks of src/hmmufotu.cpp:325-340
+    for bad in (dict(num_seg=3), dict(num_seg=8), dict(max_chimera_error=0.0), dict(min_chimera_lod=-1.0)):
+        with pytest.raises(E.EngineError):
+            B.check_chimera(W, opts, **bad)
+    W.close(); B.close(); D.close()
+
+
+def test_given_seed_stage_matches_pdist():
+    """hu_seed_batch_given: the distance of each given node over the CURRENT region, optionally to another node."""
+    E = _engine()
+    db = get_db(100, 700, "GTR", dg_k=0)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 6, 120)
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, reads, vps, opts)
+    cd, st, en = B.codes()
+    half = (st + en) // 2
+    B.set_aligned(cd, st, half)
+    rng = np.random.default_rng(5)
+    nonroot = np.flatnonzero(np.asarray(db.parent) >= 0)
+    ids = rng.choice(nonroot, (len(reads), 7)).astype(np.int32)
+    other = rng.integers(0, len(db.parent), ids.shape).astype(np.int32)
+    n_seeds = np.array([7, 0, 3, 7, 1, 5], np.int32)
+    for dist_ids in (None, other):
+        B.get_seed_given(n_seeds, ids, dist_ids)
+        cnt, gid, gd, gN = B.seeds()
+        assert (cnt == n_seeds).all()
+        for i in range(len(reads)):
+            od, oN = T.pdist_all(cd[i], int(st[i]), int(half[i]))
+            k = n_seeds[i]
+            src = ids[i, :k] if dist_ids is None else other[i, :k]
+            assert (gid[i, :k] == ids[i, :k]).all()
+            assert (gd[i, :k] == od[src]).all() and (gN[i, :k] == oN[src]).all()
+    root = int(np.flatnonzero(np.asarray(db.parent) < 0)[0])
+    ids[0, 0] = root
+    with pytest.raises(E.EngineError):
+        B.get_seed_given(n_seeds, ids)
     B.close(); D.close()

@@ -129,3 +129,44 @@ def test_simulated_reads_place_near_truth():
         near = {r.node, int(db.parent[r.node])} | {int(c) for c in np.nonzero(db.parent == r.node)[0]}
         hit += bool(near & set(int(x) for x in top))
     assert hit >= 14
+
+
+def test_chimera_check_restated_from_its_stages():
+    """-C (src/hmmufotu.cpp:653-691): the one-call restatement equals the composition of the single-placement
+    calls it is made of (segment distance -> estimate -> filter -> place, pooled per half, std::sort on all-tied
+    keys), and under F4 the log-odds are exactly 0, so no read is ever flagged."""
+    from oracle import oracle_py as O
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    al = _aligned(db, H, 6)
+    for k, (r, ds, s, e) in enumerate(al):
+        ds = ds.copy()
+        if k % 2:                                      # a real chimera: 3' half from the next read
+            ds[(s + e) // 2:] = al[(k + 1) % len(al)][1][(s + e) // 2:]
+        for num_seg in (2, 4):
+            seeds = T.get_seed(ds, s, e)[0][:12]
+            res = T.chimera(ds, s, e, num_seg=num_seg, seeds=seeds)
+            assert res["checked"] and not res["is_chimera"] and res["lod"] == 0.0
+            seg_len = (e - s + 1) // num_seg
+            max_err = 20.0 / num_seg                   # src/hmmufotu.cpp:147
+            pools = ([], [])
+            for n in range(num_seg):
+                s0 = s + n * seg_len; e0 = s0 + seg_len - 1
+                d, N = T.pdist_all(ds, s0, e0)
+                ests = []
+                for sid in seeds:
+                    est = T.estimate(ds, s0, e0, int(sid), d[sid] / N[sid] if N[sid] else float("nan"))
+                    ests.append((est["loglik"], int(sid), est))
+                ests = sorted(ests, key=lambda x: -x[0])
+                kept = [x for x in ests if ests[0][0] - x[0] <= max_err]
+                for ll, sid, est in kept:
+                    p = T.place(ds, s0, e0, sid, est["ratio"], est["wnr"])
+                    pools[0 if n < num_seg // 2 else 1].append((sid, s0, e0, p))
+            assert (res["n5"], res["n3"]) == (len(pools[0]), len(pools[1]))
+            for side, pool in zip(("seg5", "seg3"), pools):
+                if len(pool) <= 16:                    # all keys tie: <= 16 elements stay in pooled order
+                    sid, s0, e0, p = pool[0]
+                    got = res[side]
+                    assert (got["c"], got["start"], got["end"]) == (sid, s0, e0)
+                    assert got["ratio"] == p["ratio"] and got["wnr"] == p["wnr"] and got["a"] == p["aNode"]
+                    assert got["loglik"] == p["loglik"]
