@@ -2,7 +2,8 @@
 // (src/hmmufotu.cpp:71-110, defaults :37-57) around the batched engine.  Host C++ only: option parsing,
 // FASTA/FASTQ reading, the seed scans (hu_seed_index_*), strand auto-detection (:500-542), batching, TSV.
 // -C/--chimera* run the segment check of src/hmmufotu.cpp:653-691 in a second batch (hu_chimera_batch).
-// Not implemented: -a alignment FASTA output, --align-only, gz/bz2 inputs.
+// -a writes the aligned reads as FASTA (60 columns, description + ";csStart=..;csEnd=..;", :709-715); --align-only stops
+// after the alignment.  Not implemented: gz/bz2 inputs and outputs.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +51,7 @@ static void usage(const char* p) {
 		"            -i|--ignore  -N INT [50]  -d|--max-diff DBL  -H|--max-height DBL  -e|--err DBL [20]\n"
 		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
 		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
-		"            --chimera-out FILE  --chimera-info\n"
+		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0]  -v  -h|--help\n";
 }
 #define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
@@ -62,7 +63,8 @@ struct Packed { std::string bases; std::vector<int64_t> offs{0}; std::vector<int
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
 	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, verbose = 0;
-	bool single = false, checkChimera = false, chimeraInfo = false;
+	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false;
+	std::string alnFn;
 	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
 	hu_opts o; hu_default_opts(&o);
 	std::string cmd;
@@ -92,6 +94,8 @@ int main(int argc, char** argv) {
 		else if(a == "--chimera-lod") chimeraLod = atof(val());
 		else if(a == "--chimera-out") chiOutFn = val();
 		else if(a == "--chimera-info") chimeraInfo = true;
+		else if(a == "-a") alnFn = val();
+		else if(a == "--align-only") alignOnly = true;
 		else if(a == "--batch") batch = atoi(val());
 		else if(a == "--gpu") gpu = atoi(val());
 		else if(a == "-v") verbose++;
@@ -177,7 +181,10 @@ int main(int argc, char** argv) {
 		if(!chiOut) { std::cerr << "Unable to write to '" << chiOutFn << "'" << std::endl; return EXIT_FAILURE; }
 		chiOut << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << header << "\n";
 	}
+	std::ofstream alnOut;
+	if(!alnFn.empty()) { alnOut.open(alnFn); if(!alnOut) { std::cerr << "Unable to write to align file '" << alnFn << "'" << std::endl; return EXIT_FAILURE; } }
 	std::vector<hu_chimera_rec> chi;
+	std::vector<hu_align_rec> alnRecs; std::vector<char> alnRows;
 	long flagged = 0;
 
 	std::vector<const char*> annos(nNodes);
@@ -197,19 +204,30 @@ int main(int argc, char** argv) {
 			chi.resize((size_t) n);
 			if((rc = hu_align_batch(gb, &o)) != HU_OK || (rc = hu_seed_batch(gb, &o)) != HU_OK) return rc;
 			if((rc = hu_chimera_batch(gb, wb, &o, &co, chi.data())) != HU_OK) return rc;
-			if((rc = hu_estimate_batch(gb, &o)) != HU_OK || (rc = hu_filter_batch(gb, &o)) != HU_OK || (rc = hu_place_batch(gb, &o)) != HU_OK ||
-					(rc = hu_finish_batch(gb, &o)) != HU_OK) return rc;
+			if(!alignOnly && ((rc = hu_estimate_batch(gb, &o)) != HU_OK || (rc = hu_filter_batch(gb, &o)) != HU_OK || (rc = hu_place_batch(gb, &o)) != HU_OK ||
+					(rc = hu_finish_batch(gb, &o)) != HU_OK)) return rc;
 			for(const hu_chimera_rec& c : chi) flagged += c.is_chimera;
 		}
-		else if((rc = hu_assign_batch(gb, &o)) != HU_OK) return rc;
+		else if((rc = alignOnly ? hu_align_batch(gb, &o) : hu_assign_batch(gb, &o)) != HU_OK) return rc;
+		const int mainKind = alignOnly ? 2 : 0;
 		std::vector<const char*> pid(n), pdesc(n);
 		for(int i = 0; i < n; ++i) { pid[i] = ids[i].c_str(); pdesc[i] = descs[i].c_str(); }
 		const hu_chimera_rec* cp = checkChimera ? chi.data() : nullptr;
-		const int64_t need = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 0, nullptr, 0);
+		const int64_t need = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, nullptr, 0);
 		if(need < 0) return (int) need;
 		std::string buf((size_t) need, '\0');
-		hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 0, &buf[0], need);
+		hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, &buf[0], need);
 		out << buf;
+		if(alnOut.is_open()) { /* aligned reads that are not chimeras (src/hmmufotu.cpp:709-715; SeqIO::writeFastaSeq, 60 columns) */
+			alnRecs.resize((size_t) n); alnRows.resize((size_t) n * L);
+			if((rc = hu_batch_get_alignments(gb, alnRecs.data(), alnRows.data(), nullptr, 0)) != HU_OK) return rc;
+			for(int i = 0; i < n; ++i) {
+				if(alnRecs[i].status != HU_READ_OK || (cp && cp[i].is_chimera)) continue;
+				const std::string d = descs[i] + ";csStart=" + std::to_string(alnRecs[i].cs_start) + ";csEnd=" + std::to_string(alnRecs[i].cs_end) + ";";
+				alnOut << '>' << ids[i] << ' ' << d << '\n';
+				for(int c = 0; c < L; c += 60) { alnOut.write(&alnRows[(size_t) i * L + c], std::min(60, L - c)); alnOut.put('\n'); }
+			}
+		}
 		if(chiOut.is_open()) {
 			const int64_t cneed = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, nullptr, 0);
 			if(cneed < 0) return (int) cneed;

@@ -1387,7 +1387,8 @@ extern "C" const char* hu_tsv_header(void) {
 static void put_g(std::string& o, double v) { char t[40]; snprintf(t, sizeof(t), "%g", v); o += t; }
 
 /* which = 0: the assignment file (reads that are HU_READ_OK and not flagged); which = 1: --chimera-out (bad PE orientation
- * or flagged by the check; the placement columns are a default-constructed PTPlacement, src/hmmufotu.cpp:693-706) */
+ * or flagged by the check; the placement columns are a default-constructed PTPlacement, src/hmmufotu.cpp:693-706);
+ * which = 2: the assignment file of --align-only (as 0, nothing placed: default placement columns, :717-739) */
 static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		const hu_chimera_rec* chi, int info, int which, char* buf, int64_t cap) {
 	if(!b || !ids) { hu_set_error("hu_batch_format_tsv: bad argument"); return HU_ERR_ARG; }
@@ -1402,7 +1403,7 @@ static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* 
 	for(int r = 0; r < b->n; ++r) {
 		const HuAlnDev& a = b->hAlns[r];
 		const bool flagged = chi && a.status == HU_READ_OK && chi[r].is_chimera;
-		if(which == 0 ? (a.status != HU_READ_OK || flagged) : !(a.status == HU_READ_CHIMERA || flagged)) continue;
+		if(which != 1 ? (a.status != HU_READ_OK || flagged) : !(a.status == HU_READ_CHIMERA || flagged)) continue;
 		o += ids[r]; o += '\t'; if(descs && descs[r]) o += descs[r]; o += '\t';
 		o += std::to_string(a.seqStart) + "\t" + std::to_string(a.seqEnd) + "\t" + std::to_string(a.hmmStart) + "\t" + std::to_string(a.hmmEnd) + "\t" +
 				std::to_string(a.csStart) + "\t" + std::to_string(a.csEnd) + "\t";
@@ -1437,7 +1438,7 @@ extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, cons
 }
 extern "C" int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap) {
-	if(which != 0 && which != 1) { hu_set_error("hu_batch_format_tsv_chimera: which must be 0 or 1"); return HU_ERR_ARG; }
+	if(which < 0 || which > 2) { hu_set_error("hu_batch_format_tsv_chimera: which must be 0, 1 or 2"); return HU_ERR_ARG; }
 	return format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which, buf, cap);
 }
 extern "C" const char* hu_tsv_header_chimera(void) {

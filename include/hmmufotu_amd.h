@@ -264,6 +264,7 @@ int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* con
 		char* buf, int64_t cap);
 /* the same with -C: which = 0 writes the assignment file's lines (HU_READ_OK reads the check did not flag), which = 1 the
  * --chimera-out lines (bad PE orientation, or flagged; placement columns of a default PTPlacement, src/hmmufotu.cpp:693-706).
+ * which = 2 is the assignment file of --align-only: as 0 for a batch that is only aligned, default placement columns.
  * chimera_info != 0 inserts the --chimera-info columns before the placement (src/hmmufotu.cpp:57, 742-746).  chi [n] from
  * hu_chimera_batch (NULL: nothing was checked) */
 int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,

@@ -499,6 +499,20 @@ def test_cli_end_to_end(tmp_path):
         assert row[12] == db.annos[int(row[10])] and row[13] == db.annos[int(row[11])] and row[14] == "0"
     with open(chi) as f:
         assert [l for l in f.read().split("\n") if l and not l.startswith("#")] == ["\t".join(l4[0])]
+    # -a: the aligned reads as FASTA, 60 columns a line; --align-only: the alignment columns with a default placement
+    alnf = str(tmp_path / "aln.fasta")
+    out5 = subprocess.run([cli, pre, fa, "-s", "1", "-a", alnf, "--align-only"], capture_output=True, text=True, timeout=300)
+    assert out5.returncode == 0, out5.stderr
+    l5 = [l.split("\t") for l in out5.stdout.split("\n") if l and not l.startswith("#")]
+    assert [r[:10] for r in l5[1:]] == [w.split("\t")[:10] for w in want]
+    assert all(r[10:] == ["NULL", "nan", "-1", "UNASSIGNED", "nan", "nan", "nan", "nan"] for r in l5[1:])
+    recs = open(alnf).read().split(">")[1:]
+    assert len(recs) == len(reads)
+    for i, (rec, w) in enumerate(zip(recs, want)):
+        head, *body = rec.strip("\n").split("\n")
+        f = w.split("\t")
+        assert head == "read%d sample=%d;csStart=%s;csEnd=%s;" % (i, i % 3, f[6], f[7])
+        assert "".join(body) == f[9] and all(len(x) == 60 for x in body[:-1]) and len(body[-1]) <= 60
     assert subprocess.run([cli, pre, fa, "-C", "--num-segment", "3"], capture_output=True).returncode != 0
     assert subprocess.run([cli, pre, fa, "-C", "--chimera-err", "0"], capture_output=True).returncode != 0
     W.close()
