@@ -758,3 +758,52 @@ def test_given_seed_stage_matches_pdist():
     with pytest.raises(E.EngineError):
         B.get_seed_given(n_seeds, ids)
     B.close(); D.close()
+
+
+def test_chimera_check_edge_cases():
+    """Regions too short to cut, one-column segments, the weighted method with a height bound, and a work batch on the
+    wrong database."""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(100, 700, "HKY85", dg_k=4)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 8, 120)
+    mh = float(np.quantile(db.height, 0.8))
+    opts = E.default_opts(weighted=1, max_height=mh, max_nseed=12)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    cd, st, en = B.codes()
+    st = st.copy(); en = en.copy()
+    en[0] = st[0] + 2            # 3 columns: no segment with num_seg = 4, one-column segments with num_seg = 2
+    en[1] = st[1] + 3            # 4 columns: one-column segments with num_seg = 4
+    B.set_aligned(cd, st, en)
+    B.get_seed(opts)
+    cnt, ids, _, _ = B.seeds()
+    W = E.Batch(D, len(reads))
+    oo = O.default_opts(weighted=1, maxHeight=mh, maxNSeed=12)
+    for num_seg in (2, 4):
+        res = B.check_chimera(W, opts, num_seg=num_seg)
+        for i in range(len(reads)):
+            o = T.chimera(cd[i], int(st[i]), int(en[i]), oo, num_seg=num_seg, seeds=ids[i, :cnt[i]])
+            g = res[i]
+            assert bool(g["checked"]) == o["checked"], (num_seg, i)
+            if i == 0 and num_seg == 4:
+                assert not o["checked"] and g["seg5"]["c_node"] == -1 and np.isnan(g["lod"])
+                continue
+            assert (g["n_seg5"], g["n_seg3"]) == (o["n5"], o["n3"]) and g["lod"] == o["lod"] and not g["is_chimera"]
+            for side in ("seg5", "seg3"):
+                if int(g[side]["c_node"]) == o[side]["c"] and int(g[side + "_start"]) == o[side]["start"]:
+                    assert int(g[side]["a_node"]) == o[side]["a"]
+                    assert abs(g[side]["wnr"] - o[side]["wnr"]) <= REL * max(abs(o[side]["wnr"]), 1e-3)
+                else:   # near-tie swap of the segment's estimates (see test_chimera_check_parity)
+                    assert abs(g[side]["est_loglik"] - o[side]["est_loglik"]) <= 1e-6 * abs(o[side]["est_loglik"])
+    db2 = get_db(60, 700, "JC69", dg_k=0)
+    D2 = E.Database.from_synth(db2)
+    W2 = E.Batch(D2, len(reads))
+    with pytest.raises(E.EngineError):
+        B.check_chimera(W2, opts)
+    W3 = E.Batch(D, 2)
+    with pytest.raises(E.EngineError):
+        B.check_chimera(W3, opts)
+    with pytest.raises(E.EngineError):
+        B.check_chimera(B, opts)
+    W3.close(); W2.close(); D2.close(); W.close(); B.close(); D.close()
