@@ -524,7 +524,9 @@ struct hu_batch {
 	DBuf<HuVitOut> dVit;
 	DBuf<HuAlnDev> dAlns;
 	DBuf<int8_t> dCodes;
-	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven;
+	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven, dPermCnt;
+	DBuf<uint16_t> dPerm;
+	PinnedVec<int32_t> hPermCnt;
 	DBuf<uint32_t> dRp, dPairs, dSeedDN;
 	DBuf<int32_t> dTileQ;
 	DBuf<uint32_t> dRq;
@@ -575,7 +577,7 @@ extern "C" void hu_batch_destroy(hu_batch* b) {
 	(void) hipStreamSynchronize(b->stream);
 	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
 	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dGiven.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
+	b->dSeedDN.free_(); b->dGiven.free_(); b->dPermCnt.free_(); b->dPerm.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;
@@ -1019,6 +1021,11 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());
+	if(n) { /* gap / base site counts per read for the split placement kernel (read back in the filter stage) */
+		if((rc = b->dPermCnt.ensure(n * 2)) != HU_OK) return rc;
+		k_site_count<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPermCnt.p);
+		HIPCHK(hipGetLastError());
+	}
 	b->state = ST_ESTIMATED;
 	return HU_OK;
 }
@@ -1034,11 +1041,13 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 	const hu_db* db = b->db;
 	const size_t n = (size_t) b->n;
 	b->hSeedCnt.resize(n); b->hSeedId.resize(n * HU_MAX_SEEDS); b->hSeedDN.resize(n * HU_MAX_SEEDS); b->hEst.resize(n * HU_MAX_SEEDS);
+	b->hPermCnt.resize(n * 2);
 	if(n) {
 		HIPCHK(hipMemcpyAsync(b->hSeedCnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(b->hSeedId.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(b->hSeedDN.data(), b->dSeedDN.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(b->hEst.data(), b->dEst.p, n * HU_MAX_SEEDS * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipMemcpyAsync(b->hPermCnt.data(), b->dPermCnt.p, n * 8, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
 	}
 	b->candOffs.assign(n + 1, 0);
@@ -1146,9 +1155,25 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
 			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
 			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
-			else if(spt2 <= 8) PL_GO(8, 2, 3, 0, 2);
+			else if(spt2 <= 12 && !(var == 7)) {
+				/* 8 or 12 sites per thread.  When every read of the batch fits, its gap sites and its base sites go to separate
+				 * slots (k_place_blk GS: 6 + 2 slots = up to 768 gap and 256 base sites, 10 + 2 = 1,280 and 256): the gap slots
+				 * need no per-site table.  The counts come from k_site_count (estimate stage, read back by the filter stage). */
+				const int S = spt2 <= 8 ? 8 : 12, G = S - 2;
+				bool split = !getenv("HU_PLACE_NOSPLIT") && b->hPermCnt.size() == (size_t) b->n * 2;
+				for(int r = 0; r < b->n && split; ++r)
+					if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > G * 128 || b->hPermCnt[2 * r + 1] > (S - G) * 128)) split = false;
+				if(getenv("HU_TRACE")) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order");
+				if(split) {
+					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
+					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
+					if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p);
+					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p);
+				}
+				else if(S == 8) PL_GO(8, 2, 3, 0, 2);
+				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order);
+			}
 			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
-			else if(spt2 <= 12) k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order);
 			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
 			else PL_GO(12, 4, 3, 0, 1);
 			#undef PL_GO

@@ -446,10 +446,49 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
  * VL = 1: the third component of the normalised v message lives in LDS (SPT x THREADS doubles) instead of
  * registers: 2 x 12 sites x 7 doubles do not fit 256 VGPRs beside the temporaries, and the spills were reloaded
  * inside the serial table phases */
-template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 0>
+/* site list of every read for the split placement kernel: offsets (from the region's first column) of its gap sites in
+ * [0, gapCap), of its base sites in [gapCap, gapCap + baseCap), and the two counts.  One wave per read.  The caps are chosen
+ * by the host from the counts of k_site_count, so nothing is clipped. */
+__global__ __launch_bounds__(64) void k_site_count(HuDbDev db, int n, const int8_t* __restrict__ codes, const int32_t* __restrict__ rstart,
+		const int32_t* __restrict__ rend, int32_t* __restrict__ cnt) {
+	const int read = blockIdx.x, lane = threadIdx.x;
+	const int start = rstart[read], len = rend[read] - start + 1;
+	int g = 0, bc = 0;
+	for(int j0 = 0; j0 < len; j0 += 64) {
+		const int j = j0 + lane;
+		const bool val = j < len;
+		const int b = val ? codes[(size_t) read * db.csLen + start + j] : 0;
+		g += __popcll(__ballot(val && b < 0)); bc += __popcll(__ballot(val && b >= 0));
+	}
+	if(lane == 0) { cnt[2 * read] = g; cnt[2 * read + 1] = bc; }
+}
+__global__ __launch_bounds__(64) void k_site_perm(HuDbDev db, int n, const int8_t* __restrict__ codes, const int32_t* __restrict__ rstart,
+		const int32_t* __restrict__ rend, int gapCap, int baseCap, uint16_t* __restrict__ perm) {
+	const int read = blockIdx.x, lane = threadIdx.x;
+	const int start = rstart[read], len = rend[read] - start + 1;
+	uint16_t* __restrict__ pr = perm + (size_t) read * (gapCap + baseCap);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	int g = 0, bc = 0;
+	for(int j0 = 0; j0 < len; j0 += 64) {
+		const int j = j0 + lane;
+		const bool val = j < len;
+		const int b = val ? codes[(size_t) read * db.csLen + start + j] : 0;
+		const unsigned long long mg = __ballot(val && b < 0), mb = __ballot(val && b >= 0);
+		if(val && b < 0) { const int at = g + __popcll(mg & lt); if(at < gapCap) pr[at] = (uint16_t) j; }
+		if(val && b >= 0) { const int at = bc + __popcll(mb & lt); if(at < baseCap) pr[gapCap + at] = (uint16_t) j; }
+		g += __popcll(mg); bc += __popcll(mb);
+	}
+}
+
+/* GS > 0: the sites of a read are taken in the order of its site list (k_site_perm): gap sites in slots 0 .. GS-1, base sites
+ * in slots GS .. SPT-1.  The sweeps over the gap slots are straight-line code on ONE table held in registers (every lane
+ * would read the same 160 bytes per site and sweep from LDS: the sweeps are bound by the LDS return path, and 82 % of a
+ * region's sites are gaps); only the base slots read their per-site table. */
+template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 0, int GS = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr, const uint32_t* __restrict__ order = nullptr) {
+		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr, const uint32_t* __restrict__ order = nullptr,
+		const uint16_t* __restrict__ perm = nullptr, const int32_t* __restrict__ permCnt = nullptr) {
 	constexpr int THREADS = 64 * NW;
 	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
 	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
@@ -476,12 +515,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	const int64_t mOff = ((int64_t) un * db.winLen + (start - db.winStart)) * 4;
 	const double* __restrict__ Ub = db.up + mOff;
 	const double* __restrict__ Vb = db.down + mOff;
+	const int nGap = GS > 0 ? permCnt[2 * read] : 0, nBase = GS > 0 ? permCnt[2 * read + 1] : 0;
 	double u[SPT][3], v[SPT][3]; unsigned long long bop = 0, bop2 = 0;   /* base / gap code of slot t: 3 bits, slots 21.. in bop2 */
 	{
 		double aU[SPT][4], aV[SPT][4];
 #pragma unroll
 		for(int t = 0; t < SPT; ++t) {
-			const int j = tid + THREADS * t, jj = j < n ? j : 0;
+			int jj;
+			if(GS > 0) { /* slot t of the site list: [0, GS x THREADS) gap sites, then the base sites */
+				const int i = t < GS ? tid + THREADS * t : tid + THREADS * (t - GS);
+				const bool val = i < (t < GS ? nGap : nBase);
+				jj = val ? (int) perm[(size_t) read * (SPT * THREADS) + (t < GS ? 0 : GS * THREADS) + i] : 0;
+			}
+			else { const int j = tid + THREADS * t; jj = j < n ? j : 0; }
 			load4(Ub + (size_t) jj * 4, aU[t]); load4(Vb + (size_t) jj * 4, aV[t]);
 			const int b = cdr[jj];
 			if(t < 21) bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
@@ -537,9 +583,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			unsigned long long bq = bop, bq2 = bop2;
 			asm volatile("" : "+v"(bq), "+v"(bq2));  /* the per-site table addresses are recomputed per sweep, not kept live */
 			const double g0 = tabD[0], g1 = tabD[1], g2 = tabD[2], g3 = tabD[3];
+			double Mg[GS > 0 ? 16 : 1];
+			if(GS > 0) {
+#pragma unroll
+				for(int e = 0; e < 16; ++e) Mg[e] = tabM[4 * HU_TP + e];
+			}
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
-				const double* M = tabM + (unsigned)(((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21)))) & 7u) * HU_TP;
+				const double* M = (GS > 0 && t < GS) ? Mg : tabM + (unsigned)(((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21)))) & 7u) * HU_TP;
 				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
 				const double v2 = VL == 3 ? vdyn[(2 * SPT + t) * THREADS + tid] : VL == 1 ? vl[t * THREADS + tid] : v[t][2];
 				double num = fma(M[3], v2, fma(M[2], v1, fma(M[1], v0, M[0])));
@@ -550,7 +601,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 				}
 				const double den = fma(g3 * u[t][2], v2, fma(g2 * u[t][1], v1, fma(g1 * u[t][0], v0, g0)));
 				const double r = fast_div(num, den);
-				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
+				const bool inr = GS > 0 ? (t < GS ? tid + THREADS * t < nGap : tid + THREADS * (t - GS) < nBase) : tid + THREADS * t < n;
+				const bool ok = inr && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
 				rho[t] = ok ? r : HU_RHO_SKIP;
 				nv += __popcll(__ballot(ok));
 			}
@@ -588,11 +640,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 		{
 			unsigned long long bq = bop, bq2 = bop2;
 			asm volatile("" : "+v"(bq), "+v"(bq2));
+			double Mg[GS > 0 ? 16 : 1], Dg[GS > 0 ? 4 : 1];
+			if(GS > 0) {
+#pragma unroll
+				for(int e = 0; e < 16; ++e) Mg[e] = tabM[4 * HU_TP + e];
+#pragma unroll
+				for(int e = 0; e < 4; ++e) Dg[e] = tabD[4 * 4 + e];
+			}
 #pragma unroll
 			for(int t = 0; t < SPT; ++t) {
 				const unsigned bi = (unsigned)((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21))) & 7u);
-				const double* M = tabM + bi * HU_TP;
-				const double* D = tabD + bi * 4;
+				const double* M = (GS > 0 && t < GS) ? Mg : tabM + bi * HU_TP;
+				const double* D = (GS > 0 && t < GS) ? Dg : tabD + bi * 4;
 				const double v0 = VL == 3 ? vdyn[(0 * SPT + t) * THREADS + tid] : v[t][0], v1 = VL == 3 ? vdyn[(1 * SPT + t) * THREADS + tid] : v[t][1];
 				const double v2 = VL == 3 ? vdyn[(2 * SPT + t) * THREADS + tid] : VL == 1 ? vl[t * THREADS + tid] : v[t][2];
 				double A = fma(M[3], u[t][2], fma(M[2], u[t][1], fma(M[1], u[t][0], M[0])));
@@ -603,7 +662,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 				}
 				const double piX = fma(D[3], v2, fma(D[2], v1, fma(D[1], v0, D[0])));
 				const double r = fast_div(A, piX);
-				const bool ok = tid + THREADS * t < n && fabs(r) < HU_RHO_SKIP;
+				const bool inr = GS > 0 ? (t < GS ? tid + THREADS * t < nGap : tid + THREADS * (t - GS) < nBase) : tid + THREADS * t < n;
+				const bool ok = inr && fabs(r) < HU_RHO_SKIP;
 				rho[t] = ok ? r : HU_RHO_SKIP;
 				nv += __popcll(__ballot(ok));
 			}

@@ -807,3 +807,47 @@ def test_chimera_check_edge_cases():
     with pytest.raises(E.EngineError):
         B.check_chimera(B, opts)
     W3.close(); W2.close(); D2.close(); W.close(); B.close(); D.close()
+
+
+@pytest.mark.parametrize("read_len,lo,hi,gap_cap", [(220, 1024, 1536, 1280), (150, 512, 1024, 768)])
+def test_split_gap_base_placement_kernel(monkeypatch, capfd, read_len, lo, hi, gap_cap):
+    """Regions of 513 .. 1,536 columns with <= 256 bases (the 150 / 250 bp benchmark shapes) take the placement kernel that
+    walks a read's gap sites and base sites in separate slots (k_site_count / k_site_perm + k_place_blk GS = 6 / 10): against
+    the oracle, and against the kernel that takes the sites in column order (HU_PLACE_NOSPLIT)."""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(60, 2000, "GTR", dg_k=4, seed=5)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 10, read_len)
+    opts = E.default_opts(max_nseed=16)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts)
+    cd, st, en = B.codes()
+    span = en - st + 1
+    nb = np.array([(cd[i, st[i]:en[i] + 1] >= 0).sum() for i in range(len(reads))])
+    assert (span.max() > lo) and (span <= hi).all() and (nb <= 256).all() and (span - nb <= gap_cap).all(), (span, nb)
+    monkeypatch.setenv("HU_TRACE", "1")
+    B.place_seq(opts); B.calc_q_values(opts)
+    split = B.candidates(); best = B.placements()
+    monkeypatch.setenv("HU_PLACE_NOSPLIT", "1")
+    B.place_seq(opts); B.calc_q_values(opts)
+    plain = B.candidates()
+    monkeypatch.delenv("HU_PLACE_NOSPLIT"); monkeypatch.delenv("HU_TRACE")
+    err = capfd.readouterr().err
+    assert "gap/base split slots" in err and "column order" in err, err      # both kernels ran
+    assert np.array_equal(split["c_node"], plain["c_node"]) and np.array_equal(split["iters"], plain["iters"])
+    assert np.abs(split["ratio"] - plain["ratio"]).max() < 1e-8 and np.abs(split["wnr"] - plain["wnr"]).max() < 1e-8
+    oo = O.default_opts(maxNSeed=16)
+    worst = 0.0
+    for i in range(len(reads)):
+        res = T.assign(cd[i], int(st[i]), int(en[i]), oo)
+        lo, hi = split["offs"][i], split["offs"][i + 1]
+        assert hi - lo == res["n"]
+        oc = {int(n_[0]): (v[0], v[1], int(n_[3])) for n_, v in zip(res["nodes"], res["vals"])}
+        for c in range(lo, hi):
+            r0, w0_, it = oc[int(split["c_node"][c])]
+            worst = max(worst, abs(split["ratio"][c] - r0) / max(abs(r0), 1e-3), abs(split["wnr"][c] - w0_) / max(abs(w0_), 1e-3))
+            assert (int(split["iters"][c]) & 0xff) == it, (i, c)
+        assert best[i]["n_cand"] == res["n"]
+    assert worst < REL, worst
+    B.close(); D.close()
