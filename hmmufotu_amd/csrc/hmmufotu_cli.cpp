@@ -3,7 +3,7 @@
 // FASTA/FASTQ reading, the seed scans (hu_seed_index_*), strand auto-detection (:500-542), batching, TSV.
 // -C/--chimera* run the segment check of src/hmmufotu.cpp:653-691 in a second batch (hu_chimera_batch).
 // -a writes the aligned reads as FASTA (60 columns, description + ";csStart=..;csEnd=..;", :709-715); --align-only stops
-// after the alignment.  Not implemented: gz/bz2 inputs and outputs.
+// after the alignment.  Inputs may be gzip-compressed, outputs are when their name ends in .gz (zlib; no bz2).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,24 +12,59 @@
 #include <iostream>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <zlib.h>
 #include "../../include/hmmufotu_amd.h"
 
 struct Read { std::string id, desc, seq; };
 
-static bool next_read(std::istream& in, bool fastq, Read& r) {
+/* line reader over zlib: plain and gzip-compressed inputs alike (the reference reads .gz / .bz2 through boost::iostreams) */
+struct LineIn {
+	gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+	bool open(const std::string& fn) { f = gzopen(fn.c_str(), "rb"); if(f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr; }
+	~LineIn() { if(f) gzclose(f); }
+	bool fill() { if(eof) return false; const int k = gzread(f, buf.data(), (unsigned) buf.size()); pos = 0; len = k > 0 ? (size_t) k : 0; if(k <= 0) eof = true; return k > 0; }
+	int peek() { if(pos >= len && !fill()) return EOF; return (unsigned char) buf[pos]; }
+	bool getline(std::string& s) {
+		s.clear();
+		if(pos >= len && !fill()) return false;
+		for(;;) {
+			const char* b = buf.data() + pos; const char* e = (const char*) memchr(b, '\n', len - pos);
+			if(e) { s.append(b, e - b); pos += (size_t)(e - b) + 1; return true; }
+			s.append(b, len - pos); pos = len;
+			if(!fill()) return true;
+		}
+	}
+};
+/* writer: gzip when the file name ends in .gz */
+struct LineOut {
+	gzFile z = nullptr; std::ofstream f; bool on = false;
+	bool open(const std::string& fn) {
+		on = true;
+		if(fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) { z = gzopen(fn.c_str(), "wb"); return z != nullptr; }
+		f.open(fn); return (bool) f;
+	}
+	void write(const char* p, size_t n) { if(z) { while(n) { const unsigned k = (unsigned) std::min<size_t>(n, 1u << 30); gzwrite(z, p, k); p += k; n -= k; } } else f.write(p, (std::streamsize) n); }
+	void write(const std::string& s) { write(s.data(), s.size()); }
+	~LineOut() { if(z) gzclose(z); }
+};
+
+static bool next_read(LineIn& in, bool fastq, Read& r) {
 	std::string line;
 	r = Read();
+	bool got = false;
 	if(fastq) {
-		while(std::getline(in, line)) if(!line.empty() && line[0] == '@') break;
-		if(!in || line.empty() || line[0] != '@') return false;
+		while((got = in.getline(line))) if(!line.empty() && line[0] == '@') break;
+		if(!got || line.empty() || line[0] != '@') return false;
 		std::string q, plus;
-		if(!std::getline(in, r.seq) || !std::getline(in, plus) || !std::getline(in, q)) return false;
+		if(!in.getline(r.seq) || !in.getline(plus) || !in.getline(q)) return false;
 	}
 	else {
-		while(std::getline(in, line)) if(!line.empty() && line[0] == '>') break;
-		if(!in || line.empty() || line[0] != '>') return false;
-		while(in.peek() != EOF && in.peek() != '>') { std::string s; std::getline(in, s); while(!s.empty() && (s.back() == '\r' || s.back() == ' ')) s.pop_back(); r.seq += s; }
+		while((got = in.getline(line))) if(!line.empty() && line[0] == '>') break;
+		if(!got || line.empty() || line[0] != '>') return false;
+		while(in.peek() != EOF && in.peek() != '>') { std::string s; in.getline(s); while(!s.empty() && (s.back() == '\r' || s.back() == ' ')) s.pop_back(); r.seq += s; }
 	}
+	while(!line.empty() && line.back() == '\r') line.pop_back();
 	const size_t sp = line.find_first_of(" \t");
 	r.id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
 	if(sp != std::string::npos) r.desc = line.substr(sp + 1);
@@ -124,7 +159,11 @@ int main(int argc, char** argv) {
 	const bool paired = pos.size() == 3;
 	o.align_mode = (paired || !single) ? HU_MODE_GLOBAL : HU_MODE_NGCL;               /* src/hmmufotu.cpp:358 */
 	std::string fwdFn = pos[1], revFn = paired ? pos[2] : "";
-	auto is_fastq = [&](const std::string& fn) { if(!fmt.empty()) return fmt == "fastq"; return fn.size() > 2 && (fn.rfind(".fastq") == fn.size() - 6 || fn.rfind(".fq") == fn.size() - 3); };
+	auto is_fastq = [&](std::string fn) {
+		if(!fmt.empty()) return fmt == "fastq";
+		if(fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) fn.resize(fn.size() - 3);
+		return (fn.size() > 6 && fn.compare(fn.size() - 6, 6, ".fastq") == 0) || (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".fq") == 0);
+	};
 
 	hu_db* db = nullptr;
 	CHK(hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), gpu, &db));
@@ -143,8 +182,8 @@ int main(int argc, char** argv) {
 
 	/* strand auto-detection on the first nTest reads by alignment cost (src/hmmufotu.cpp:500-542) */
 	if(strand == 0) {
-		std::ifstream tin(fwdFn);
-		if(!tin) { std::cerr << "Unable to test forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
+		LineIn tin;
+		if(!tin.open(fwdFn)) { std::cerr << "Unable to test forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
 		Packed f, r; Read rd;
 		for(int i = 0; i < nTest && i < batch && next_read(tin, is_fastq(fwdFn), rd); ++i) { f.add(rd.seq); r.add(revcom(rd.seq)); }
 		double fwdScore = 0, revScore = 0;
@@ -168,21 +207,21 @@ int main(int argc, char** argv) {
 		if(verbose) std::cerr << "Read strand determined as " << strand << std::endl;
 	}
 	if(strand == 2 && paired) std::swap(fwdFn, revFn);
-	std::ifstream fin(fwdFn), rin;
-	if(!fin) { std::cerr << "Unable to open forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
-	if(paired) { rin.open(revFn); if(!rin) { std::cerr << "Unable to open reverse seq file '" << revFn << "'" << std::endl; return EXIT_FAILURE; } }
-	std::ofstream fout; if(!outFn.empty()) { fout.open(outFn); if(!fout) { std::cerr << "Unable to write to '" << outFn << "'" << std::endl; return EXIT_FAILURE; } }
-	std::ostream& out = outFn.empty() ? std::cout : fout;
+	LineIn fin, rin;
+	if(!fin.open(fwdFn)) { std::cerr << "Unable to open forward seq file '" << fwdFn << "'" << std::endl; return EXIT_FAILURE; }
+	if(paired) { if(!rin.open(revFn)) { std::cerr << "Unable to open reverse seq file '" << revFn << "'" << std::endl; return EXIT_FAILURE; } }
+	LineOut fout; if(!outFn.empty() && !fout.open(outFn)) { std::cerr << "Unable to write to '" << outFn << "'" << std::endl; return EXIT_FAILURE; }
+	auto out = [&](const std::string& t) { if(fout.on) fout.write(t); else std::cout.write(t.data(), (std::streamsize) t.size()); };
 	const char* header = chimeraInfo ? hu_tsv_header_chimera() : hu_tsv_header();
-	out << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << header << "\n";
-	std::ofstream chiOut;
+	const std::string preamble = std::string("# hmmufotu_amd v0.1.0 taxonomy assignment generated by ") + argv[0] + "\n# command: " + cmd + "\n" + header + "\n";
+	out(preamble);
+	LineOut chiOut;
 	if(!chiOutFn.empty()) {
-		chiOut.open(chiOutFn);
-		if(!chiOut) { std::cerr << "Unable to write to '" << chiOutFn << "'" << std::endl; return EXIT_FAILURE; }
-		chiOut << "# hmmufotu_amd v0.1.0 taxonomy assignment generated by " << argv[0] << "\n# command: " << cmd << "\n" << header << "\n";
+		if(!chiOut.open(chiOutFn)) { std::cerr << "Unable to write to '" << chiOutFn << "'" << std::endl; return EXIT_FAILURE; }
+		chiOut.write(preamble);
 	}
-	std::ofstream alnOut;
-	if(!alnFn.empty()) { alnOut.open(alnFn); if(!alnOut) { std::cerr << "Unable to write to align file '" << alnFn << "'" << std::endl; return EXIT_FAILURE; } }
+	LineOut alnOut;
+	if(!alnFn.empty() && !alnOut.open(alnFn)) { std::cerr << "Unable to write to align file '" << alnFn << "'" << std::endl; return EXIT_FAILURE; }
 	std::vector<hu_chimera_rec> chi;
 	std::vector<hu_align_rec> alnRecs; std::vector<char> alnRows;
 	long flagged = 0;
@@ -217,23 +256,23 @@ int main(int argc, char** argv) {
 		if(need < 0) return (int) need;
 		std::string buf((size_t) need, '\0');
 		hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, &buf[0], need);
-		out << buf;
-		if(alnOut.is_open()) { /* aligned reads that are not chimeras (src/hmmufotu.cpp:709-715; SeqIO::writeFastaSeq, 60 columns) */
+		out(buf);
+		if(alnOut.on) { /* aligned reads that are not chimeras (src/hmmufotu.cpp:709-715; SeqIO::writeFastaSeq, 60 columns) */
 			alnRecs.resize((size_t) n); alnRows.resize((size_t) n * L);
 			if((rc = hu_batch_get_alignments(gb, alnRecs.data(), alnRows.data(), nullptr, 0)) != HU_OK) return rc;
 			for(int i = 0; i < n; ++i) {
 				if(alnRecs[i].status != HU_READ_OK || (cp && cp[i].is_chimera)) continue;
 				const std::string d = descs[i] + ";csStart=" + std::to_string(alnRecs[i].cs_start) + ";csEnd=" + std::to_string(alnRecs[i].cs_end) + ";";
-				alnOut << '>' << ids[i] << ' ' << d << '\n';
-				for(int c = 0; c < L; c += 60) { alnOut.write(&alnRows[(size_t) i * L + c], std::min(60, L - c)); alnOut.put('\n'); }
+				alnOut.write(">" + ids[i] + " " + d + "\n");
+				for(int c = 0; c < L; c += 60) { alnOut.write(&alnRows[(size_t) i * L + c], (size_t) std::min(60, L - c)); alnOut.write("\n", 1); }
 			}
 		}
-		if(chiOut.is_open()) {
+		if(chiOut.on) {
 			const int64_t cneed = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, nullptr, 0);
 			if(cneed < 0) return (int) cneed;
 			std::string cbuf((size_t) cneed, '\0');
 			hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, &cbuf[0], cneed);
-			chiOut << cbuf;
+			chiOut.write(cbuf);
 		}
 		for(char c : buf) if(c == '\n') placed++;
 		total += n;

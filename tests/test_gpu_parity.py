@@ -474,6 +474,15 @@ def test_cli_end_to_end(tmp_path):
     out2 = subprocess.run([cli, pre, fq, "-t", "10"], capture_output=True, text=True, timeout=300)
     assert out2.returncode == 0, out2.stderr
     assert [l for l in out2.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
+    import gzip
+    fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")
+    with open(fq, "rb") as fi, gzip.open(fqz, "wb") as fo:
+        fo.write(fi.read())
+    outg = subprocess.run([cli, pre, fqz, "-s", "1", "-o", outz], capture_output=True, text=True, timeout=300)
+    assert outg.returncode == 0 and outg.stdout == "", outg.stderr
+    with gzip.open(outz, "rt") as f:
+        assert [l for l in f.read().split("\n") if l and not l.startswith("#")][1:] == want
     # reverse-complemented input is recognised (strand 2) and assigned identically
     rc = str(tmp_path / "rc.fasta")
     with open(rc, "w") as f:
