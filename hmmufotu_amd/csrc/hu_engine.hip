@@ -511,6 +511,7 @@ struct hu_batch {
 	hu_db* db = nullptr;
 	int maxReads = 0, n = 0, nSeq = 0, state = ST_NONE;
 	bool paired = false, fromCodes = false, profile = false;
+	int seedCap = HU_MAX_SEEDS;   /* most seeds any read of the batch can have (seed stage) */
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[2 * HU_T_COUNT];
 	bool evSet[HU_T_COUNT] = {false};
@@ -907,6 +908,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		}
 		HIPCHK(hipGetLastError());
 	}
+	b->seedCap = o->max_nseed;
 	b->state = ST_SEEDED;
 	return HU_OK;
 }
@@ -959,6 +961,8 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
 	}
+	b->seedCap = 1;
+	for(size_t r = 0; r < n; ++r) b->seedCap = std::max(b->seedCap, (int) n_seeds[r]);
 	b->state = ST_SEEDED;
 	return HU_OK;
 }
@@ -1001,6 +1005,11 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
 		 * streaming 12.3 ms with twice the HBM traffic. */
 		const int spt = (maxR + 255) / 256;
+		/* sorted launch: the valid slots come first and number at most n x (seeds per read), so only that many workgroups
+		 * start; and XCD x (workgroups b = x mod 8) walks the contiguous eighth x of the sorted list, so that the reads sharing
+		 * a seed node share an L2 (5.13 -> 4.55 ms; without the trim the empty slots all fall to one XCD: 5.48 ms) */
+		const int xm = getenv("HU_XCD_MAP") ? atoi(getenv("HU_XCD_MAP")) : 1;
+		const unsigned egl = order ? std::min<unsigned>(eg, (unsigned) b->n * (unsigned) b->seedCap) : eg;
 		const char* ev = getenv("HU_EST_VAR");
 		const int var = ev ? atoi(ev) : 0;
 		if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
@@ -1011,13 +1020,13 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 			else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
 			else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
 		}
-		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<eg, 128, 0, b->stream>>>(EST_ARGS, order);
-		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
-		else if(spt <= 2) k_estimate_prod<2, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
-		else if(spt <= 4) k_estimate_prod<4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
-		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
-		else if(spt <= 8) k_estimate_prod<8, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
-		else k_estimate_prod<12, 4><<<eg, 256, 0, b->stream>>>(EST_ARGS, order);
+		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<egl, 128, 0, b->stream>>>(EST_ARGS, order, xm);
+		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+		else if(spt <= 2) k_estimate_prod<2, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+		else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
+		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+		else k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());
@@ -1126,6 +1135,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			Timer t(b, HU_T_PLACE);
 			const char* ev = getenv("HU_PLACE_VAR");
 			const int var = ev ? atoi(ev) : 0;
+			const int xm = getenv("HU_XCD_MAP") ? atoi(getenv("HU_XCD_MAP")) : 1;   /* an eighth of the node-sorted list per XCD, as in the estimate stage */
 			const uint32_t* order = nullptr;
 			if(!getenv("HU_PLACE_UNSORTED")) { /* launch order: by candidate node */
 				if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
@@ -1136,7 +1146,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 				HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
 				order = b->dSortV.p + nc;
 			}
-			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order)
+			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
 			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				long long* dd = nullptr;
 				HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
@@ -1167,11 +1177,11 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 				if(split) {
 					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
 					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
-					if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p);
-					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p);
+					if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 				}
 				else if(S == 8) PL_GO(8, 2, 3, 0, 2);
-				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order);
+				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
 			}
 			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
 			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);

@@ -168,18 +168,27 @@ __device__ inline int wave_sum_i32(int v) {
 	return v;
 }
 
+/* Position in the node-sorted list for workgroup b: blocks are dealt round-robin over the 8 XCDs (observed, not promised),
+ * so b % 8 names the XCD and XCD x walks the CONTIGUOUS eighth x of the list: workgroups that want the same node's
+ * messages share one L2 instead of meeting in the Infinity Cache.  xmap = 0: position b. */
+__device__ inline uint32_t hu_xcd_pos(uint32_t b, uint32_t nb, int xmap) {
+	if(!xmap) return b;
+	const uint32_t per = nb >> 3;
+	return b < per * 8 ? (b & 7u) * per + (b >> 3) : b;
+}
+
 template<int SPT, int NW, int OCC = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
-		int weighted, HuEstOut* __restrict__ out, const uint32_t* __restrict__ order) {
+		int weighted, HuEstOut* __restrict__ out, const uint32_t* __restrict__ order, int xmap = 0) {
 	constexpr int THREADS = 64 * NW;
 	__shared__ double redd[2 * NW];
 	__shared__ int redi[2 * NW];
 	__shared__ __attribute__((aligned(16))) double Qtab[NW][24];   /* [wave][0..3] = exp(lam_m wnr), [4 + b * 4 + i] = Q^b_i */
 	/* `order`: the (read, seed) slots sorted by seed NODE, so that the workgroups reading one node's messages run
 	 * together and all but the first find them in the Infinity Cache / L2 (reads of one sample share their seeds) */
-	const uint32_t slot = order ? order[blockIdx.x] : blockIdx.x;
+	const uint32_t slot = order ? order[hu_xcd_pos(blockIdx.x, gridDim.x, xmap)] : blockIdx.x;
 	const int read = slot / HU_MAX_SEEDS, s = slot % HU_MAX_SEEDS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if(s >= seedCnt[read]) return;
 	const int un = seedId[(size_t) read * HU_MAX_SEEDS + s];
@@ -488,7 +497,7 @@ template<int SPT, int NW, int EMV, int RED, int OCC, bool DBG = false, int VL = 
 __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
 		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, long long* __restrict__ dbg = nullptr, const uint32_t* __restrict__ order = nullptr,
-		const uint16_t* __restrict__ perm = nullptr, const int32_t* __restrict__ permCnt = nullptr) {
+		const uint16_t* __restrict__ perm = nullptr, const int32_t* __restrict__ permCnt = nullptr, int xmap = 0) {
 	constexpr int THREADS = 64 * NW;
 	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
 	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	/* the serial table work of a workgroup runs in one or two of its waves: rotate which by workgroup so that
 	 * the workgroups sharing a CU load different SIMDs with it */
 	const int vt = (tid + 64 * (blockIdx.x % NW)) % THREADS;
-	const uint32_t ci = order ? order[blockIdx.x] : blockIdx.x;     /* candidates in node order: see k_estimate_prod */
+	const uint32_t ci = order ? order[hu_xcd_pos(blockIdx.x, gridDim.x, xmap)] : blockIdx.x;     /* candidates in node order, an eighth of the list per XCD: see k_estimate_prod */
 	const HuCand cd = cands[ci];
 	const int read = cd.read, un = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
