@@ -13,6 +13,10 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <zlib.h>
 #include "../../include/hmmufotu_amd.h"
 
@@ -94,6 +98,10 @@ static void usage(const char* p) {
 struct Packed { std::string bases; std::vector<int64_t> offs{0}; std::vector<int32_t> vp;
 	void add(const std::string& s) { bases += s; offs.push_back((int64_t) bases.size()); }
 	void clear() { bases.clear(); offs.assign(1, 0); vp.clear(); } int n() const { return (int) offs.size() - 1; } };
+
+/* one batch of parsed reads on the host.  The main thread parses and runs the seed lookups of batch k + 1 while the
+ * worker thread drives batch k through the engine and writes its lines (output stays in read order) */
+struct Slot { Packed f, r; std::vector<std::string> ids, descs; };
 
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
@@ -228,15 +236,11 @@ int main(int argc, char** argv) {
 
 	std::vector<const char*> annos(nNodes);
 	for(int i = 0; i < nNodes; ++i) annos[i] = hu_db_get_annotation(db, i);
-	Packed f, r; std::vector<std::string> ids, descs;
 	long total = 0, placed = 0;
-	auto flush = [&]() -> int {
+	auto process = [&](Slot& sl) -> int { /* worker thread: engine + output of one batch */
+		Packed& f = sl.f; Packed& r = sl.r; std::vector<std::string>& ids = sl.ids; std::vector<std::string>& descs = sl.descs;
 		const int n = f.n();
-		if(n == 0) return HU_OK;
-		f.vp.assign((size_t) n * 12, 0);
 		int rc;
-		if((rc = hu_seed_index_lookup(ix, n, f.bases.data(), f.offs.data(), seedRegion, o.align_mode, f.vp.data())) != HU_OK) return rc;
-		if(paired) { r.vp.assign((size_t) n * 12, 0); if((rc = hu_seed_index_lookup(ix, n, r.bases.data(), r.offs.data(), seedRegion, o.align_mode, r.vp.data())) != HU_OK) return rc; }
 		if((rc = hu_batch_set_reads(gb, n, f.bases.data(), f.offs.data(), f.vp.data(), paired ? r.bases.data() : nullptr, paired ? r.offs.data() : nullptr,
 				paired ? r.vp.data() : nullptr)) != HU_OK) return rc;
 		if(checkChimera) { /* common seeds first, the check on them, then the ordinary estimate/filter/place (src/hmmufotu.cpp:643-733) */
@@ -276,18 +280,49 @@ int main(int argc, char** argv) {
 		}
 		for(char c : buf) if(c == '\n') placed++;
 		total += n;
-		f.clear(); r.clear(); ids.clear(); descs.clear();
 		return HU_OK;
 	};
+	std::mutex mu; std::condition_variable cv; std::unique_ptr<Slot> pending; bool finished = false; int werr = HU_OK; std::string wmsg;
+	std::thread worker([&] {
+		for(;;) {
+			std::unique_ptr<Slot> sl;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return pending || finished; }); if(!pending) return; sl = std::move(pending); }
+			cv.notify_all();
+			bool ok; { std::lock_guard<std::mutex> lk(mu); ok = werr == HU_OK; }
+			if(ok) { const int rc = process(*sl); if(rc != HU_OK) { std::lock_guard<std::mutex> lk(mu); werr = rc; wmsg = hu_last_error(); } }
+		}
+	});
+	struct Joiner { std::mutex& mu; std::condition_variable& cv; bool& fin; std::thread& t;
+		~Joiner() { { std::lock_guard<std::mutex> lk(mu); fin = true; } cv.notify_all(); if(t.joinable()) t.join(); } } joiner{mu, cv, finished, worker};
+	auto submit = [&](std::unique_ptr<Slot>& sl) -> int { /* main thread: seed lookups, then hand the batch to the worker */
+		const int n = sl->f.n();
+		if(n == 0) return HU_OK;
+		int rc;
+		sl->f.vp.assign((size_t) n * 12, 0);
+		if((rc = hu_seed_index_lookup(ix, n, sl->f.bases.data(), sl->f.offs.data(), seedRegion, o.align_mode, sl->f.vp.data())) != HU_OK) return rc;
+		if(paired) { sl->r.vp.assign((size_t) n * 12, 0); if((rc = hu_seed_index_lookup(ix, n, sl->r.bases.data(), sl->r.offs.data(), seedRegion, o.align_mode, sl->r.vp.data())) != HU_OK) return rc; }
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&] { return !pending; });
+		if(werr != HU_OK) { std::cerr << "Error: " << wmsg << std::endl; return werr; }
+		pending = std::move(sl);
+		lk.unlock(); cv.notify_all();
+		sl.reset(new Slot());
+		return HU_OK;
+	};
+	std::unique_ptr<Slot> cur(new Slot());
 	Read a, b;
 	while(next_read(fin, is_fastq(fwdFn), a) && (!paired || next_read(rin, is_fastq(revFn), b))) {
 		std::string s = a.seq;
 		if(strand == 2 && !paired) s = revcom(s);          /* wrong strand for single-strand reads (src/hmmufotu.cpp:617-618) */
-		f.add(s); ids.push_back(a.id); descs.push_back(a.desc);
-		if(paired) r.add(revcom(b.seq));                   /* mates are reverse-complemented at read time (:609) */
-		if(f.n() == batch) CHK(flush());
+		cur->f.add(s); cur->ids.push_back(a.id); cur->descs.push_back(a.desc);
+		if(paired) cur->r.add(revcom(b.seq));              /* mates are reverse-complemented at read time (:609) */
+		if(cur->f.n() == batch) { const int rc = submit(cur); if(rc != HU_OK) { if(rc != werr) std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } }
 	}
-	CHK(flush());
+	{ const int rc = submit(cur); if(rc != HU_OK) { if(rc != werr) std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } }
+	{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !pending; }); finished = true; }
+	cv.notify_all();
+	worker.join();
+	if(werr != HU_OK) { std::cerr << "Error: " << wmsg << std::endl; return EXIT_FAILURE; }
 	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << (checkChimera ? ", " + std::to_string(flagged) + " flagged as chimera" : std::string()) << std::endl;
 	if(wb) hu_batch_destroy(wb);
 	hu_batch_destroy(gb); hu_seed_index_destroy(ix); hu_db_destroy(db);

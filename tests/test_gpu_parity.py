@@ -474,6 +474,10 @@ def test_cli_end_to_end(tmp_path):
     out2 = subprocess.run([cli, pre, fq, "-t", "10"], capture_output=True, text=True, timeout=300)
     assert out2.returncode == 0, out2.stderr
     assert [l for l in out2.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # five batches through the reader / worker pipeline: same lines, same order
+    outb = subprocess.run([cli, pre, fa, "-s", "1", "--batch", "5"], capture_output=True, text=True, timeout=300)
+    assert outb.returncode == 0, outb.stderr
+    assert [l for l in outb.stdout.split("\n") if l and not l.startswith("#")][1:] == want
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
     import gzip
     fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")
