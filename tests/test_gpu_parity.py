@@ -819,6 +819,9 @@ def test_chimera_check_edge_cases():
         B.check_chimera(W3, opts)
     with pytest.raises(E.EngineError):
         B.check_chimera(B, opts)
+    B.set_reads([], np.zeros((0, 2, 6), np.int32))          # an empty batch passes through every stage
+    B.align(opts); B.get_seed(opts)
+    assert len(B.check_chimera(W, opts)) == 0
     W3.close(); W2.close(); D2.close(); W.close(); B.close(); D.close()
 
 
