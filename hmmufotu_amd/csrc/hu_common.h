@@ -7,7 +7,7 @@
 #include "../../include/hmmufotu_amd.h"
 
 #define HU_MAX_DGK 16
-#define HU_MAX_SEEDS 64          /* capacity of per-read seed lists (max_nseed <= 64)           */
+/* HU_MAX_SEEDS (64: capacity of the per-read seed lists) is part of the ABI: include/hmmufotu_amd.h */
 #define HU_READ_TILE 16          /* reads per workgroup tile in the seed p-distance scan        */
 #define HU_MAX_INS 24            /* bases of one read outside the profile columns handled as a list */
 #define HU_NODE_PAD 256          /* node count is padded to a multiple of this                  */

@@ -107,6 +107,26 @@ template<class T> struct PinnedAlloc {
 };
 template<class T> using PinnedVec = std::vector<T, PinnedAlloc<T>>;
 
+/* growable device buffer */
+template<class X> struct DBuf {
+	X* p = nullptr; size_t cap = 0;
+	int ensure(size_t n) {
+		if(n <= cap) return HU_OK;
+		if(p) (void) hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = n + n / 8 + 16;
+		hipError_t e = hipMalloc((void**) &p, want * sizeof(X));
+		if(e != hipSuccess) { hu_set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(X), hipGetErrorString(e)); return HU_ERR_NOMEM; }
+		cap = want;
+		return HU_OK;
+	}
+	void free_() { if(p) (void) hipFree(p); p = nullptr; cap = 0; }
+	DBuf() = default;
+	DBuf(const DBuf&) = delete;
+	DBuf& operator=(const DBuf&) = delete;
+	~DBuf() { free_(); }      /* temporaries on an early-return path and the members of a deleted hu_batch free themselves */
+};
+
 struct hu_db {
 	int device = 0;
 	HuDbDev dev;
@@ -407,14 +427,14 @@ __global__ void k_model_pr(HuModelDev mdl, int n, const double* __restrict__ t, 
 extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P) {
 	if(!db || n < 0) return HU_ERR_ARG;
 	HIPCHK(hipSetDevice(db->device));
-	double *dt, *dP;
-	HIPCHK(hipMalloc((void**) &dt, std::max(n, 1) * 8)); HIPCHK(hipMalloc((void**) &dP, std::max(n, 1) * 128));
-	HIPCHK(hipMemcpy(dt, t, n * 8, hipMemcpyHostToDevice));
+	DBuf<double> dt, dP;
+	int rc;
+	if((rc = dt.ensure((size_t) std::max(n, 1))) != HU_OK || (rc = dP.ensure((size_t) std::max(n, 1) * 16)) != HU_OK) return rc;
+	HIPCHK(hipMemcpy(dt.p, t, (size_t) n * 8, hipMemcpyHostToDevice));
 	(void) hipGetLastError();
-	if(n) k_model_pr<<<(n + 63) / 64, 64>>>(db->mdl, n, dt, dP);
+	if(n) k_model_pr<<<(n + 63) / 64, 64>>>(db->mdl, n, dt.p, dP.p);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpy(P, dP, (size_t) n * 128, hipMemcpyDeviceToHost));
-	(void) hipFree(dt); (void) hipFree(dP);
+	HIPCHK(hipMemcpy(P, dP.p, (size_t) n * 128, hipMemcpyDeviceToHost));
 	return HU_OK;
 }
 
@@ -484,20 +504,6 @@ extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent
 }
 
 /* ------------------------------------------------------------------------------ batch */
-template<class X> struct DBuf {
-	X* p = nullptr; size_t cap = 0;
-	int ensure(size_t n) {
-		if(n <= cap) return HU_OK;
-		if(p) (void) hipFree(p);
-		p = nullptr; cap = 0;
-		size_t want = n + n / 8 + 16;
-		hipError_t e = hipMalloc((void**) &p, want * sizeof(X));
-		if(e != hipSuccess) { hu_set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(X), hipGetErrorString(e)); return HU_ERR_NOMEM; }
-		cap = want;
-		return HU_OK;
-	}
-	void free_() { if(p) (void) hipFree(p); p = nullptr; cap = 0; }
-};
 
 struct HostPlace {
 	int32_t seedIdx, cNode, pNode, aNode, iters;
@@ -505,12 +511,55 @@ struct HostPlace {
 	double annoDist() const { return aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr; }
 };
 
+/* Kernel-selection and diagnostic knobs of a batch.  Defaults come from the environment ONCE, when the batch is created
+ * (HU_<NAME>, e.g. HU_XCD_MAP=0; a variable that is set but not a number counts as 1); hu_batch_set_knob changes one
+ * afterwards.  Nothing on the per-step path reads the environment. */
+struct HuKnobs {
+	int viterbi_hbm = 0;         /* HBM-staged value-filing Viterbi for every read                                   */
+	int viterbi_values = 0;      /* LDS wavefront that files (M, I, D) of every cell instead of decision bytes       */
+	int viterbi_mode = 0;        /* 1 generic workgroup decision-byte kernel, 2 row-per-thread workgroup kernel       */
+	int viterbi_dec1 = 0;        /* alias of viterbi_mode = 1                                                        */
+	int vw_diag = 0;             /* k_viterbi_wave diagnostics variant                                               */
+	int viterbi_force_redo = 0;  /* flag every traceback "needs values": the redo pass runs for all sequences        */
+	int pdist_v1 = 0;            /* the per-read insert loop scan kernel                                             */
+	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
+	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
+	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
+	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
+	int est_var = 0, place_var = 0;             /* alternative kernel variants (comparison / diagnostics)            */
+	int place_nosplit = 0;       /* column-order placement kernel even when the gap / base split applies             */
+	int place_pair = 1;          /* two candidates per workgroup with interleaved EM steps                           */
+	int topk_blocks = 1;         /* top-k reads only the 256-node blocks at / below the sampled threshold            */
+	int trace = 0;               /* one line per stage decision to stderr                                            */
+};
+struct HuKnobEntry { const char* name; int HuKnobs::* field; };
+static const HuKnobEntry kKnobs[] = {
+	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
+	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
+	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
+	{"place_pair", &HuKnobs::place_pair}, {"topk_blocks", &HuKnobs::topk_blocks}, {"trace", &HuKnobs::trace},
+};
+static void knobs_from_env(HuKnobs& k) {
+	for(const HuKnobEntry& e : kKnobs) {
+		std::string env = "HU_";
+		for(const char* c = e.name; *c; ++c) env += (char) toupper(*c);
+		const char* v = getenv(env.c_str());
+		if(!v) continue;
+		char* end = nullptr;
+		const long x = strtol(v, &end, 10);
+		k.*(e.field) = (end == v) ? 1 : (int) x;
+	}
+}
+
 enum { ST_NONE = 0, ST_READS = 1, ST_ALIGNED = 2, ST_SEEDED = 3, ST_ESTIMATED = 4, ST_FILTERED = 5, ST_PLACED = 6, ST_FINISHED = 7 };
 
 struct hu_batch {
 	hu_db* db = nullptr;
 	int maxReads = 0, n = 0, nSeq = 0, state = ST_NONE;
 	bool paired = false, fromCodes = false, profile = false;
+	HuKnobs knob;
 	int seedCap = HU_MAX_SEEDS;   /* most seeds any read of the batch can have (seed stage) */
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[2 * HU_T_COUNT];
@@ -542,6 +591,7 @@ struct hu_batch {
 	std::vector<char> hBases;
 	PinnedVec<HuVitOut> hVit;
 	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
+	int nFullRedo = 0;          /* sequences of the last align call whose banded DP found no path: full DP, one launch */
 	PinnedVec<HuAlnDev> hAlns;
 	PinnedVec<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
 	PinnedVec<uint32_t> hSeedDN;
@@ -566,22 +616,34 @@ extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) {
 	HIPCHK(hipSetDevice(db->device));
 	hu_batch* b = new hu_batch;
 	b->db = db; b->maxReads = max_reads;
-	HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-	for(int i = 0; i < 2 * HU_T_COUNT; ++i) HIPCHK(hipEventCreate(&b->ev[i]));
+	knobs_from_env(b->knob);
+	for(int i = 0; i < 2 * HU_T_COUNT; ++i) b->ev[i] = nullptr;
 	for(int i = 0; i < HU_T_COUNT; ++i) b->ms[i] = 0;
+	hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+	for(int i = 0; i < 2 * HU_T_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
+	if(e != hipSuccess) { /* nothing of a half-made batch stays behind */
+		hu_set_error("hu_batch_create: stream / event creation failed: %s", hipGetErrorString(e));
+		for(int i = 0; i < 2 * HU_T_COUNT; ++i) if(b->ev[i]) (void) hipEventDestroy(b->ev[i]);
+		if(b->stream) (void) hipStreamDestroy(b->stream);
+		delete b;
+		return HU_ERR_DEVICE;
+	}
 	*out = b;
 	return HU_OK;
+}
+extern "C" int hu_batch_set_knob(hu_batch* b, const char* name, int value) {
+	if(!b || !name) return HU_ERR_ARG;
+	for(const HuKnobEntry& e : kKnobs) if(strcmp(e.name, name) == 0) { b->knob.*(e.field) = value; return HU_OK; }
+	hu_set_error("hu_batch_set_knob: no knob named '%s'", name);
+	return HU_ERR_ARG;
 }
 extern "C" void hu_batch_destroy(hu_batch* b) {
 	if(!b) return;
 	(void) hipSetDevice(b->db->device);
 	(void) hipStreamSynchronize(b->stream);
-	b->dBases.free_(); b->dTraces.free_(); b->dRows.free_(); b->dDescs.free_(); b->dScratch.free_(); b->dDec.free_(); b->dVit.free_(); b->dAlns.free_();
-	b->dCodes.free_(); b->dStart.free_(); b->dEnd.free_(); b->dSeedCnt.free_(); b->dSeedId.free_(); b->dRp.free_(); b->dPairs.free_();
-	b->dSeedDN.free_(); b->dGiven.free_(); b->dPermCnt.free_(); b->dPerm.free_(); b->dTileQ.free_(); b->dRq.free_(); b->dIns.free_(); b->dTileIns.free_(); b->dSortK.free_(); b->dSortV.free_(); b->dSortTmp.free_(); b->dEst.free_(); b->dCands.free_(); b->dPlaceOut.free_();
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
-	delete b;
+	delete b;      /* the DBuf members free their device memory */
 }
 extern "C" int hu_batch_sync(hu_batch* b) { if(!b) return HU_ERR_ARG; HIPCHK(hipStreamSynchronize(b->stream)); return HU_OK; }
 extern "C" int hu_batch_profile(hu_batch* b, int enable) { if(!b) return HU_ERR_ARG; b->profile = enable != 0; return HU_OK; }
@@ -757,6 +819,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	if(b->state < ST_READS || b->fromCodes) { hu_set_error("hu_align_batch: no reads set"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
 	const HuDbDev& d = b->db->dev;
+	const HuKnobs& kb = b->knob;
 	double tNN, tNB, tEC, tCC;
 	hu_mode_costs(d.K, o->align_mode, &tNN, &tNB, &tEC, &tCC);
 	int rc;
@@ -774,22 +837,21 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 		const size_t vlds = (size_t) 9 * ldsRows * sizeof(double);
 		{
 			Timer t(b, HU_T_VITERBI);
-			if(vlds <= 96 * 1024 && !getenv("HU_VITERBI_HBM")) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
-				if(!getenv("HU_VITERBI_VALUES")) { /* one decision byte per cell; (M, I, D) only where a later phase looks */
+			if(vlds <= 96 * 1024 && !kb.viterbi_hbm) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
+				if(!kb.viterbi_values) { /* one decision byte per cell; (M, I, D) only where a later phase looks */
 					if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_dec, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
 					#define VD_ARGS d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows
 					int haloW = 2;
 					for(int s = 0; s < b->nSeq; ++s) for(int r = 0; r < b->hDescs[s].nRegions; ++r)
 						haloW = std::max(haloW, b->hDescs[s].reg[r].j1 - b->hDescs[s].reg[r].j0 + 3);
 					const size_t vlds2 = vlds + (size_t) 3 * haloW * sizeof(double) + 32 * (maxLen <= 256 ? 256 : 512);
-					const char* vm = getenv("HU_VITERBI_MODE");     /* test hook: 1 = generic workgroup kernel, 2 = row-per-thread workgroup kernel */
-					const int mode = vm ? atoi(vm) : (getenv("HU_VITERBI_DEC1") ? 1 : 0);
+					const int mode = kb.viterbi_mode ? kb.viterbi_mode : (kb.viterbi_dec1 ? 1 : 0);   /* 1 = generic workgroup kernel, 2 = row-per-thread workgroup kernel */
 					const int haloWw = std::min(haloW, 512);
 					if(mode == 0 && maxLen <= 512) { /* one wave per sequence, no barrier */
 						const size_t wl = (size_t) 3 * haloWw * sizeof(double);
-						const char* dgv = getenv("HU_VW_DIAG");
-						if(maxLen <= 256 && dgv && atoi(dgv) == 1) { k_viterbi_wave<4, 1><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
-						else if(maxLen <= 256 && dgv && atoi(dgv) == 2) { k_viterbi_wave<4, 2><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						const int dgv = kb.vw_diag;
+						if(maxLen <= 256 && dgv == 1) { k_viterbi_wave<4, 1><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
+						else if(maxLen <= 256 && dgv == 2) { k_viterbi_wave<4, 2><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
 						else if(maxLen <= 256) { k_viterbi_wave<4><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
 						else { k_viterbi_wave<8><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 8; }
 					}
@@ -803,7 +865,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 					}
 					else k_viterbi_dec<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(VD_ARGS);
 					#undef VD_ARGS
-					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, getenv("HU_VITERBI_FORCE_REDO") != nullptr, decRpl);
+					k_viterbi_trace_dec<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dDec.p, b->dTraces.p, b->dVit.p, b->nSeq, kb.viterbi_force_redo != 0, decRpl);
 					usedDec = true;
 				}
 				else {
@@ -830,25 +892,42 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 				HIPCHK(hipStreamSynchronize(b->stream));
 			}
 		}
-		/* banded version failed -> regular HMM (src/HmmUFOtu_main.cpp:89-93), one sequence at a time */
+		/* banded version failed -> regular HMM (src/HmmUFOtu_main.cpp:89-93): all such sequences in ONE launch, each with a
+		 * full-DP descriptor of its own (same bases, same trace slot) and its share of one temporary scratch */
 		std::vector<int> redo;
 		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL && !(b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) redo.push_back(s);
-		for(int s : redo) {
-			HuReadDesc rd = b->hDescs[s];
-			build_regions(b->db, rd.len, nullptr, rd);
-			const int64_t cells = rd.scratchOff;
+		b->nFullRedo = (int) redo.size();
+		/* launches of at most 48 M cells (1.2 GB of (M, I, D) scratch): ~130 reads of 250 bp against K = 1,400 each */
+		const int64_t cellCap = 48ll << 20;
+		for(size_t at = 0; at < redo.size();) {
+			std::vector<HuReadDesc> rdv;
+			int64_t cells = 0;
+			size_t e = at;
+			for(; e < redo.size(); ++e) {
+				HuReadDesc rd = b->hDescs[redo[e]];
+				build_regions(b->db, rd.len, nullptr, rd);
+				const int64_t c = rd.scratchOff;
+				if(!rdv.empty() && cells + c > cellCap) break;
+				rd.scratchOff = cells; cells += c;
+				rdv.push_back(rd);
+			}
 			DBuf<double> scr; DBuf<HuReadDesc> dd; DBuf<HuVitOut> vo;
-			if((rc = scr.ensure((size_t) cells * 3)) != HU_OK || (rc = dd.ensure(1)) != HU_OK || (rc = vo.ensure(1)) != HU_OK) { scr.free_(); dd.free_(); vo.free_(); return rc; }
-			rd.scratchOff = 0;
-			HIPCHK(hipMemcpyAsync(dd.p, &rd, sizeof(rd), hipMemcpyHostToDevice, b->stream));
-			k_viterbi<<<1, 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
-			HIPCHK(hipMemcpyAsync(&b->hVit[s], vo.p, sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
+			if((rc = scr.ensure((size_t) cells * 3)) != HU_OK || (rc = dd.ensure(rdv.size())) != HU_OK || (rc = vo.ensure(rdv.size())) != HU_OK) return rc;
+			std::vector<HuVitOut> hv(rdv.size());
+			HIPCHK(hipMemcpyAsync(dd.p, rdv.data(), rdv.size() * sizeof(HuReadDesc), hipMemcpyHostToDevice, b->stream));
+			k_viterbi<<<(unsigned) rdv.size(), 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
 			HIPCHK(hipStreamSynchronize(b->stream));
-			if(b->hVit[s].status == HU_READ_NEEDS_FULL) b->hVit[s].status = HU_READ_INVALID;
-			b->hVit[s].traceLen = b->hVit[s].traceLen; /* trace already written at rd.traceOff */
-			HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
-			scr.free_(); dd.free_(); vo.free_();
-			b->hDescs[s].nRegions = -1; /* mark: full DP was used */
+			for(size_t k = 0; k < rdv.size(); ++k) {
+				const int s = redo[at + k];
+				b->hVit[s] = hv[k];                     /* the trace is already written at the sequence's traceOff */
+				if(b->hVit[s].status == HU_READ_NEEDS_FULL) b->hVit[s].status = HU_READ_INVALID;
+				HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
+				b->hDescs[s].nRegions = -1; /* mark: full DP was used */
+			}
+			HIPCHK(hipStreamSynchronize(b->stream)); /* the temporaries die here */
+			at = e;
 		}
 		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL) {
 			b->hVit[s].status = HU_READ_INVALID;
@@ -871,11 +950,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 		HIPCHK(hipMemcpyAsync(b->hEnd.data(), b->dEnd.p, (size_t) b->n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
 		for(int s = 0; s < b->nSeq; ++s) b->hAlns[s].usedFull |= (b->hDescs[s].nRegions == -1 || (b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) ? 1 : 0;
-		/* reads whose region leaves the resident message window cannot be placed */
-		for(int r = 0; r < b->n; ++r) if(b->hAlns[r].status == HU_READ_OK && (b->hStart[r] < d.winStart || b->hEnd[r] >= d.winStart + d.winLen)) {
-			hu_set_error("read %d aligns to CS columns [%d,%d] outside the resident message window", r, b->hStart[r], b->hEnd[r]);
-			return HU_ERR_ARG;
-		}
+		/* reads whose region leaves the resident message window carry HU_READ_OUT_OF_WINDOW and an empty region (k_encode_rows) */
 	}
 	b->state = ST_ALIGNED;
 	return HU_OK;
@@ -898,13 +973,12 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(getenv("HU_PDIST_V1")) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
+			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
 			else k_seed_pdist2<<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			const char* fm = getenv("HU_TOPK_FAST_MIN");   /* trees smaller than this take the exact two-pass histogram (test hook) */
-			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, fm ? atoi(fm) : 16384);
+			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
 		}
 		HIPCHK(hipGetLastError());
 	}
@@ -987,12 +1061,12 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		Timer t(b, HU_T_ESTIMATE);
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
-		const bool stream = getenv("HU_STREAMING_SEP") != nullptr;
+		const bool stream = b->knob.streaming_sep != 0;
 		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
 		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
 		/* launch order of the table-driven kernels: by seed node */
 		const uint32_t* order = nullptr;
-		if(!getenv("HU_EST_UNSORTED")) {
+		if(!b->knob.est_unsorted) {
 			if((rc = b->dSortK.ensure((size_t) eg * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) eg * 2)) != HU_OK) return rc;
 			size_t tb = 0;
 			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
@@ -1008,10 +1082,9 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		/* sorted launch: the valid slots come first and number at most n x (seeds per read), so only that many workgroups
 		 * start; and XCD x (workgroups b = x mod 8) walks the contiguous eighth x of the sorted list, so that the reads sharing
 		 * a seed node share an L2 (5.13 -> 4.55 ms; without the trim the empty slots all fall to one XCD: 5.48 ms) */
-		const int xm = getenv("HU_XCD_MAP") ? atoi(getenv("HU_XCD_MAP")) : 1;
+		const int xm = b->knob.xcd_map;
 		const unsigned egl = order ? std::min<unsigned>(eg, (unsigned) b->n * (unsigned) b->seedCap) : eg;
-		const char* ev = getenv("HU_EST_VAR");
-		const int var = ev ? atoi(ev) : 0;
+		const int var = b->knob.est_var;
 		if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
 		else if(var == 2) { /* the per-site log() form, kept for comparison */
 			if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
@@ -1119,7 +1192,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
 		const int spt2 = (maxR + 127) / 128, spt4 = (maxR + 255) / 256;  /* sites per thread with 2 / 4 waves per candidate */
-		const bool stream = getenv("HU_STREAMING_SEP") != nullptr || spt4 > 12;
+		const bool stream = b->knob.streaming_sep != 0 || spt4 > 12;
 		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
 		#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
 		if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
@@ -1133,11 +1206,10 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		        * (8192 reads, R = 1363, 25.6 candidates per read): 4 waves x 6 sites 11.9 ms, 2 waves x 12 sites with two
 		        * workgroups per SIMD pair 9.5 ms (fewer reduction / exchange / loop instructions per candidate) */
 			Timer t(b, HU_T_PLACE);
-			const char* ev = getenv("HU_PLACE_VAR");
-			const int var = ev ? atoi(ev) : 0;
-			const int xm = getenv("HU_XCD_MAP") ? atoi(getenv("HU_XCD_MAP")) : 1;   /* an eighth of the node-sorted list per XCD, as in the estimate stage */
+			const int var = b->knob.place_var;
+			const int xm = b->knob.xcd_map;   /* an eighth of the node-sorted list per XCD, as in the estimate stage */
 			const uint32_t* order = nullptr;
-			if(!getenv("HU_PLACE_UNSORTED")) { /* launch order: by candidate node */
+			if(!b->knob.place_unsorted) { /* launch order: by candidate node */
 				if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
 				size_t tb = 0;
 				HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
@@ -1148,14 +1220,14 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			}
 			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
 			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
-				long long* dd = nullptr;
-				HIPCHK(hipMalloc((void**) &dd, nc * 8 * sizeof(long long)));
+				DBuf<long long> ddb;
+				if((rc = ddb.ensure(nc * 8)) != HU_OK) return rc;
+				long long* dd = ddb.p;
 				if(var == 99) k_place_blk<6, 4, 3, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
 				else k_place_blk<12, 2, 3, 0, 2, true, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, dd);
 				std::vector<long long> hd(nc * 8);
 				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
 				HIPCHK(hipStreamSynchronize(b->stream));
-				(void) hipFree(dd);
 				double acc[8] = {0};
 				for(size_t c = 0; c < nc; ++c) for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i];
 				fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
@@ -1170,10 +1242,10 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 				 * slots (k_place_blk GS: 6 + 2 slots = up to 768 gap and 256 base sites, 10 + 2 = 1,280 and 256): the gap slots
 				 * need no per-site table.  The counts come from k_site_count (estimate stage, read back by the filter stage). */
 				const int S = spt2 <= 8 ? 8 : 12, G = S - 2;
-				bool split = !getenv("HU_PLACE_NOSPLIT") && b->hPermCnt.size() == (size_t) b->n * 2;
+				bool split = !b->knob.place_nosplit && b->hPermCnt.size() == (size_t) b->n * 2;
 				for(int r = 0; r < b->n && split; ++r)
 					if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > G * 128 || b->hPermCnt[2 * r + 1] > (S - G) * 128)) split = false;
-				if(getenv("HU_TRACE")) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order");
+				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order");
 				if(split) {
 					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
 					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
@@ -1229,6 +1301,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 			const HuPlaceOut& po = b->hPlaceOut[c];
 			p.loglik = ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
 			p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
+			p.qPlace = p.qTaxon = NAN;     /* --ML computes none */
 			b->places[c] = p;
 		}
 		if(o->only_ml) std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
@@ -1260,6 +1333,8 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 				const double q = p2q(1 - std::exp(tp - norm));
 				pl[i].qTaxon = q > 250 ? 250 : q;
 			}
+			/* the q-values belong to the candidates' records too (hu_batch_get_candidate_places): still in filter order here */
+			for(size_t i = 0; i < pl.size(); ++i) { b->places[lo + i].qPlace = pl[i].qPlace; b->places[lo + i].qTaxon = pl[i].qTaxon; }
 			std::sort(pl.rbegin(), pl.rend(), cmpQPlace);
 		}
 		const HostPlace& p = pl[0];
@@ -1529,7 +1604,13 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 	return HU_OK;
 }
 extern "C" int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N) {
-	if(!b) return HU_ERR_ARG;
+	return hu_batch_get_seeds_strided(b, n_seeds, ids, d, N, HU_MAX_SEEDS);
+}
+extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik) {
+	return hu_batch_get_estimates_strided(b, ratio, wnr, loglik, HU_MAX_SEEDS);
+}
+extern "C" int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N, int stride) {
+	if(!b || stride < 1) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("no seeds yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
 	const size_t n = (size_t) b->n;
@@ -1542,18 +1623,18 @@ extern "C" int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, i
 	}
 	for(size_t r = 0; r < n; ++r) {
 		if(n_seeds) n_seeds[r] = cnt[r];
-		for(int s = 0; s < HU_MAX_SEEDS; ++s) {
+		for(int s = 0; s < HU_MAX_SEEDS && s < stride; ++s) {
 			const bool ok = s < cnt[r];
-			const size_t k = r * HU_MAX_SEEDS + s;
-			if(ids) ids[k] = ok ? id[k] : -1;
-			if(d) d[k] = ok ? (int32_t)(dn[k] >> 16) : 0;
-			if(N) N[k] = ok ? (int32_t)(dn[k] & 0xffffu) : 0;
+			const size_t k = r * HU_MAX_SEEDS + s, w = r * (size_t) stride + s;
+			if(ids) ids[w] = ok ? id[k] : -1;
+			if(d) d[w] = ok ? (int32_t)(dn[k] >> 16) : 0;
+			if(N) N[w] = ok ? (int32_t)(dn[k] & 0xffffu) : 0;
 		}
 	}
 	return HU_OK;
 }
-extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik) {
-	if(!b) return HU_ERR_ARG;
+extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double* wnr, double* loglik, int stride) {
+	if(!b || stride < 1) return HU_ERR_ARG;
 	if(b->state < ST_ESTIMATED) { hu_set_error("no estimates yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
 	const size_t n = (size_t) b->n;
@@ -1563,11 +1644,11 @@ extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, d
 		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
 	}
-	for(size_t r = 0; r < n; ++r) for(int s = 0; s < HU_MAX_SEEDS; ++s) {
-		const size_t k = r * HU_MAX_SEEDS + s; const bool ok = s < cnt[r];
-		if(ratio) ratio[k] = ok ? e[k].ratio : NAN;
-		if(wnr) wnr[k] = ok ? e[k].wnr : NAN;
-		if(loglik) loglik[k] = ok ? e[k].loglik : NAN;
+	for(size_t r = 0; r < n; ++r) for(int s = 0; s < HU_MAX_SEEDS && s < stride; ++s) {
+		const size_t k = r * HU_MAX_SEEDS + s, w = r * (size_t) stride + s; const bool ok = s < cnt[r];
+		if(ratio) ratio[w] = ok ? e[k].ratio : NAN;
+		if(wnr) wnr[w] = ok ? e[k].wnr : NAN;
+		if(loglik) loglik[w] = ok ? e[k].loglik : NAN;
 	}
 	return HU_OK;
 }

@@ -1187,14 +1187,20 @@ __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restri
 	if(lane == 0) { if(db.WQ & 31) qbits[(db.WQ - 1) >> 5] = acc; il[0] = li; }
 }
 
-__global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, const HuAlnDev* __restrict__ alns,
+__global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, HuAlnDev* __restrict__ alns,
 		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
 		int32_t* __restrict__ ins) {
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const HuAlnDev a = alns[r];
 	const char* row = rows + (size_t) r * db.csLen;
 	int8_t* cd = codes + (size_t) r * db.csLen;
-	const bool ok = a.status == HU_READ_OK;
+	bool ok = a.status == HU_READ_OK;
+	/* a read whose region leaves the resident message window cannot be placed: marked per read, with an empty region, so that
+	 * the later stages never index the messages with it */
+	if(ok && (a.csStart - 1 < db.winStart || a.csEnd - 1 >= db.winStart + db.winLen)) {
+		ok = false;
+		if(lane == 0) alns[r].status = HU_READ_OUT_OF_WINDOW;
+	}
 	const int start = ok ? a.csStart - 1 : 0, end = ok ? a.csEnd - 1 : -1;
 	if(lane == 0) { rstart[r] = start; rend[r] = end; }
 	for(int c = lane; c < db.csLen; c += 64) {

@@ -342,6 +342,10 @@ class Batch:
     def sync(self): _chk(load_library().hu_batch_sync(self.h))
     def profile(self, enable=True): _chk(load_library().hu_batch_profile(self.h, C.c_int(int(enable))))
 
+    def set_knob(self, name: str, value: int = 1):
+        """hu_batch_set_knob: pick an alternative kernel / diagnostic for this batch (tests force every kernel path with it)."""
+        _chk(load_library().hu_batch_set_knob(self.h, name.encode(), C.c_int(int(value))))
+
     def wall(self):
         ms = np.zeros(4)
         _chk(load_library().hu_batch_wall(self.h, _p(ms, C.c_double)))
@@ -384,6 +388,20 @@ class Batch:
         cnt = np.zeros(n, np.int32); ids = np.zeros((n, HU_MAX_SEEDS), np.int32); d = np.zeros_like(ids); N = np.zeros_like(ids)
         _chk(load_library().hu_batch_get_seeds(self.h, _p(cnt, C.c_int32), _p(ids, C.c_int32), _p(d, C.c_int32), _p(N, C.c_int32)))
         return cnt, ids, d, N
+
+    def seeds_strided(self, stride: int, guard: int = 0):
+        """hu_batch_get_seeds_strided into [n][stride] buffers followed by `guard` sentinel entries (ABI test)."""
+        n = self.n
+        cnt = np.zeros(n, np.int32)
+        bufs = [np.full(n * stride + guard, -777, np.int32) for _ in range(3)]
+        _chk(load_library().hu_batch_get_seeds_strided(self.h, _p(cnt, C.c_int32), *[_p(b, C.c_int32) for b in bufs], C.c_int(stride)))
+        return (cnt,) + tuple(bufs)
+
+    def estimates_strided(self, stride: int, guard: int = 0):
+        n = self.n
+        bufs = [np.full(n * stride + guard, -777.0) for _ in range(3)]
+        _chk(load_library().hu_batch_get_estimates_strided(self.h, *[_p(b, C.c_double) for b in bufs], C.c_int(stride)))
+        return tuple(bufs)
 
     def estimates(self):
         n = self.n

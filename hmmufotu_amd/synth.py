@@ -490,6 +490,16 @@ def simulate_reads(db: SynthDB, n_reads: int, read_len: int, rng: np.random.Gene
     return out
 
 
+def split_pair(ins: SimRead, read_len: int):
+    """A simulated insert -> (forward read, mate after reverse-complementing it back: src/hmmufotu.cpp:609): the first and
+    the last read_len bases of the insert."""
+    n = len(ins.seq)
+    m = min(read_len, n)
+    f = SimRead(ins.seq[:m], ins.cols[:m], ins.node, ins.rc, ins.cs_start, ins.cs_end)
+    r = SimRead(ins.seq[n - m:], ins.cols[n - m:], ins.node, ins.rc, ins.cs_start, ins.cs_end)
+    return f, r
+
+
 def seed_vpath(hmm: SynthHMM, cs2p: np.ndarray, rd: SimRead, seed_from: int, seed_len: int = 20):
     """The CSLoc a CSFM hit at read[seed_from:+seed_len] would return for the read's true
     alignment, pushed through buildAlignPath (src/BandedHMMP7.cpp:894-941).  Returns the 6 ints

@@ -118,14 +118,18 @@ def make_db_gpu(n_leaves: int, cs_len: int, model_name="GTR", dg_k=0, dg_alpha=0
     return db, up, down
 
 
-def simulate_reads_gpu(db, up, down, n_reads, read_len, seed, amplicon_start, amplicon_cols, jitter=30, device="cuda:0"):
-    """Batched version of synth.simulate_reads (src/hmmufotu-sim.cpp:351-424)."""
+def simulate_reads_gpu(db, up, down, n_reads, read_len, seed, amplicon_start, amplicon_cols, jitter=30, device="cuda:0", uniform=False):
+    """Batched version of synth.simulate_reads (src/hmmufotu-sim.cpp:351-424).  uniform: window starts uniform over the
+    resident columns (the reference simulator's own choice, :371) instead of one amplicon window +- jitter."""
     rng = np.random.default_rng(seed)
     gen = torch.Generator(device=device); gen.manual_seed(seed)
     w0, wl = db.win
     nodes = rng.integers(1, db.n_nodes, size=n_reads)
     rc = rng.random(n_reads)
-    start = np.clip(amplicon_start + rng.integers(-jitter, jitter + 1, size=n_reads), w0, w0 + wl - amplicon_cols - 1)
+    if uniform:
+        start = rng.integers(w0, w0 + wl - amplicon_cols - 1, size=n_reads)
+    else:
+        start = np.clip(amplicon_start + rng.integers(-jitter, jitter + 1, size=n_reads), w0, w0 + wl - amplicon_cols - 1)
     S = amplicon_cols + 1
     v = db.blen[nodes]
     Pu = torch.tensor(synth.model_P(db.model, v * rc), device=device)[:, None]

@@ -43,8 +43,14 @@ enum {
 	HU_READ_OK = 1,
 	HU_READ_INVALID = 0,      /* bad base code or no finite Viterbi path                            */
 	HU_READ_CHIMERA = 2,      /* PE orientation check failed (src/hmmufotu.cpp:629-637)             */
-	HU_READ_NEEDS_FULL = 4    /* internal: banded DP found no path, full DP scheduled              */
+	HU_READ_NEEDS_FULL = 4,   /* internal: banded DP found no path, full DP scheduled              */
+	HU_READ_OUT_OF_WINDOW = 16 /* aligned, but its CS region leaves the column window the database keeps messages for
+	                            * (hu_tree_desc.win_*): not placed, no TSV line; the rest of the batch goes on   */
 };
+
+/* capacity of the per-read seed lists: max_nseed <= HU_MAX_SEEDS, and the per-seed result arrays of
+ * hu_batch_get_seeds / hu_batch_get_estimates / hu_seed_batch_given have this ROW STRIDE whatever max_nseed is */
+#define HU_MAX_SEEDS 64
 
 typedef struct hu_db hu_db;        /* profile + pre-evaluated tree packed once into HBM             */
 typedef struct hu_batch hu_batch;  /* device workspace + stream for one batch of reads in flight    */
@@ -239,6 +245,12 @@ void hu_default_chimera_opts(const hu_opts* o, hu_chimera_opts* co);
  * seed/estimate/filter/place stages run in it).  out [n] */
 int hu_chimera_batch(hu_batch* b, hu_batch* work, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out);
 
+/* Kernel-selection / diagnostic knobs of a batch (which Viterbi kernel, node-ordered launches, split placement slots ...;
+ * the list with defaults is HuKnobs in hmmufotu_amd/csrc/hu_engine.hip).  A batch reads its defaults from the environment
+ * (HU_<NAME>) once, in hu_batch_create; this call changes one of them afterwards.  Results do not depend on any knob
+ * beyond the documented tolerances — the parity tests force each alternative kernel through here.  HU_ERR_ARG: no such knob. */
+int hu_batch_set_knob(hu_batch* b, const char* name, int value);
+
 /* wait for everything queued on the batch's stream */
 int hu_batch_sync(hu_batch* b);
 
@@ -246,8 +258,14 @@ int hu_batch_sync(hu_batch* b);
 int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align /* [n][cs_len] */, char* trace, int trace_stride);
 int hu_batch_get_codes(hu_batch* b, int8_t* codes /* [n][cs_len] */, int32_t* start, int32_t* end);
 int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d /* [n_nodes] */, int32_t* N);
-int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N /* [n][max_nseed] */);
-int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik /* [n][max_nseed] */);
+/* n_seeds [n]; ids, d, N: [n][HU_MAX_SEEDS] — every row is written in full (entries past n_seeds[r]: id -1, d = N = 0) */
+int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N);
+/* ratio, wnr, loglik: [n][HU_MAX_SEEDS], NaN past the read's seed count */
+int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik);
+/* the same with a caller-chosen row stride (>= 1): min(stride, HU_MAX_SEEDS) entries are written per read, nothing beyond;
+ * for callers that size their buffers [n][max_nseed] */
+int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N, int stride);
+int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double* wnr, double* loglik, int stride);
 /* all candidates after placement, in filterPlacements order: offs [n+1]; arrays sized offs[n] */
 int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters);
 int hu_batch_get_placements(hu_batch* b, hu_place_rec* best /* [n] */);

@@ -191,7 +191,9 @@ void orc_tree_evaluate(int nNodes, int csLen, const int* parent, const double* b
 void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, const long* offs,
 		const char* mates, const long* moffs, const int* vpaths, const int* mvpaths,
 		const OrcOpts* o, int nThreads,
-		int* ai, double* cost, char* alignOut, int* bi, double* bd, int* nCand, double* stageSec) {
+		int* ai, double* cost, char* alignOut, int* bi, double* bd, int* nCand, double* stageSec,
+		int* candNode /* optional [nReads][64]: candidates in filterPlacements order */, double* candEst /* their estimated logliks */,
+		double* candRatio0 /* their estimated ratios */, int* bestPos /* position of the final pick in that order */) {
 	HmmHandle* H = (HmmHandle*) hmm; Tree* t = (Tree*) tr;
 	const int L = H->h.L;
 	AssignOpts opts = to_opts(o);
@@ -241,6 +243,11 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			std::vector<Placement> places;
 			for(const PTLoc& l : seeds) places.push_back(estimateSeq(*t, dseq.data(), l, opts.weighted != 0));
 			filterPlacements(places, opts.maxError);
+			if(candNode) for(size_t k = 0; k < places.size() && k < 64; ++k) {
+				candNode[64 * (size_t) r + k] = places[k].cNode;
+				if(candEst) candEst[64 * (size_t) r + k] = places[k].estLoglik;
+				if(candRatio0) candRatio0[64 * (size_t) r + k] = places[k].ratio;
+			}
 			auto t3 = std::chrono::steady_clock::now();
 			loc[2] += std::chrono::duration<double>(t3 - t2).count();
 			for(Placement& p : places) placeSeq(*t, dseq.data(), p, opts.maxHeight);
@@ -254,6 +261,10 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			loc[3] += std::chrono::duration<double>(t4 - t3).count();
 			nCand[r] = (int) places.size();
 			if(!places.empty()) export_place(places[0], bi + 4 * r, bd + 8 * r);
+			if(bestPos) {
+				bestPos[r] = -1;
+				if(candNode) for(size_t k = 0; k < places.size() && k < 64; ++k) if(candNode[64 * (size_t) r + k] == places[0].cNode) { bestPos[r] = (int) k; break; }
+			}
 		}
 		#pragma omp critical
 		for(int k = 0; k < 4; ++k) acc[k] += loc[k];

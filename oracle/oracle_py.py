@@ -209,8 +209,10 @@ def tree_evaluate(parent, blen, leaf_seq, model: Model, dg_r=None):
     return up, down, seq, h
 
 
-def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, want_align=False):
-    """Whole per-read task on the CPU (OpenMP over reads).  reads/mates: list of str."""
+def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, want_align=False, want_cands=False):
+    """Whole per-read task on the CPU (OpenMP over reads).  reads/mates: list of str.
+    want_cands: also the candidates of every read in filterPlacements order (node, estimated loglik, estimated ratio;
+    rows padded with -1 / NaN to 64) and the position of the final pick in that order."""
     opts = opts or default_opts()
     n = len(reads)
     cat = "".join(reads).encode(); offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
@@ -221,12 +223,19 @@ def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None
     ai = np.zeros((n, 8), np.int32); cost = np.zeros(n); bi = np.zeros((n, 4), np.int32); bd = np.zeros((n, 8))
     nc = np.zeros(n, np.int32); st = np.zeros(4)
     aln = np.zeros((n, hmm.L), np.uint8) if want_align else None
+    cn = np.full((n, 64), -1, np.int32) if want_cands else None
+    ce = np.full((n, 64), np.nan) if want_cands else None
+    cr = np.full((n, 64), np.nan) if want_cands else None
+    bp = np.full(n, -1, np.int32) if want_cands else None
     lib().orc_pipeline_batch(hmm.h, tree.h, C.c_int(n), cat, _p(offs, C.c_long),
                              mcat if mates is not None else None, _p(moffs, C.c_long) if mates is not None else None,
                              _p(vp, C.c_int), _p(mvp, C.c_int) if mates is not None else None, C.byref(opts), C.c_int(threads),
                              _p(ai, C.c_int), _p(cost, C.c_double), _p(aln, C.c_char) if aln is not None else None,
-                             _p(bi, C.c_int), _p(bd, C.c_double), _p(nc, C.c_int), _p(st, C.c_double))
-    return dict(aln_ints=ai, cost=cost, align=aln, best_nodes=bi, best_vals=bd, n_cand=nc, stage_sec=st)
+                             _p(bi, C.c_int), _p(bd, C.c_double), _p(nc, C.c_int), _p(st, C.c_double),
+                             _p(cn, C.c_int) if want_cands else None, _p(ce, C.c_double) if want_cands else None,
+                             _p(cr, C.c_double) if want_cands else None, _p(bp, C.c_int) if want_cands else None)
+    return dict(aln_ints=ai, cost=cost, align=aln, best_nodes=bi, best_vals=bd, n_cand=nc, stage_sec=st,
+                cand_node=cn, cand_est=ce, cand_ratio0=cr, best_pos=bp)
 
 
 def max_threads():

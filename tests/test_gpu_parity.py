@@ -30,27 +30,46 @@ def _rel(a, b):
 NEAR_TIE = 1e-9
 
 
-def check_order_and_best(res, gpu_filt, gpu_best, stats):
-    """Candidate order and final pick vs the oracle.  The reference ranks candidates by the
-    ESTIMATED loglik and then sorts all-tied final keys, so the winner is the candidate
-    at a fixed position of the filterPlacements order.  Placing at a node from either adjacent
-    branch (ratio 0 on one, ratio 1 on the other) is the same tree and the same likelihood in exact
-    arithmetic; which of the two sorts first is rounding noise in the reference itself.
-    Such pairs (oracle est. logliks within 1e-9 relative) may swap; anything else must be identical."""
+def check_order_and_best(res, gpu_filt, gpu_best, stats, parent):
+    """Candidate order and final pick vs the oracle: bit-exact, or EXPLAINED difference by difference.  The reference ranks
+    candidates by the ESTIMATED loglik and then sorts all-tied final keys, so the winner is the candidate at a
+    fixed position of the filterPlacements order.  The only accepted difference is the documented near-tie of
+    oracle/parity.py: two candidates that attach at the SAME tree node (estimated ratio exactly 0 / 1 on branches incident
+    to it: the same tree in exact arithmetic) whose oracle estimates agree to 1e-9 relative.  Anything else fails."""
+    from oracle import parity
     ofilt = [int(x) for x in res["filt_order"]]
-    est = {int(n_[0]): v[7] for n_, v in zip(res["nodes"], res["vals"])}
-    assert sorted(ofilt) == sorted(gpu_filt)
-    for a, b in zip(ofilt, gpu_filt):
-        if a != b:
-            assert abs(est[a] - est[b]) <= NEAR_TIE * abs(est[a]), (a, b, est[a], est[b])
-            stats["near_tie_swaps"] += 1
+    seed_est = {int(s_): e for s_, e in zip(res["seed_ids"], res["est"])}
     pos = ofilt.index(int(res["nodes"][0][0]))          # position picked by the all-ties final std::sort
+    c = parity.classify_read(ofilt, [seed_est[n_][2] for n_ in ofilt], [seed_est[n_][0] for n_ in ofilt], gpu_filt, parent, pos)
+    assert c["set_differs"] == 0 and c["swaps_unexplained"] == 0 and c["best_unexplained"] == 0, c["detail"]
     assert int(gpu_best["c_node"]) == gpu_filt[pos], (pos, gpu_filt, ofilt)
-    if gpu_filt[pos] != ofilt[pos]:
-        stats["best_differs_by_tie"] += 1
-    else:
-        assert (int(gpu_best["p_node"]), int(gpu_best["a_node"])) == (int(res["nodes"][0][1]), int(res["nodes"][0][2]))
+    stats["near_tie_swaps"] += c["swaps_explained"]
+    stats["best_differs_by_tie"] += c["best_differs"]
     stats["reads"] += 1
+    return c["best_differs"] == 0
+
+
+def check_all_candidates(res, cplaces, stats):
+    """a15: every candidate's PTPlacement after placeSeq + calcQValues against the oracle's, matched by branch: the taxon node,
+    height, annotation distance, both q-values (src/HmmUFOtu_main.cpp:182-216, src/PhyloTreeUnrooted.cpp:936-952)."""
+    oc = {int(n_[0]): (n_, v) for n_, v in zip(res["nodes"], res["vals"])}
+    assert sorted(oc) == sorted(int(x) for x in cplaces["c_node"])
+    for g in cplaces:
+        n_, v = oc[int(g["c_node"])]
+        assert int(g["p_node"]) == int(n_[1])
+        ratio, wnr, loglik, height, qp, qt, ad, est = v
+        assert abs(g["ratio"] - ratio) <= REL * max(abs(ratio), 1e-3) and abs(g["wnr"] - wnr) <= REL * max(abs(wnr), 1e-3)
+        assert _rel(g["loglik"], loglik) < 1e-12 and _rel(g["est_loglik"], est) < REL
+        if abs(ratio - 0.5) > 1e-6:                          # aNode switches at ratio 0.5: not decidable closer than the tolerance
+            assert int(g["a_node"]) == int(n_[2]), (g, n_)
+            assert abs(g["anno_dist"] - ad) <= REL * max(abs(ad), 1e-3)
+        else:
+            stats["ratio_at_half"] = stats.get("ratio_at_half", 0) + 1
+        assert abs(g["height"] - height) <= REL * max(abs(height), 1e-3)
+        assert abs(g["q_place"] - qp) <= 1e-9 * max(1.0, abs(qp)), (g["q_place"], qp)
+        if int(g["a_node"]) == int(n_[2]):
+            assert abs(g["q_taxon"] - qt) <= 1e-9 * max(1.0, abs(qt)), (g["q_taxon"], qt)
+        stats["cands"] = stats.get("cands", 0) + 1
 
 
 @pytest.mark.parametrize("model", ["GTR", "TN93", "HKY85", "F81", "K80", "JC69"])
@@ -65,6 +84,20 @@ def test_model_pr(model):
     for i, t in enumerate(ts):
         assert np.abs(P[i] - m.P(float(t))).max() < 1e-12, (model, t)
     D.close()
+
+
+def classify_batch(ref, cand, best, parent):
+    """oracle pipeline_batch(want_cands=True) vs the engine's candidates / picks: totals of oracle/parity.py's classes"""
+    from oracle import parity
+    per = []
+    for i in range(len(best)):
+        k = int(ref["n_cand"][i]); a, b = int(cand["offs"][i]), int(cand["offs"][i + 1])
+        c = parity.classify_read(ref["cand_node"][i, :k], ref["cand_est"][i, :k], ref["cand_ratio0"][i, :k], cand["c_node"][a:b], parent,
+                                 pos=int(ref["best_pos"][i]) if k else None)
+        if k:
+            assert int(best[i]["c_node"]) == int(cand["c_node"][a + int(ref["best_pos"][i])])   # same position of the same std::sort
+        per.append(c)
+    return parity.summarize(per)
 
 
 def _run_stages(E, db, reads, vps, opts, mode=0, mates=None, mvps=None):
@@ -252,6 +285,7 @@ def test_sep_parity(cfg):
     er, ew, el = B.estimates()
     cand = B.candidates()
     best = B.placements()
+    coffs, cpl = B.candidate_places()
     oo = O.default_opts()
     worst = dict(est=0.0, ratio=0.0, wnr=0.0)
     stats = dict(reads=0, near_tie_swaps=0, best_differs_by_tie=0)
@@ -275,13 +309,41 @@ def test_sep_parity(cfg):
             worst["ratio"] = max(worst["ratio"], abs(cand["ratio"][c] - r0) / max(abs(r0), 1e-3))
             worst["wnr"] = max(worst["wnr"], abs(cand["wnr"][c] - w0_) / max(abs(w0_), 1e-3))
         b = best[i]
-        check_order_and_best(res, [int(x) for x in cand["c_node"][lo:hi]], b, stats)      # bit-exact ids up to exact-arithmetic ties
+        same = check_order_and_best(res, [int(x) for x in cand["c_node"][lo:hi]], b, stats, db.parent)   # bit-exact ids, or explained one by one
+        check_all_candidates(res, cpl[coffs[i]:coffs[i + 1]], stats)
         assert b["n_cand"] == res["n"]
         assert _rel(b["loglik"], res["vals"][0][2]) < 1e-12
         assert _rel(b["q_place"], res["vals"][0][4]) < 1e-9
+        if same:                                             # the record of the winner as written to the TSV (a15)
+            n0, v0 = res["nodes"][0], res["vals"][0]
+            assert (int(b["p_node"]), int(b["a_node"])) == (int(n0[1]), int(n0[2]))
+            assert _rel(b["q_taxon"], v0[5]) < 1e-9 and abs(b["anno_dist"] - v0[6]) <= REL * max(abs(v0[6]), 1e-3)
+            assert abs(b["height"] - v0[3]) <= REL * max(abs(v0[3]), 1e-3)
     assert worst["est"] < REL and worst["ratio"] < REL and worst["wnr"] < REL, worst
-    assert stats["best_differs_by_tie"] <= stats["reads"] // 4, stats
     print("parity stats", cfg, stats, worst)
+    B.close(); D.close()
+
+
+def test_seed_getters_respect_the_callers_stride():
+    """hu_batch_get_seeds / _estimates write rows of HU_MAX_SEEDS (64) entries; the _strided forms write min(stride, 64) per read
+    and nothing beyond: a caller that sizes its buffers [n][max_nseed] must not be overrun (guard entries stay untouched)."""
+    E = _engine()
+    db = get_db(150, 700, "GTR", dg_k=0)
+    reads, vps = sim_reads(db, 6, 150)
+    opts = E.default_opts(max_nseed=50)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts)
+    cnt, ids, sd, sN = B.seeds(); er, ew, el = B.estimates()
+    assert ids.shape[1] == E.HU_MAX_SEEDS == 64
+    for stride in (50, 7, 64, 100):
+        c2, i2, d2, n2 = B.seeds_strided(stride, guard=40)
+        r2, w2, l2 = B.estimates_strided(stride, guard=40)
+        m = min(stride, 64)
+        assert (c2 == cnt).all()
+        for full, got in ((ids, i2), (sd, d2), (sN, n2), (er, r2), (ew, w2), (el, l2)):
+            rows = got[:len(reads) * stride].reshape(len(reads), stride)
+            assert np.array_equal(rows[:, :m], full[:, :m], equal_nan=True)
+            assert (rows[:, m:] == -777).all() and (got[len(reads) * stride:] == -777).all()      # nothing written past min(stride, 64)
     B.close(); D.close()
 
 
@@ -299,17 +361,33 @@ def test_sep_weighted_and_maxheight():
     cnt, ids, _, _ = B.seeds()
     er, ew, el = B.estimates()
     best = B.placements()
+    coffs, cpl = B.candidate_places()
     oo = O.default_opts(weighted=1, maxHeight=mh, maxNSeed=20, prior=1)
+    diff = 0
     for i in range(len(reads)):
         res = T.assign(cd[i], int(st[i]), int(en[i]), oo)
         k = len(res["seed_ids"])
         assert cnt[i] == k and (ids[i, :k] == res["seed_ids"]).all()
         assert _rel(ew[i, :k], res["est"][:, 1]).max() < REL and _rel(el[i, :k], res["est"][:, 2]).max() < REL
+        # with --prior height the final keys (q_place) are distinct: every candidate's record is compared by branch
+        # (a_node under the height bound, height, anno_dist, q_place, q_taxon), and the pick is the oracle's unless the
+        # oracle's own two best keys are a tie to 1e-9
+        oc = {int(n_[0]): (n_, v) for n_, v in zip(res["nodes"], res["vals"])}
+        g = cpl[coffs[i]:coffs[i + 1]]
+        assert sorted(oc) == sorted(int(x) for x in g["c_node"])
+        for rec in g:
+            n_, v = oc[int(rec["c_node"])]
+            assert int(rec["a_node"]) == int(n_[2]) or abs(v[0] - 0.5) < 1e-6
+            assert abs(rec["height"] - v[3]) <= REL * max(abs(v[3]), 1e-3) and abs(rec["anno_dist"] - v[6]) <= REL * max(abs(v[6]), 1e-3)
+            assert abs(rec["q_place"] - v[4]) <= 1e-5 * max(1.0, abs(v[4])), (rec["q_place"], v[4])    # q = -10 log10(1 - p): p to 1e-6
+            assert abs(rec["q_taxon"] - v[5]) <= 1e-5 * max(1.0, abs(v[5]))
         b = best[i]
-        if b["c_node"] == int(res["nodes"][0][0]):
-            assert b["a_node"] == int(res["nodes"][0][2]) and _rel(b["q_place"], res["vals"][0][4]) < 1e-5
-        else:   # prior=height makes the final keys distinct; a differing pick must be a near-tie of those keys
-            assert abs(b["q_place"] - res["vals"][0][4]) < 1e-5 * max(1.0, abs(b["q_place"]))
+        if b["c_node"] != int(res["nodes"][0][0]):
+            diff += 1
+            assert len(res["vals"]) > 1 and abs(res["vals"][0][4] - res["vals"][1][4]) <= 1e-9 * max(1.0, abs(res["vals"][0][4])), (i, res["vals"][:2])
+        else:
+            assert b["a_node"] == int(res["nodes"][0][2]) and abs(b["q_taxon"] - res["vals"][0][5]) <= 1e-5 * max(1.0, abs(res["vals"][0][5]))
+    print("prior=height: picks differing by an exact key tie:", diff)
     B.close(); D.close()
 
 
@@ -328,13 +406,14 @@ def test_set_aligned_entry_and_empty_batch():
     opts = E.default_opts()
     B.set_aligned(np.stack(codes), s, e)
     B.assign(opts)
-    best = B.placements()
-    hit = 0
+    best = B.placements(); cand = B.candidates()
+    stats = dict(reads=0, near_tie_swaps=0, best_differs_by_tie=0)
     for i in range(len(reads)):
         res = T.assign(codes[i], s[i], e[i], O.default_opts())
-        hit += best[i]["c_node"] == int(res["nodes"][0][0])
+        lo, hi = cand["offs"][i], cand["offs"][i + 1]
+        check_order_and_best(res, [int(x) for x in cand["c_node"][lo:hi]], best[i], stats, db.parent)
         assert best[i]["n_cand"] == res["n"]
-    assert hit >= len(reads) - 2        # exact-arithmetic ties may swap (see check_order_and_best)
+    print("set_aligned parity", stats)
     B.set_reads([], np.zeros((0, 2, 6), np.int32))
     B.assign(opts)
     assert len(B.placements()) == 0
@@ -540,6 +619,7 @@ def test_edge_cases_small_tree_short_reads_and_window():
     length (full DP), a database resident only for a column window"""
     E = _engine()
     from oracle import oracle_py as O
+    from hmmufotu_amd import synth
     db = get_db(16, 400, "GTR", dg_k=4, seed=21, n_match=150)    # 31 nodes < 50 seeds
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, 10, 60, cols=250)
@@ -568,15 +648,34 @@ def test_edge_cases_small_tree_short_reads_and_window():
                                   db2.anno_id, db2.anno_dist, win_start=lo, win_len=hi - lo)
     res = []
     for D in (Dfull, Dwin):
-        B = E.Batch(D, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts); res.append(B.placements().copy()); B.close()
+        B = E.Batch(D, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts); res.append(B.placements().copy())
+        full_recs = B.alignments(want_align=False)["recs"].copy(); B.close()
     for k in ("c_node", "a_node", "ratio", "wnr", "est_loglik"):
         assert np.array_equal(res[0][k], res[1][k]), k
     Dtiny = E.Database.from_arrays(db2.hmm, db2.parent, db2.blen, db2.seq, db2.up[:, 300:400].copy(), db2.down[:, 300:400].copy(), db2.height, md,
                                    win_start=300, win_len=100)
+    # reads that align outside the resident window are marked per read (status 16), the batch goes on
     B = E.Batch(Dtiny, 8); B.set_reads([r.seq for r in reads], vps)
-    with pytest.raises(E.EngineError, match="outside the resident message window"):
-        B.assign(opts)
-    B.close(); Dfull.close(); Dwin.close(); Dtiny.close()
+    B.assign(opts)
+    recs = B.alignments(want_align=False)["recs"]
+    assert (recs["status"] == 16).all() and (B.placements()["c_node"] == -1).all()
+    B.close(); Dtiny.close()
+    # stray reads among good ones: a window that starts just after the left-most alignment(s)
+    starts = np.sort(np.unique(full_recs["cs_start"] - 1))
+    assert len(starts) > 1
+    lo2 = int(starts[1])
+    out_ = (full_recs["cs_start"] - 1) < lo2
+    assert 0 < out_.sum() < len(reads)
+    Dw2 = E.Database.from_arrays(db2.hmm, db2.parent, db2.blen, db2.seq, db2.up[:, lo2:hi].copy(), db2.down[:, lo2:hi].copy(), db2.height, md,
+                                 db2.anno_id, db2.anno_dist, win_start=lo2, win_len=hi - lo2)
+    B = E.Batch(Dw2, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts)
+    recs = B.alignments(want_align=False)["recs"]; got = B.placements()
+    assert (recs["status"][out_] == 16).all() and (recs["status"][~out_] == 1).all() and (got["c_node"][out_] == -1).all()
+    assert np.array_equal(recs["cs_start"], full_recs["cs_start"])          # still aligned, just not placed
+    for k in ("c_node", "a_node", "ratio", "wnr", "est_loglik"):
+        assert np.array_equal(got[k][~out_], res[0][k][~out_]), k
+    assert len(B.format_tsv(["r%d" % i for i in range(8)], None, db2.annos).strip("\n").split("\n")) == int((~out_).sum())
+    B.close(); Dw2.close(); Dfull.close(); Dwin.close()
 
 
 def test_topk_sampled_threshold_path(monkeypatch):
@@ -636,13 +735,14 @@ def test_pe_full_pipeline_against_oracle_batch():
     D = E.Database.from_synth(db); B = E.Batch(D, 32)
     B.set_reads(fw, np.stack(vf), rv, np.stack(vr)); B.assign(opts)
     best = B.placements(); recs = B.alignments(want_align=False)["recs"]
-    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2)
+    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2, want_cands=True)
     assert (recs["status"] == ref["aln_ints"][:, 7]).all()
     assert (recs["cs_start"] == ref["aln_ints"][:, 4]).all() and (recs["cs_end"] == ref["aln_ints"][:, 5]).all()
     assert np.array_equal(recs["cost"], ref["cost"])
     assert (best["n_cand"] == ref["n_cand"]).all()
-    agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
-    assert agree >= 0.8, agree                                     # exact-arithmetic ties may swap (see check_order_and_best)
+    tot = classify_batch(ref, B.candidates(), best, db.parent)
+    assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
+    print("PE parity", tot)
     B.close(); D.close()
 
 
@@ -666,15 +766,16 @@ def test_wide_region_kernels():
     D = E.Database.from_synth(db); B = E.Batch(D, 16)
     B.set_reads(fw, np.stack(vf), rv, np.stack(vr)); B.assign(opts)
     best = B.placements(); recs = B.alignments(want_align=False)["recs"]
-    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2)
+    ref = O.pipeline_batch(H, T, fw, np.stack(vf), mates=rv, mvpaths=np.stack(vr), threads=2, want_cands=True)
     ok = recs["status"] == 1
     assert ok.sum() >= 8 and (recs["status"] == ref["aln_ints"][:, 7]).all()
     span = (recs["cs_end"] - recs["cs_start"])[ok]
     assert span.max() > 1536, span                                 # beyond the 2-wave kernel's 12 x 128 sites
     assert np.array_equal(recs["cost"], ref["cost"])
     assert (best["n_cand"] == ref["n_cand"]).all()
-    agree = (best["c_node"] == ref["best_nodes"][:, 0]).mean()
-    assert agree >= 0.8, agree
+    tot = classify_batch(ref, B.candidates(), best, db.parent)
+    assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
+    print("wide-region parity", tot)
     B.close(); D.close()
 
 
@@ -684,7 +785,7 @@ def test_chimera_check_parity(num_seg, model, dg_k):
     the log-odds against each other's branch, vs the oracle on the same codes and seeds.  Half of the inputs are
     real chimeras spliced from two reads at the middle of the region."""
     E = _engine()
-    from oracle import oracle_py as O
+    from oracle import oracle_py as O, parity
     db = get_db(150, 700, model, dg_k=dg_k)
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, 24, 150)
@@ -720,9 +821,16 @@ def test_chimera_check_parity(num_seg, model, dg_k):
             assert _rel(gp["loglik"], op["loglik"]) < 1e-12
             if int(gp["c_node"]) != op["c"] or int(g[side + "_start"]) != op["start"]:
                 # the winner sits at a fixed position of the pooled sequence; another node there means two candidates
-                # of that segment swapped in filterPlacements order, allowed for exact-arithmetic ties only (check_order_and_best)
+                # of that segment swapped in filterPlacements order: accepted only for the documented near-tie (both attach at
+                # the same tree node, oracle estimates within 1e-9: oracle/parity.py), checked difference by difference
                 assert int(g[side + "_start"]) == op["start"], (i, side)
-                assert abs(gp["est_loglik"] - op["est_loglik"]) <= NEAR_TIE * abs(op["est_loglik"]), (i, side, gp["est_loglik"], op["est_loglik"])
+                s0, e0 = op["start"], op["end"]
+                dd, NN = T.pdist_all(cd[i], s0, e0)
+                eo = {}
+                for nd_ in (op["c"], int(gp["c_node"])):
+                    eo[nd_] = T.estimate(cd[i], s0, e0, nd_, float(np.float64(dd[nd_]) / np.float64(NN[nd_])))
+                assert parity.explained_swap(op["c"], int(gp["c_node"]), {k_: v_["loglik"] for k_, v_ in eo.items()},
+                                             {k_: v_["ratio"] for k_, v_ in eo.items()}, db.parent), (i, side, eo)
                 tie_diff += 1
                 continue
             assert (int(gp["p_node"]), int(gp["a_node"])) == (op["p"], op["a"]), (i, side)
@@ -731,8 +839,7 @@ def test_chimera_check_parity(num_seg, model, dg_k):
             assert abs(gp["ratio"] - op["ratio"]) <= REL * max(abs(op["ratio"]), 1e-3)
             assert abs(gp["wnr"] - op["wnr"]) <= REL * max(abs(op["wnr"]), 1e-3)
         assert best[i]["n_cand"] >= 1
-    assert tie_diff <= len(reads) // 2, tie_diff
-    print("chimera parity: tie-order differences", tie_diff, "of", 2 * len(reads))
+    print("chimera parity: explained near-tie order differences", tie_diff, "of", 2 * len(reads))
     # argument checks of src/hmmufotu.cpp:325-340
     for bad in (dict(num_seg=3), dict(num_seg=8), dict(max_chimera_error=0.0), dict(min_chimera_lod=-1.0)):
         with pytest.raises(E.EngineError):
@@ -777,7 +884,7 @@ def test_chimera_check_edge_cases():
     """Regions too short to cut, one-column segments, the weighted method with a height bound, and a work batch on the
     wrong database."""
     E = _engine()
-    from oracle import oracle_py as O
+    from oracle import oracle_py as O, parity
     db = get_db(100, 700, "HKY85", dg_k=4)
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, 8, 120)
@@ -807,8 +914,14 @@ def test_chimera_check_edge_cases():
                 if int(g[side]["c_node"]) == o[side]["c"] and int(g[side + "_start"]) == o[side]["start"]:
                     assert int(g[side]["a_node"]) == o[side]["a"]
                     assert abs(g[side]["wnr"] - o[side]["wnr"]) <= REL * max(abs(o[side]["wnr"]), 1e-3)
-                else:   # near-tie swap of the segment's estimates (see test_chimera_check_parity)
-                    assert abs(g[side]["est_loglik"] - o[side]["est_loglik"]) <= 1e-6 * abs(o[side]["est_loglik"])
+                else:   # near-tie swap of the segment's estimates: same attachment node, oracle estimates within 1e-9 (oracle/parity.py)
+                    assert int(g[side + "_start"]) == o[side]["start"]
+                    s0, e0 = o[side]["start"], o[side]["end"]
+                    dd, NN = T.pdist_all(cd[i], s0, e0)
+                    eo = {nd_: T.estimate(cd[i], s0, e0, nd_, float(np.float64(dd[nd_]) / np.float64(NN[nd_])), weighted=True)
+                          for nd_ in (o[side]["c"], int(g[side]["c_node"]))}
+                    assert parity.explained_swap(o[side]["c"], int(g[side]["c_node"]), {k_: v_["loglik"] for k_, v_ in eo.items()},
+                                                 {k_: v_["ratio"] for k_, v_ in eo.items()}, db.parent), (num_seg, i, side, eo)
     db2 = get_db(60, 700, "JC69", dg_k=0)
     D2 = E.Database.from_synth(db2)
     W2 = E.Batch(D2, len(reads))
@@ -842,13 +955,13 @@ def test_split_gap_base_placement_kernel(monkeypatch, capfd, read_len, lo, hi, g
     span = en - st + 1
     nb = np.array([(cd[i, st[i]:en[i] + 1] >= 0).sum() for i in range(len(reads))])
     assert (span.max() > lo) and (span <= hi).all() and (nb <= 256).all() and (span - nb <= gap_cap).all(), (span, nb)
-    monkeypatch.setenv("HU_TRACE", "1")
+    B.set_knob("trace", 1)
     B.place_seq(opts); B.calc_q_values(opts)
     split = B.candidates(); best = B.placements()
-    monkeypatch.setenv("HU_PLACE_NOSPLIT", "1")
+    B.set_knob("place_nosplit", 1)
     B.place_seq(opts); B.calc_q_values(opts)
     plain = B.candidates()
-    monkeypatch.delenv("HU_PLACE_NOSPLIT"); monkeypatch.delenv("HU_TRACE")
+    B.set_knob("place_nosplit", 0); B.set_knob("trace", 0)
     err = capfd.readouterr().err
     assert "gap/base split slots" in err and "column order" in err, err      # both kernels ran
     assert np.array_equal(split["c_node"], plain["c_node"]) and np.array_equal(split["iters"], plain["iters"])
