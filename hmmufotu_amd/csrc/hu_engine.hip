@@ -528,8 +528,7 @@ struct HuKnobs {
 	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
 	int est_var = 0, place_var = 0;             /* alternative kernel variants (comparison / diagnostics)            */
 	int place_nosplit = 0;       /* column-order placement kernel even when the gap / base split applies             */
-	int place_pair = 1;          /* two candidates per workgroup with interleaved EM steps                           */
-	int topk_blocks = 1;         /* top-k reads only the 256-node blocks at / below the sampled threshold            */
+	int place_em1 = 0;           /* k_place_w1: the EM of a branch on one wave (0: k_place_blk, EM steps across both waves) */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
@@ -539,7 +538,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_pair", &HuKnobs::place_pair}, {"topk_blocks", &HuKnobs::topk_blocks}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1219,7 +1218,33 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 				order = b->dSortV.p + nc;
 			}
 			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
-			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
+			if(var == 97 && spt2 <= 12 && spt2 > 8) { /* diagnostic: s_memtime stamps of k_place_w1, per wave role, averaged over the candidates, to stderr */
+				DBuf<long long> ddb;
+				if((rc = ddb.ensure(nc * 16)) != HU_OK) return rc;
+				bool split = b->hPermCnt.size() == (size_t) b->n * 2;
+				for(int r = 0; r < b->n && split; ++r) if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > 10 * 128 || b->hPermCnt[2 * r + 1] > 2 * 128)) split = false;
+				if(split) {
+					if((rc = b->dPerm.ensure((size_t) b->n * 12 * 128)) != HU_OK) return rc;
+					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, 10 * 128, 2 * 128, b->dPerm.p);
+					k_place_w1<12, 10, 2, true><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm, ddb.p);
+				}
+				else k_place_w1<12, 0, 2, true><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm, ddb.p);
+				std::vector<long long> hd(nc * 16);
+				HIPCHK(hipMemcpyAsync(hd.data(), ddb.p, nc * 16 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+				HIPCHK(hipStreamSynchronize(b->stream));
+				double acc[16] = {0};
+				for(size_t c = 0; c < nc; ++c) { /* wave 0 of block c serves phase i when (c >> 3 & 1) == 0 */
+					const int s0 = ((c >> 3) & 1) == 0 ? 0 : 1;     /* index of the wave serving phase (i) */
+					for(int i = 0; i < 8; ++i) { acc[i] += (double) hd[(c * 2 + s0) * 8 + i]; acc[8 + i] += (double) hd[(c * 2 + (1 - s0)) * 8 + i]; }
+				}
+				const char* nm[8] = {"load", "exps+tables", "sweeps", "em", "barrier-wait", "hand-over", "total", "em-steps"};
+				for(int role = 0; role < 2; ++role) {
+					fprintf(stderr, "[place dbg] wave serving phase %s:", role == 0 ? "(i) " : "(ii)");
+					for(int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", nm[i], acc[role * 8 + i] / nc);
+					fprintf(stderr, "\n");
+				}
+			}
+			else if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				DBuf<long long> ddb;
 				if((rc = ddb.ensure(nc * 8)) != HU_OK) return rc;
 				long long* dd = ddb.p;
@@ -1236,6 +1261,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
 			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
 			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
+			else if(spt2 <= 4 && b->knob.place_em1 && var == 0) k_place_w1<4, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
 			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
 			else if(spt2 <= 12 && !(var == 7)) {
 				/* 8 or 12 sites per thread.  When every read of the batch fits, its gap sites and its base sites go to separate
@@ -1245,13 +1271,18 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 				bool split = !b->knob.place_nosplit && b->hPermCnt.size() == (size_t) b->n * 2;
 				for(int r = 0; r < b->n && split; ++r)
 					if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > G * 128 || b->hPermCnt[2 * r + 1] > (S - G) * 128)) split = false;
-				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order");
+				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", b->knob.place_em1 ? "EM on one wave" : "EM across both waves");
 				if(split) {
 					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
 					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
-					if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+					const bool em1 = b->knob.place_em1 != 0;
+					if(S == 8 && em1) k_place_w1<8, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
+					else if(em1) k_place_w1<12, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
+					else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 				}
+				else if(S == 8 && b->knob.place_em1) k_place_w1<8, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
+				else if(b->knob.place_em1) k_place_w1<12, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
 				else if(S == 8) PL_GO(8, 2, 3, 0, 2);
 				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
 			}

@@ -119,6 +119,11 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
 	}
 }
 
+/* Measured and not kept (round 2): requesting the reads' planes one or two reads ahead with explicit s_load_dwordx8/x4 asm and
+ * two / four SGPR sets in rotation (left to the compiler every request is followed at once by s_waitcnt lgkmcnt(0)): 4.89 ms against
+ * 3.68 ms.  Scalar loads return out of order, so a wait is always "all of them" and a request is covered by one vector block only;
+ * the four register sets push the kernel to its 102 SGPRs (v_writelane spills) and the fake dependencies that keep the scheduler from
+ * hoisting all sixteen request / wait pairs in front of the vector work cost more than the latency four waves per SIMD already hide. */
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
 		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, uint32_t* __restrict__ pairs, int nReads) {
 	constexpr int T = HU_READ_TILE;

@@ -962,6 +962,13 @@ def test_split_gap_base_placement_kernel(monkeypatch, capfd, read_len, lo, hi, g
     B.place_seq(opts); B.calc_q_values(opts)
     plain = B.candidates()
     B.set_knob("place_nosplit", 0); B.set_knob("trace", 0)
+    # k_place_blk (EM steps across both waves, one barrier per step) against the default k_place_w1 (EM on one wave)
+    B.set_knob("place_em1", 0)
+    B.place_seq(opts); B.calc_q_values(opts)
+    two = B.candidates()
+    B.set_knob("place_em1", 1)
+    assert np.array_equal(split["c_node"], two["c_node"]) and np.array_equal(split["iters"] & 0xff, two["iters"] & 0xff)
+    assert np.abs(split["ratio"] - two["ratio"]).max() < 1e-8 and np.abs(split["wnr"] - two["wnr"]).max() < 1e-8
     err = capfd.readouterr().err
     assert "gap/base split slots" in err and "column order" in err, err      # both kernels ran
     assert np.array_equal(split["c_node"], plain["c_node"]) and np.array_equal(split["iters"], plain["iters"])

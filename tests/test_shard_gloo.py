@@ -57,3 +57,35 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def _bench(*args, env=None, timeout=600):
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` without a launcher must run TWO ranks (it starts torch.distributed.run itself), go through
+    the real rendezvous / barrier / gather_records / max-over-ranks control flow and print ONE line with n_gpus = 2.
+    --rehearse replaces the engine by a sleep (no GPU here); the engine-backed 2-rank run is tests/test_bench_gpu.py."""
+    p, lines = _bench("--gpus", "2", "--rehearse", "--steps", "3", "--batch", "5")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["self_launched"] and j["backend"] == "gloo" and j["gathered_records"] == 10 and j["gather_ok"]
+    assert j["value"] is None and "rehearsal" in j["data"]           # nothing is measured in a rehearsal
+
+
+def test_bench_refuses_a_rank_count_it_was_not_asked_for():
+    p, lines = _bench("--gpus", "2", "--rehearse", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode == 2 and not lines and "refusing" in p.stderr
+
+
+def test_bench_failure_of_a_rank_is_a_failure_of_the_run():
+    p, lines = _bench("--gpus", "2", "--rehearse", "--batch", "-1")
+    assert p.returncode != 0 and not lines
