@@ -221,7 +221,7 @@ int main(int argc, char** argv) {
 	LineOut fout; if(!outFn.empty() && !fout.open(outFn)) { std::cerr << "Unable to write to '" << outFn << "'" << std::endl; return EXIT_FAILURE; }
 	auto out = [&](const std::string& t) { if(fout.on) fout.write(t); else std::cout.write(t.data(), (std::streamsize) t.size()); };
 	const char* header = chimeraInfo ? hu_tsv_header_chimera() : hu_tsv_header();
-	const std::string preamble = std::string("# hmmufotu_amd v0.1.0 taxonomy assignment generated by ") + argv[0] + "\n# command: " + cmd + "\n" + header + "\n";
+	const std::string preamble = std::string("# HmmUFOtu v1.5.1 taxonomy assignment generated by ") + argv[0] + "\n# command: " + cmd + "\n" + header + "\n";
 	out(preamble);
 	LineOut chiOut;
 	if(!chiOutFn.empty()) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <functional>
+#include <istream>
 #include <vector>
 #include "../../include/hmmufotu_amd.h"
 
@@ -129,3 +131,7 @@ struct HuTreeHost {
 int hu_read_hmm(const char* path, HuProfileHost& out, std::vector<double>& EM, std::vector<double>& EI,
 		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L);
 int hu_read_ptu(const char* path, HuTreeHost& out);
+int hu_read_ptu_sink(const char* path, HuTreeHost& out, const std::function<int(bool, int64_t, const double*)>* sink);
+int hu_read_hmm_stream(std::istream& in, const char* name, HuProfileHost& out, std::vector<double>& EM, std::vector<double>& EI,
+		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L);
+int hu_read_model_text(std::istream& in, hu_model_desc& m);

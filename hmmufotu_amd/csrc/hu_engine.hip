@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <chrono>
+#include <sstream>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 #include "hu_kern_align.h"
@@ -332,20 +333,76 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 
 extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) {
 	if(!hmm_path || !ptu_path || !out) { hu_set_error("hu_db_load: null argument"); return HU_ERR_ARG; }
+	*out = nullptr;
+	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
 	HuProfileHost prof; std::vector<double> EM, EI, T; std::vector<int32_t> p2cs; int K, L;
 	int rc = hu_read_hmm(hmm_path, prof, EM, EI, T, p2cs, K, L);
 	if(rc != HU_OK) return rc;
+	HIPCHK(hipSetDevice(device));
+	/* the messages (4 x csLen doubles per directed edge: 98 GB at gg_97 scale) go from the file to the device edge by edge,
+	 * through two page-locked staging rows, never through a host copy of the whole set */
 	HuTreeHost t;
-	if((rc = hu_read_ptu(ptu_path, t)) != HU_OK) return rc;
-	if(K > t.csLen) { hu_set_error("HMM profile size is greater than the tree's CS length"); return HU_ERR_ARG; }
+	double *dUp = nullptr, *dDown = nullptr;
+	double* stage[2] = {nullptr, nullptr};
+	hipStream_t st = nullptr;
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	auto cleanup = [&](bool keepMsgs) {
+		for(int i = 0; i < 2; ++i) { if(stage[i]) (void) hipHostFree(stage[i]); if(ev[i]) (void) hipEventDestroy(ev[i]); }
+		if(st) (void) hipStreamDestroy(st);
+		if(!keepMsgs) { if(dUp) (void) hipFree(dUp); if(dDown) (void) hipFree(dDown); }
+	};
+	size_t row = 0; int turn = 0; hipError_t herr = hipSuccess;
+	const std::function<int(bool, int64_t, const double*)> sink = [&](bool isDown, int64_t node, const double* data) -> int {
+		if(!dUp) { /* first message: n and csLen are known */
+			row = (size_t) t.csLen * 4;
+			const size_t bytes = (size_t) t.n * row * sizeof(double);
+			if((herr = hipMalloc((void**) &dUp, bytes)) != hipSuccess || (herr = hipMalloc((void**) &dDown, bytes)) != hipSuccess ||
+					(herr = hipMemset(dDown, 0, bytes)) != hipSuccess || (herr = hipStreamCreate(&st)) != hipSuccess) return HU_ERR_NOMEM;
+			for(int i = 0; i < 2; ++i) if((herr = hipHostMalloc((void**) &stage[i], row * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
+					(herr = hipEventCreate(&ev[i])) != hipSuccess) return HU_ERR_NOMEM;
+		}
+		if((herr = hipEventSynchronize(ev[turn])) != hipSuccess) return HU_ERR_DEVICE;     /* the copy that last used this staging row */
+		memcpy(stage[turn], data, row * sizeof(double));
+		if((herr = hipMemcpyAsync((isDown ? dDown : dUp) + (size_t) node * row, stage[turn], row * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess ||
+				(herr = hipEventRecord(ev[turn], st)) != hipSuccess) return HU_ERR_DEVICE;
+		turn ^= 1;
+		return HU_OK;
+	};
+	rc = hu_read_ptu_sink(ptu_path, t, &sink);
+	if(rc == HU_OK && st && (herr = hipStreamSynchronize(st)) != hipSuccess) rc = HU_ERR_DEVICE;
+	if(rc != HU_OK) {
+		if(herr != hipSuccess) hu_set_error("hu_db_load: moving the messages to the device failed: %s", hipGetErrorString(herr));
+		cleanup(false); return rc;
+	}
+	if(K > t.csLen) { hu_set_error("HMM profile size is greater than the tree's CS length"); cleanup(false); return HU_ERR_ARG; }
 	hu_profile_desc pd{K, t.csLen, EM.data(), EI.data(), T.data(), p2cs.data()};
 	hu_tree_desc td;
 	memset(&td, 0, sizeof(td));
 	td.n_nodes = t.n; td.cs_len = t.csLen; td.parent = t.parent.data(); td.blen = t.blen.data(); td.seq = t.seq.data();
-	td.up = t.up.data(); td.down = t.down.data(); td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
+	td.up = dUp; td.down = dDown; td.msgs_on_device = 1;
+	td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
 	rc = hu_db_create(&pd, &td, &t.model, device, out);
-	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; }
+	cleanup(rc == HU_OK);
+	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; (*out)->allocs.push_back(dUp); (*out)->allocs.push_back(dDown); }   /* the database owns them */
 	return rc;
+}
+
+/* the reference's own text forms, parsed from memory: what operator<<(ostream&, const BandedHMMP7&) and DNASubModel::write emit */
+extern "C" int hu_profile_parse_text(const char* text, int64_t len, int32_t* K, int32_t* L, double* EM, double* EI, double* T, int32_t* p2cs) {
+	if(!text || len < 0 || !K || !L) { hu_set_error("hu_profile_parse_text: bad argument"); return HU_ERR_ARG; }
+	std::istringstream in(std::string(text, (size_t) len));
+	HuProfileHost prof; std::vector<double> vEM, vEI, vT; std::vector<int32_t> vp; int k = 0, l = 0;
+	int rc = hu_read_hmm_stream(in, "<memory>", prof, vEM, vEI, vT, vp, k, l);
+	if(rc != HU_OK) return rc;
+	*K = k; *L = l;
+	if(EM) memcpy(EM, vEM.data(), vEM.size() * 8); if(EI) memcpy(EI, vEI.data(), vEI.size() * 8);
+	if(T) memcpy(T, vT.data(), vT.size() * 8); if(p2cs) memcpy(p2cs, vp.data(), vp.size() * 4);
+	return HU_OK;
+}
+extern "C" int hu_model_parse_text(const char* text, int64_t len, hu_model_desc* out) {
+	if(!text || len < 0 || !out) { hu_set_error("hu_model_parse_text: bad argument"); return HU_ERR_ARG; }
+	std::istringstream in(std::string(text, (size_t) len));
+	return hu_read_model_text(in, *out);
 }
 
 /* host-only parse of the two files (no device needed): used by the format tests */
@@ -793,7 +850,7 @@ static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKi
 		const bool ok = start[r] >= 0 && start[r] <= end[r] && end[r] < d.csLen && start[r] >= d.winStart && end[r] < d.winStart + d.winLen;
 		a.status = ok ? HU_READ_OK : HU_READ_INVALID;
 		a.csStart = start[r] + 1; a.csEnd = end[r] + 1;
-		if(!ok) { b->hStart[r] = 0; b->hEnd[r] = -1; }
+		if(!ok) { b->hStart[r] = (int32_t) d.winStart; b->hEnd[r] = (int32_t) d.winStart - 1; }   /* empty, inside the resident window */
 	}
 	(void) hipGetLastError();
 	if(n) {

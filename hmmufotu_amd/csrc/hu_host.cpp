@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <limits>
 #include <map>
 #include <sstream>
@@ -219,6 +220,10 @@ int hu_read_hmm(const char* path, HuProfileHost& prof, std::vector<double>& EM, 
 		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L) {
 	std::ifstream in(path);
 	if(!in) { hu_set_error("cannot open HMM file '%s'", path); return HU_ERR_IO; }
+	return hu_read_hmm_stream(in, path, prof, EM, EI, T, p2cs, K, L);
+}
+int hu_read_hmm_stream(std::istream& in, const char* path, HuProfileHost& prof, std::vector<double>& EM, std::vector<double>& EI,
+		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L) {
 	std::string line;
 	K = 0; L = 0;
 	int k = 0;
@@ -301,7 +306,7 @@ struct Rd {
 /* model text block embedded in the .ptu (readers: src/GTR.cpp:43-81, TN93.cpp:40-77,
  * HKY85.cpp:40-75, F81.cpp:40-73, K80.cpp:41-71, JC69.cpp:39-65); consumes exactly the bytes
  * the reference consumes so that the binary dG block that follows stays aligned */
-static int read_model_text(std::ifstream& in, hu_model_desc& m) {
+int hu_read_model_text(std::istream& in, hu_model_desc& m) {
 	memset(&m, 0, sizeof(m));
 	std::string type, tag, line, value;
 	in >> type;
@@ -337,7 +342,11 @@ static int read_model_text(std::ifstream& in, hu_model_desc& m) {
 
 /* PTUnrooted::load (src/PhyloTreeUnrooted.cpp:496-535 and :99-114, :605-621, :632-697,
  * :1068-1083; src/DigitalSeq.cpp:105-121; src/util/ProgEnv.cpp:24-64) */
-int hu_read_ptu(const char* path, HuTreeHost& t) {
+int hu_read_ptu(const char* path, HuTreeHost& t) { return hu_read_ptu_sink(path, t, nullptr); }
+
+/* sink != NULL: the 4 x csLen messages are handed to it one directed edge at a time (is_down, node, data, root flag) instead of
+ * being kept in t.up / t.down: a gg_97-scale file holds 98 GB of them, which hu_db_load sends straight on to the device */
+int hu_read_ptu_sink(const char* path, HuTreeHost& t, const std::function<int(bool, int64_t, const double*)>* sink) {
 	Rd r;
 	r.in.open(path, std::ios::binary);
 	if(!r.in) { hu_set_error("cannot open PTU file '%s'", path); return HU_ERR_IO; }
@@ -370,8 +379,9 @@ int hu_read_ptu(const char* path, HuTreeHost& t) {
 	}
 	uint64_t nEdges = r.get<uint64_t>();
 	if(!r.ok || nEdges != 2 * (n - 1)) { hu_set_error("ptu: edge count %llu does not match %llu nodes", (unsigned long long) nEdges, (unsigned long long) n); return HU_ERR_IO; }
-	t.up.assign((size_t) n * csLen * 4, 0.0);
-	t.down.assign((size_t) n * csLen * 4, 0.0);
+	std::vector<double> one;
+	if(sink) one.resize((size_t) csLen * 4);
+	else { t.up.assign((size_t) n * csLen * 4, 0.0); t.down.assign((size_t) n * csLen * 4, 0.0); }
 	/* first pass cannot know parents before all isParent flags are seen, so keep the edge list */
 	struct Edge { int64_t a, b; bool aParent; double len; std::streampos pos; };
 	std::vector<Edge> edges(nEdges);
@@ -383,15 +393,17 @@ int hu_read_ptu(const char* path, HuTreeHost& t) {
 		if(!r.ok || N != (uint64_t) 4 * csLen || E.a < 0 || E.b < 0 || E.a >= (int64_t) n || E.b >= (int64_t) n) { hu_set_error("ptu: bad edge %llu", (unsigned long long) e); return HU_ERR_IO; }
 		E.pos = r.in.tellg();
 		/* message of a->b: if a is the parent it is down[b], else up[a] */
-		double* dst = E.aParent ? &t.down[(size_t) E.b * csLen * 4] : &t.up[(size_t) E.a * csLen * 4];
+		double* dst = sink ? one.data() : E.aParent ? &t.down[(size_t) E.b * csLen * 4] : &t.up[(size_t) E.a * csLen * 4];
 		r.in.read((char*) dst, sizeof(double) * N);
 		if(!r.in) { r.ok = false; break; }
+		if(sink) { int rc = (*sink)(E.aParent, E.aParent ? E.b : E.a, dst); if(rc != HU_OK) return rc; }
 		if(E.aParent) { t.parent[E.b] = (int32_t) E.a; t.blen[E.b] = E.len; }
 	}
 	int64_t rootId = r.get<int64_t>();
 	if(!r.ok || rootId < 0 || rootId >= (int64_t) n) { hu_set_error("ptu: bad root"); return HU_ERR_IO; }
 	t.root = (int32_t) rootId;
-	r.in.read((char*) &t.up[(size_t) rootId * csLen * 4], sizeof(double) * 4 * csLen);
+	r.in.read((char*) (sink ? one.data() : &t.up[(size_t) rootId * csLen * 4]), sizeof(double) * 4 * csLen);
+	if(sink && r.in) { int rc = (*sink)(false, rootId, one.data()); if(rc != HU_OK) return rc; }
 	for(uint64_t i = 0; i < n; ++i) {
 		int64_t id = r.get<int64_t>(); double h = r.get<double>();
 		if(!r.ok || id < 0 || id >= (int64_t) n) { hu_set_error("ptu: bad height record"); return HU_ERR_IO; }
@@ -400,7 +412,7 @@ int hu_read_ptu(const char* path, HuTreeHost& t) {
 	uint32_t nIdx = r.get<uint32_t>();
 	for(uint32_t i = 0; i < nIdx && r.ok; ++i) { r.get<uint32_t>(); r.get<int64_t>(); }
 	if(!r.ok) { hu_set_error("ptu: truncated file"); return HU_ERR_IO; }
-	int rc = read_model_text(r.in, t.model);
+	int rc = hu_read_model_text(r.in, t.model);
 	if(rc != HU_OK) return rc;
 	bool hasDG = r.get<uint8_t>() != 0;
 	if(hasDG) {

@@ -1201,7 +1201,9 @@ __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __re
 		ok = false;
 		if(lane == 0) alns[r].status = HU_READ_OUT_OF_WINDOW;
 	}
-	const int start = ok ? a.csStart - 1 : 0, end = ok ? a.csEnd - 1 : -1;
+	/* the empty region of a read that is not placed sits at the first resident column: the later stages form message
+	 * addresses from a region's start even when it has no column */
+	const int start = ok ? a.csStart - 1 : (int) db.winStart, end = ok ? a.csEnd - 1 : (int) db.winStart - 1;
 	if(lane == 0) { rstart[r] = start; rend[r] = end; }
 	for(int c = lane; c < db.csLen; c += 64) {
 		char ch = row[c];

@@ -648,3 +648,122 @@ def load_70otus():
     with open(os.path.join(REF_DATA, "70_otus.tree")) as f:
         nwk = f.read().strip()
     return seqs, nwk
+
+
+# ----------------------------------------------------------------------------- config 1: the reference's own fixture
+def parse_newick(nwk: str):
+    """Newick text -> (parent, blen, names) with node ids as PTUnrooted(const NewickTree&) assigns them
+    (src/PhyloTreeUnrooted.cpp:131-182): depth-first from the root with an explicit stack, children pushed in file order,
+    so the LAST child is numbered first; root = 0, parents before children.  Quoted labels and inner labels / support
+    values are kept as names; a missing length is 0."""
+    s = nwk.strip()
+    if s.endswith(";"):
+        s = s[:-1]
+    pos = 0
+
+    def label():
+        nonlocal pos
+        if pos < len(s) and s[pos] == "'":
+            e = s.index("'", pos + 1); out = s[pos + 1:e]; pos = e + 1
+            return out
+        st = pos
+        while pos < len(s) and s[pos] not in ",():;":
+            pos += 1
+        return s[st:pos].strip()
+
+    def node():
+        nonlocal pos
+        kids = []
+        if s[pos] == "(":
+            pos += 1
+            while True:
+                kids.append(node())
+                if s[pos] == ",":
+                    pos += 1; continue
+                if s[pos] == ")":
+                    pos += 1; break
+                raise ValueError("newick: unexpected '%s' at %d" % (s[pos], pos))
+        name = label()
+        length = 0.0
+        if pos < len(s) and s[pos] == ":":
+            pos += 1
+            st = pos
+            while pos < len(s) and s[pos] not in ",();":
+                pos += 1
+            length = float(s[st:pos])
+        return (name, length, kids)
+
+    root = node()
+    parent, blen, names = [], [], []
+    stack = [(root, -1)]
+    while stack:
+        (name, length, kids), par = stack.pop()
+        i = len(parent)
+        parent.append(par); blen.append(length if par >= 0 else 0.0); names.append(name)
+        for k in kids:
+            stack.append((k, i))
+    return np.asarray(parent, np.int32), np.asarray(blen, np.float64), names
+
+
+_IUPAC_FIRST = {"A": 0, "C": 1, "G": 2, "T": 3, "U": 3, "M": 0, "R": 0, "W": 0, "S": 1, "Y": 1, "K": 2, "V": 0, "H": 0, "D": 0, "B": 1, "N": 0}
+
+
+def make_db_70otus(model_name: str = "JC69", dg_k: int = 0, dg_alpha: float = 0.5, min_blen: float = 1e-5) -> SynthDB:
+    """BASELINE.json config 1: a database from the reference's test fixture (test/70_otus.fasta + .tree + taxonomy, copied
+    as data under tests/golden/ref_data) with the reduced hmmufotu-build recipe of SURVEY.md §8d: MSA pruned of its all-gap
+    columns (MSA::prune, src/MSA.cpp:87), tree from the Newick file with the reference's node numbering, leaf branches of
+    length <= 0 set to BRANCH_EPS (fixBranchLength, src/PhyloTreeUnrooted.cpp:289-296), messages for every directed edge by
+    two-pass pruning under the trained model of data/gg_97_otus_<model>.sm, ancestors by per-site argmax, profile from the
+    leaf columns (the HMM training of the reference is out of scope: any valid .hmm is accepted)."""
+    seqs, nwk = load_70otus()
+    parent, blen, names = parse_newick(nwk)
+    n = len(parent)
+    is_leaf = np.ones(n, bool); is_leaf[parent[parent >= 0]] = False
+    L0 = len(next(iter(seqs.values())))
+    raw = np.full((n, L0), -2, np.int8)
+    for i in range(n):
+        if is_leaf[i]:
+            if names[i] not in seqs:
+                raise ValueError("leaf %s has no sequence in the fixture" % names[i])
+            a = np.frombuffer(seqs[names[i]].upper().encode(), np.uint8)
+            row = np.full(L0, -2, np.int8)
+            for ch, code in _IUPAC_FIRST.items():
+                row[a == ord(ch)] = code
+            raw[i] = row
+    keep = (raw[is_leaf] >= 0).any(0)                       # MSA::prune: drop the columns that are all gaps
+    leaf_seq = np.ascontiguousarray(raw[:, keep])
+    cs_len = leaf_seq.shape[1]
+    blen = blen.copy()
+    fix = is_leaf & (parent >= 0) & (blen <= 0)
+    blen[fix] = min_blen
+    model = load_model(model_name)
+    if dg_k > 0:
+        b, r = dgamma(dg_k, dg_alpha); rates = r
+    else:
+        b = np.zeros(0); r = np.zeros(0); rates = np.ones(1)
+    leaf_only = leaf_seq.copy(); leaf_only[~is_leaf] = 0
+    up, down, seq, height = evaluate_tree(parent, blen, leaf_only, is_leaf, model, rates, dg_k > 0)
+    tax = {}
+    with open(os.path.join(REF_DATA, "70_otus_taxonomy.txt")) as f:
+        for line in f:
+            k, _, v = line.rstrip("\n").partition("\t")
+            tax[k] = v
+    annos = [tax.get(names[i], "") if is_leaf[i] else None for i in range(n)]
+    for i in range(n - 1, -1, -1):                            # inner nodes: the common taxonomy prefix of their children
+        if annos[i] is None:
+            ks = [annos[c] for c in np.nonzero(parent == i)[0]]
+            pre = [x.split("; ") for x in ks]
+            com = []
+            for parts in zip(*pre):
+                if all(q == parts[0] for q in parts):
+                    com.append(parts[0])
+                else:
+                    break
+            annos[i] = "; ".join(com)
+    cls = {}
+    anno_id = np.array([cls.setdefault(a, len(cls)) for a in annos], np.int32)
+    leaves = leaf_seq[is_leaf]
+    db = SynthDB(n, cs_len, parent, blen, seq, up, down, height, model, dg_k, dg_alpha, b, r, is_leaf, anno_id, names, annos,
+                 np.zeros(n), (leaves < 0).mean(0))
+    db.hmm = build_hmm(leaves, name="70_otus")
+    return db

@@ -139,6 +139,20 @@ int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu
 		int device, hu_db** out);
 /* same from the reference's on-disk formats (.hmm text, .ptu binary) */
 int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out);
+/* The reference's own TEXT forms, from memory — for a caller that holds loaded reference objects: BandedHMMP7 keeps its cost
+ * matrices private and has no accessors for them (src/BandedHMMP7.h:497-548), but operator<<(ostream&, const BandedHMMP7&)
+ * (src/BandedHMMP7.cpp:324-378) writes exactly what hu_profile_desc wants; likewise DNASubModel::write (src/GTR.cpp:83-104 and
+ * friends).  hu_profile_parse_text: first call with NULL arrays for K and L, then with EM/EI [K+1][4], T [K+1][7], p2cs [K+1].
+ * hu_model_parse_text fills type, pi and par; dg_k / dg_rate are the caller's (DiscreteGammaModel::getK / rate(k)). */
+int hu_profile_parse_text(const char* text, int64_t len, int32_t* K, int32_t* L, double* EM, double* EI, double* T, int32_t* p2cs);
+int hu_model_parse_text(const char* text, int64_t len, hu_model_desc* out);
+/* host-only parse of the two database files (no device needed): sizes with fill = 0, then the arrays a non-NULL pointer names;
+ * up / down [n][cs_len][4] are the whole message set (use it on test-sized files) */
+int hu_files_parse(const char* hmm_path, const char* ptu_path, int32_t* K, int32_t* L, int32_t* n_nodes, int32_t* root,
+		double* EM, double* EI, double* T, int32_t* p2cs, double* entry_cost, double* exit_cost,
+		int32_t* parent, double* blen, int8_t* seq, double* height, double* up, double* down, hu_model_desc* model, int fill);
+/* host-only: the spectral form P(t) = U diag(exp(lam t)) U1 the kernels use for a model (U, U1 [16] row-major, lam [4]) */
+int hu_model_spectral(const hu_model_desc* model, double* U, double* lam, double* U1);
 void hu_db_destroy(hu_db* db);
 int hu_db_info(const hu_db* db, int32_t* K, int32_t* cs_len, int32_t* n_nodes, int32_t* root, int64_t* hbm_bytes);
 /* host copies of what the readers parsed (for format tests); any pointer may be NULL */
