@@ -13,7 +13,11 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -91,7 +95,8 @@ static void usage(const char* p) {
 		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
 		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
-		"            --batch INT [8192]  --gpu INT [0]  -v  -h|--help\n";
+		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
+		"            --inflight INT [3] batches in flight per device  -v  -h|--help\n";
 }
 #define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
 
@@ -105,7 +110,7 @@ struct Slot { Packed f, r; std::vector<std::string> ids, descs; };
 
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
-	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, verbose = 0;
+	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0;
 	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false;
 	std::string alnFn;
 	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
@@ -141,6 +146,8 @@ int main(int argc, char** argv) {
 		else if(a == "--align-only") alignOnly = true;
 		else if(a == "--batch") batch = atoi(val());
 		else if(a == "--gpu") gpu = atoi(val());
+		else if(a == "--gpus") nGpus = atoi(val());
+		else if(a == "--inflight") inflight = atoi(val());
 		else if(a == "-v") verbose++;
 		else if(a == "-S" || a == "--seed" || a == "-p" || a == "--process") (void) val(); /* accepted, no effect: lookups are deterministic */
 		else if(a[0] == '-' && a.size() > 1) { std::cerr << "Error: unknown option " << a << std::endl; usage(argv[0]); return EXIT_FAILURE; }
@@ -157,6 +164,7 @@ int main(int argc, char** argv) {
 	if(prior != "uniform" && prior != "height") { std::cerr << "--prior must be either 'uniform' or 'height'" << std::endl; return EXIT_FAILURE; }
 	/* the chimera options only count with -C (src/hmmufotu.cpp:248-260); checks of :325-340 */
 	if(!checkChimera) { chimeraInfo = false; chiOutFn.clear(); numSeg = 2; chimeraErr = NAN; chimeraLod = 0; }
+	if(nGpus < 1 || nGpus > 64 || inflight < 1 || inflight > 16 || batch < 1) { std::cerr << "--gpus must be in [1, 64], --inflight in [1, 16], --batch positive" << std::endl; return EXIT_FAILURE; }
 	if(numSeg < 2 || numSeg > 6) { std::cerr << "--num-segment must be in [2, 6]" << std::endl; return EXIT_FAILURE; }
 	if(numSeg % 2) { std::cerr << "--num-segment must be an even number" << std::endl; return EXIT_FAILURE; }
 	if(std::isnan(chimeraErr)) chimeraErr = o.max_error / numSeg;
@@ -173,20 +181,29 @@ int main(int argc, char** argv) {
 		return (fn.size() > 6 && fn.compare(fn.size() - 6, 6, ".fastq") == 0) || (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".fq") == 0);
 	};
 
-	hu_db* db = nullptr;
-	CHK(hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), gpu, &db));
+	if(hu_device_count() < (getenv("HU_CLI_SHARE_GPU") ? 1 : nGpus) + gpu) { std::cerr << "Error: " << nGpus << " device(s) from index " << gpu << " asked for, " << hu_device_count() << " gfx950 device(s) visible" << std::endl; return EXIT_FAILURE; }
+	/* one database replica per device (src/hmmufotu.cpp:457-494 loads the one shared copy); loaded side by side */
+	std::vector<hu_db*> dbs(nGpus, nullptr);
+	{
+		std::vector<std::thread> lt; std::vector<int> lrc(nGpus, HU_OK); std::vector<std::string> lmsg(nGpus);
+		const bool share = getenv("HU_CLI_SHARE_GPU") != nullptr;    /* rehearsal of --gpus N on a box with one device: every replica on --gpu */
+		for(int g = 0; g < nGpus; ++g) lt.emplace_back([&, g] { lrc[g] = hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), share ? gpu : gpu + g, &dbs[g]); if(lrc[g] != HU_OK) lmsg[g] = hu_last_error(); });
+		for(auto& t : lt) t.join();
+		for(int g = 0; g < nGpus; ++g) if(lrc[g] != HU_OK) { std::cerr << "Error: " << lmsg[g] << std::endl; return EXIT_FAILURE; }
+	}
+	hu_db* db = dbs[0];
 	int32_t K, L, nNodes, root; int64_t hbm;
 	CHK(hu_db_info(db, &K, &L, &nNodes, &root, &hbm));
-	if(verbose) std::cerr << "database loaded: K=" << K << " csLen=" << L << " nodes=" << nNodes << " HBM=" << hbm / 1e9 << " GB" << std::endl;
+	if(verbose) std::cerr << "database loaded on " << nGpus << " device(s): K=" << K << " csLen=" << L << " nodes=" << nNodes << " HBM=" << hbm / 1e9 << " GB each" << std::endl;
 	std::vector<int32_t> parent(nNodes), p2cs(K + 1); std::vector<int8_t> seq((size_t) nNodes * L);
 	CHK(hu_db_get_tree(db, parent.data(), nullptr, seq.data(), nullptr));
 	CHK(hu_db_get_profile(db, nullptr, nullptr, nullptr, p2cs.data(), nullptr, nullptr));
 	hu_seed_index* ix = nullptr;
 	CHK(hu_seed_index_create(nNodes, L, parent.data(), seq.data(), K, p2cs.data(), seedLen, &ix));
-	if(verbose) std::cerr << "seed index built: " << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers" << std::endl;
-	hu_batch* gb = nullptr; hu_batch* wb = nullptr;
-	CHK(hu_batch_create(db, batch, &gb));
-	if(checkChimera) CHK(hu_batch_create(db, batch, &wb));
+	{ std::vector<int8_t>().swap(seq); }
+	if(verbose) { int64_t np = 0; const int64_t by = hu_seed_index_bytes(ix, &np); std::cerr << "seed index built: " << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers at " << np << " positions, " << by / 1e6 << " MB" << std::endl; }
+	hu_batch* gb = nullptr;
+	CHK(hu_batch_create(db, std::min(batch, std::max(nTest, 1)), &gb));       /* strand detection only */
 
 	/* strand auto-detection on the first nTest reads by alignment cost (src/hmmufotu.cpp:500-542) */
 	if(strand == 0) {
@@ -230,17 +247,44 @@ int main(int argc, char** argv) {
 	}
 	LineOut alnOut;
 	if(!alnFn.empty() && !alnOut.open(alnFn)) { std::cerr << "Unable to write to align file '" << alnFn << "'" << std::endl; return EXIT_FAILURE; }
-	std::vector<hu_chimera_rec> chi;
-	std::vector<hu_align_rec> alnRecs; std::vector<char> alnRows;
-	long flagged = 0;
-
+	hu_batch_destroy(gb); gb = nullptr;
 	std::vector<const char*> annos(nNodes);
 	for(int i = 0; i < nNodes; ++i) annos[i] = hu_db_get_annotation(db, i);
-	long total = 0, placed = 0;
-	auto process = [&](Slot& sl) -> int { /* worker thread: engine + output of one batch */
+
+	/* Four stages, every one on threads of its own, batches numbered in read order:
+	 *   reader (this thread)   parses FASTA / FASTQ into batches
+	 *   seeder                 the seed scans of alignSeq for a batch (hu_seed_index_lookup, itself multi-threaded)
+	 *   engine workers         nGpus x inflight of them, each with its own hu_batch (and work batch for -C) on device w % nGpus:
+	 *                          the batch through the engine, then its lines formatted into strings (65 MB per 8,192 reads: the
+	 *                          formatting of several batches runs side by side)
+	 *   writer                 writes the finished batches in read order
+	 * The reference: one OpenMP task per read, lines in completion order under a critical section (src/hmmufotu.cpp:603-751). */
+	struct Done { std::string mainTxt, chiTxt, alnTxt; long n = 0, placed = 0, flagged = 0; };
+	struct Pipe {
+		std::mutex mu; std::condition_variable cv;
+		std::deque<std::pair<long, std::unique_ptr<Slot>>> parsed, seeded;
+		std::map<long, Done> done;
+		bool readerDone = false, seederDone = false; int workersLeft = 0;
+		int err = HU_OK; std::string msg;
+		void fail(int rc, const std::string& m) { std::lock_guard<std::mutex> lk(mu); if(err == HU_OK) { err = rc; msg = m; } cv.notify_all(); }
+	} P;
+	const auto tLoop = std::chrono::steady_clock::now();
+	/* busy seconds per stage (reported with -v): which stage bounds the pipeline */
+	std::atomic<long long> usParse{0}, usSeed{0}, usEngine{0}, usFormat{0}, usWrite{0};
+	auto usSince = [](std::chrono::steady_clock::time_point t) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
+	const int nWorkers = nGpus * inflight;
+	const size_t depth = (size_t) nWorkers + 2;
+	P.workersLeft = nWorkers;
+	std::vector<hu_batch*> wgb(nWorkers, nullptr), wwb(nWorkers, nullptr);
+	for(int w = 0; w < nWorkers; ++w) { CHK(hu_batch_create(dbs[w % nGpus], batch, &wgb[w])); if(checkChimera) CHK(hu_batch_create(dbs[w % nGpus], batch, &wwb[w])); }
+
+	auto process = [&](int w, Slot& sl, Done& dn) -> int { /* engine worker: one batch through the engine, then its text */
+		hu_batch* gb = wgb[w]; hu_batch* wb = wwb[w];
 		Packed& f = sl.f; Packed& r = sl.r; std::vector<std::string>& ids = sl.ids; std::vector<std::string>& descs = sl.descs;
 		const int n = f.n();
 		int rc;
+		std::vector<hu_chimera_rec> chi;
+		auto tE = std::chrono::steady_clock::now();
 		if((rc = hu_batch_set_reads(gb, n, f.bases.data(), f.offs.data(), f.vp.data(), paired ? r.bases.data() : nullptr, paired ? r.offs.data() : nullptr,
 				paired ? r.vp.data() : nullptr)) != HU_OK) return rc;
 		if(checkChimera) { /* common seeds first, the check on them, then the ordinary estimate/filter/place (src/hmmufotu.cpp:643-733) */
@@ -249,82 +293,131 @@ int main(int argc, char** argv) {
 			if((rc = hu_chimera_batch(gb, wb, &o, &co, chi.data())) != HU_OK) return rc;
 			if(!alignOnly && ((rc = hu_estimate_batch(gb, &o)) != HU_OK || (rc = hu_filter_batch(gb, &o)) != HU_OK || (rc = hu_place_batch(gb, &o)) != HU_OK ||
 					(rc = hu_finish_batch(gb, &o)) != HU_OK)) return rc;
-			for(const hu_chimera_rec& c : chi) flagged += c.is_chimera;
+			for(const hu_chimera_rec& c : chi) dn.flagged += c.is_chimera;
 		}
 		else if((rc = alignOnly ? hu_align_batch(gb, &o) : hu_assign_batch(gb, &o)) != HU_OK) return rc;
+		usEngine += usSince(tE);
+		auto tF = std::chrono::steady_clock::now();
 		const int mainKind = alignOnly ? 2 : 0;
 		std::vector<const char*> pid(n), pdesc(n);
 		for(int i = 0; i < n; ++i) { pid[i] = ids[i].c_str(); pdesc[i] = descs[i].c_str(); }
 		const hu_chimera_rec* cp = checkChimera ? chi.data() : nullptr;
-		const int64_t need = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, nullptr, 0);
+		const char* txt = nullptr;
+		const int64_t need = hu_batch_format_tsv_ptr(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, &txt);
 		if(need < 0) return (int) need;
-		std::string buf((size_t) need, '\0');
-		hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, &buf[0], need);
-		out(buf);
+		dn.mainTxt.assign(txt, (size_t) need);
 		if(alnOut.on) { /* aligned reads that are not chimeras (src/hmmufotu.cpp:709-715; SeqIO::writeFastaSeq, 60 columns) */
-			alnRecs.resize((size_t) n); alnRows.resize((size_t) n * L);
+			std::vector<hu_align_rec> alnRecs((size_t) n); std::vector<char> alnRows((size_t) n * L);
 			if((rc = hu_batch_get_alignments(gb, alnRecs.data(), alnRows.data(), nullptr, 0)) != HU_OK) return rc;
 			for(int i = 0; i < n; ++i) {
 				if(alnRecs[i].status != HU_READ_OK || (cp && cp[i].is_chimera)) continue;
-				const std::string d = descs[i] + ";csStart=" + std::to_string(alnRecs[i].cs_start) + ";csEnd=" + std::to_string(alnRecs[i].cs_end) + ";";
-				alnOut.write(">" + ids[i] + " " + d + "\n");
-				for(int c = 0; c < L; c += 60) { alnOut.write(&alnRows[(size_t) i * L + c], (size_t) std::min(60, L - c)); alnOut.write("\n", 1); }
+				dn.alnTxt += ">" + ids[i] + " " + descs[i] + ";csStart=" + std::to_string(alnRecs[i].cs_start) + ";csEnd=" + std::to_string(alnRecs[i].cs_end) + ";\n";
+				for(int c = 0; c < L; c += 60) { dn.alnTxt.append(&alnRows[(size_t) i * L + c], (size_t) std::min(60, L - c)); dn.alnTxt += '\n'; }
 			}
 		}
 		if(chiOut.on) {
-			const int64_t cneed = hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, nullptr, 0);
+			const char* ctxt = nullptr;
+			const int64_t cneed = hu_batch_format_tsv_ptr(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, &ctxt);
 			if(cneed < 0) return (int) cneed;
-			std::string cbuf((size_t) cneed, '\0');
-			hu_batch_format_tsv_chimera(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, &cbuf[0], cneed);
-			chiOut.write(cbuf);
+			dn.chiTxt.assign(ctxt, (size_t) cneed);
 		}
-		for(char c : buf) if(c == '\n') placed++;
-		total += n;
+		for(char c : dn.mainTxt) if(c == '\n') dn.placed++;
+		dn.n = n;
+		usFormat += usSince(tF);
 		return HU_OK;
 	};
-	std::mutex mu; std::condition_variable cv; std::unique_ptr<Slot> pending; bool finished = false; int werr = HU_OK; std::string wmsg;
-	std::thread worker([&] {
+	std::thread seeder([&] {
 		for(;;) {
-			std::unique_ptr<Slot> sl;
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return pending || finished; }); if(!pending) return; sl = std::move(pending); }
-			cv.notify_all();
-			bool ok; { std::lock_guard<std::mutex> lk(mu); ok = werr == HU_OK; }
-			if(ok) { const int rc = process(*sl); if(rc != HU_OK) { std::lock_guard<std::mutex> lk(mu); werr = rc; wmsg = hu_last_error(); } }
+			std::pair<long, std::unique_ptr<Slot>> job;
+			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || !P.parsed.empty() || P.readerDone; });
+			  if(P.err != HU_OK || P.parsed.empty()) { P.seederDone = true; P.cv.notify_all(); return; }
+			  job = std::move(P.parsed.front()); P.parsed.pop_front(); }
+			P.cv.notify_all();
+			Slot& sl = *job.second; const int n = sl.f.n();
+			auto tS = std::chrono::steady_clock::now();
+			sl.f.vp.assign((size_t) n * 12, 0);
+			int rc = hu_seed_index_lookup(ix, n, sl.f.bases.data(), sl.f.offs.data(), seedRegion, o.align_mode, sl.f.vp.data());
+			if(rc == HU_OK && paired) { sl.r.vp.assign((size_t) n * 12, 0); rc = hu_seed_index_lookup(ix, n, sl.r.bases.data(), sl.r.offs.data(), seedRegion, o.align_mode, sl.r.vp.data()); }
+			usSeed += usSince(tS);
+			if(rc != HU_OK) { P.fail(rc, hu_last_error()); continue; }
+			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || P.seeded.size() < depth; }); P.seeded.push_back(std::move(job)); }
+			P.cv.notify_all();
 		}
 	});
-	struct Joiner { std::mutex& mu; std::condition_variable& cv; bool& fin; std::thread& t;
-		~Joiner() { { std::lock_guard<std::mutex> lk(mu); fin = true; } cv.notify_all(); if(t.joinable()) t.join(); } } joiner{mu, cv, finished, worker};
-	auto submit = [&](std::unique_ptr<Slot>& sl) -> int { /* main thread: seed lookups, then hand the batch to the worker */
-		const int n = sl->f.n();
-		if(n == 0) return HU_OK;
-		int rc;
-		sl->f.vp.assign((size_t) n * 12, 0);
-		if((rc = hu_seed_index_lookup(ix, n, sl->f.bases.data(), sl->f.offs.data(), seedRegion, o.align_mode, sl->f.vp.data())) != HU_OK) return rc;
-		if(paired) { sl->r.vp.assign((size_t) n * 12, 0); if((rc = hu_seed_index_lookup(ix, n, sl->r.bases.data(), sl->r.offs.data(), seedRegion, o.align_mode, sl->r.vp.data())) != HU_OK) return rc; }
-		std::unique_lock<std::mutex> lk(mu);
-		cv.wait(lk, [&] { return !pending; });
-		if(werr != HU_OK) { std::cerr << "Error: " << wmsg << std::endl; return werr; }
-		pending = std::move(sl);
-		lk.unlock(); cv.notify_all();
-		sl.reset(new Slot());
-		return HU_OK;
-	};
-	std::unique_ptr<Slot> cur(new Slot());
-	Read a, b;
-	while(next_read(fin, is_fastq(fwdFn), a) && (!paired || next_read(rin, is_fastq(revFn), b))) {
-		std::string s = a.seq;
-		if(strand == 2 && !paired) s = revcom(s);          /* wrong strand for single-strand reads (src/hmmufotu.cpp:617-618) */
-		cur->f.add(s); cur->ids.push_back(a.id); cur->descs.push_back(a.desc);
-		if(paired) cur->r.add(revcom(b.seq));              /* mates are reverse-complemented at read time (:609) */
-		if(cur->f.n() == batch) { const int rc = submit(cur); if(rc != HU_OK) { if(rc != werr) std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } }
+	std::vector<std::thread> workers;
+	for(int w = 0; w < nWorkers; ++w) workers.emplace_back([&, w] {
+		for(;;) {
+			std::pair<long, std::unique_ptr<Slot>> job;
+			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || !P.seeded.empty() || P.seederDone; });
+			  if(P.err != HU_OK || P.seeded.empty()) { P.workersLeft--; P.cv.notify_all(); return; }
+			  job = std::move(P.seeded.front()); P.seeded.pop_front(); }
+			P.cv.notify_all();
+			Done dn;
+			const int rc = process(w, *job.second, dn);
+			if(rc != HU_OK) { P.fail(rc, hu_last_error()); continue; }
+			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || P.done.size() < depth + (size_t) nWorkers || P.done.empty() || job.first < P.done.begin()->first; });
+			  P.done.emplace(job.first, std::move(dn)); }
+			P.cv.notify_all();
+		}
+	});
+	long total = 0, placed = 0, flagged = 0;
+	std::thread writer([&] {
+		long nextSeq = 0;
+		for(;;) {
+			Done dn;
+			{ std::unique_lock<std::mutex> lk(P.mu);
+			  P.cv.wait(lk, [&] { return P.err != HU_OK || (!P.done.empty() && P.done.begin()->first == nextSeq) || P.workersLeft == 0; });
+			  if(P.err != HU_OK) return;
+			  if(P.done.empty() || P.done.begin()->first != nextSeq) return;      /* every worker has left and nothing is due */
+			  dn = std::move(P.done.begin()->second); P.done.erase(P.done.begin()); }
+			P.cv.notify_all();
+			auto tW = std::chrono::steady_clock::now();
+			out(dn.mainTxt);
+			if(alnOut.on) alnOut.write(dn.alnTxt);
+			if(chiOut.on) chiOut.write(dn.chiTxt);
+			usWrite += usSince(tW);
+			total += dn.n; placed += dn.placed; flagged += dn.flagged;
+			++nextSeq;
+		}
+	});
+	{
+		long seqNo = 0;
+		std::unique_ptr<Slot> cur(new Slot());
+		auto submit = [&]() {
+			if(cur->f.n() == 0) return;
+			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || P.parsed.size() < depth; }); P.parsed.emplace_back(seqNo++, std::move(cur)); }
+			P.cv.notify_all();
+			cur.reset(new Slot());
+		};
+		Read a, b;
+		const bool fq1 = is_fastq(fwdFn), fq2 = paired && is_fastq(revFn);
+		auto tP = std::chrono::steady_clock::now();
+		while(next_read(fin, fq1, a) && (!paired || next_read(rin, fq2, b))) {
+			if(strand == 2 && !paired) cur->f.add(revcom(a.seq));          /* wrong strand for single-strand reads (src/hmmufotu.cpp:617-618) */
+			else cur->f.add(a.seq);
+			cur->ids.push_back(std::move(a.id)); cur->descs.push_back(std::move(a.desc));
+			if(paired) cur->r.add(revcom(b.seq));              /* mates are reverse-complemented at read time (:609) */
+			if(cur->f.n() == batch) { usParse += usSince(tP); submit(); tP = std::chrono::steady_clock::now(); { std::lock_guard<std::mutex> lk(P.mu); if(P.err != HU_OK) break; } }
+		}
+		usParse += usSince(tP);
+		submit();
+		{ std::lock_guard<std::mutex> lk(P.mu); P.readerDone = true; }
+		P.cv.notify_all();
 	}
-	{ const int rc = submit(cur); if(rc != HU_OK) { if(rc != werr) std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } }
-	{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !pending; }); finished = true; }
-	cv.notify_all();
-	worker.join();
-	if(werr != HU_OK) { std::cerr << "Error: " << wmsg << std::endl; return EXIT_FAILURE; }
+	seeder.join();
+	for(auto& t : workers) t.join();
+	writer.join();
+	for(int w = 0; w < nWorkers; ++w) { if(wwb[w]) hu_batch_destroy(wwb[w]); hu_batch_destroy(wgb[w]); }
+	if(P.err != HU_OK) { std::cerr << "Error: " << P.msg << std::endl; return EXIT_FAILURE; }
+	if(verbose) {
+		const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tLoop).count();
+		std::cerr << "read loop: " << total << (paired ? " pairs" : " reads") << " in " << sec << " s = " << (sec > 0 ? total / sec : 0) << " per second (parse + seed lookup + engine + TSV, "
+		          << nGpus << " device(s) x " << inflight << " batches in flight)" << std::endl;
+		std::cerr << "stage busy seconds: parse " << usParse / 1e6 << " (1 thread), seed lookup " << usSeed / 1e6 << " (1 thread driving <= 16), engine " << usEngine / 1e6
+		          << " + format " << usFormat / 1e6 << " (summed over " << nWorkers << " workers), write " << usWrite / 1e6 << " (1 thread)" << std::endl;
+	}
 	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << (checkChimera ? ", " + std::to_string(flagged) + " flagged as chimera" : std::string()) << std::endl;
-	if(wb) hu_batch_destroy(wb);
-	hu_batch_destroy(gb); hu_seed_index_destroy(ix); hu_db_destroy(db);
+	hu_seed_index_destroy(ix);
+	for(hu_db* d : dbs) hu_db_destroy(d);
 	return EXIT_SUCCESS;
 }

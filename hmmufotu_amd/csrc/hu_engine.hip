@@ -658,6 +658,8 @@ struct hu_batch {
 	std::vector<HostPlace> places;    /* candidates in filterPlacements order, all reads */
 	std::vector<HostPlace> tmpPlaces;
 	std::vector<hu_place_rec> best;
+	PinnedVec<char> hRows;            /* alignment rows of the last format call */
+	std::vector<char> tsvBuf; std::vector<size_t> tsvOff, tsvLen; size_t tsvSize = 0;
 	int maxRegion = 0;
 };
 
@@ -1581,63 +1583,105 @@ extern "C" const char* hu_tsv_header(void) {
 	       "branch_id\tbranch_ratio\ttaxon_id\ttaxon_anno\tanno_dist\tloglik\tQ_placement\tQ_taxon";
 }
 
-/* operator<<(ostream&, double) at default precision == printf("%g") */
-static void put_g(std::string& o, double v) { char t[40]; snprintf(t, sizeof(t), "%g", v); o += t; }
 
 /* which = 0: the assignment file (reads that are HU_READ_OK and not flagged); which = 1: --chimera-out (bad PE orientation
  * or flagged by the check; the placement columns are a default-constructed PTPlacement, src/hmmufotu.cpp:693-706);
  * which = 2: the assignment file of --align-only (as 0, nothing placed: default placement columns, :717-739) */
 static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
-		const hu_chimera_rec* chi, int info, int which, char* buf, int64_t cap) {
+		const hu_chimera_rec* chi, int info, int which) {
 	if(!b || !ids) { hu_set_error("hu_batch_format_tsv: bad argument"); return HU_ERR_ARG; }
 	if((which == 0 && b->state < ST_FINISHED) || b->state < ST_ALIGNED || b->fromCodes) { hu_set_error("hu_batch_format_tsv: batch is not finished"); return HU_ERR_STATE; }
 	const int L = b->db->dev.csLen;
-	std::vector<char> rows((size_t) b->n * L);
+	/* the alignment rows (csLen bytes per read: 63 MB per 8,192 reads) come through a page-locked buffer the batch keeps */
+	b->hRows.resize((size_t) b->n * L);
 	if(b->n) {
-		if(hipSetDevice(b->db->device) != hipSuccess || hipMemcpyAsync(rows.data(), b->dRows.p, rows.size(), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+		if(hipSetDevice(b->db->device) != hipSuccess || hipMemcpyAsync(b->hRows.data(), b->dRows.p, b->hRows.size(), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
 				hipStreamSynchronize(b->stream) != hipSuccess) { hu_set_error("hu_batch_format_tsv: device copy failed"); return HU_ERR_DEVICE; }
 	}
-	std::string o;
-	for(int r = 0; r < b->n; ++r) {
+	/* lines are written per read into slices of one buffer, the reads spread over the host pool: pass 1 sizes, pass 2 fills */
+	const size_t n = (size_t) b->n;
+	std::vector<size_t>& off = b->tsvOff;
+	off.assign(n + 1, 0);
+	auto put_int = [](char* p, long v) -> char* { char t[24]; int k = 0; unsigned long u = v < 0 ? 0ul - (unsigned long) v : (unsigned long) v; do { t[k++] = (char)('0' + u % 10); u /= 10; } while(u); if(v < 0) *p++ = '-'; while(k) *p++ = t[--k]; return p; };
+	auto put_gd = [](char* p, double v) -> char* { return p + snprintf(p, 40, "%g", v); };   /* operator<<(ostream&, double) at default precision == printf("%g") */
+	auto put_s = [](char* p, const char* s) -> char* { const size_t k = strlen(s); memcpy(p, s, k); return p + k; };
+	auto wanted = [&](size_t r) {
 		const HuAlnDev& a = b->hAlns[r];
 		const bool flagged = chi && a.status == HU_READ_OK && chi[r].is_chimera;
-		if(which != 1 ? (a.status != HU_READ_OK || flagged) : !(a.status == HU_READ_CHIMERA || flagged)) continue;
-		o += ids[r]; o += '\t'; if(descs && descs[r]) o += descs[r]; o += '\t';
-		o += std::to_string(a.seqStart) + "\t" + std::to_string(a.seqEnd) + "\t" + std::to_string(a.hmmStart) + "\t" + std::to_string(a.hmmEnd) + "\t" +
-				std::to_string(a.csStart) + "\t" + std::to_string(a.csEnd) + "\t";
-		put_g(o, a.cost); o += '\t';
-		o.append(&rows[(size_t) r * L], L); o += '\t';
+		return which != 1 ? !(a.status != HU_READ_OK || flagged) : (a.status == HU_READ_CHIMERA || flagged);
+	};
+	parallel_for(n, [&](size_t r) { /* an upper bound of the line's length */
+		if(!wanted(r)) { off[r + 1] = 0; return; }
+		size_t len = strlen(ids[r]) + (descs && descs[r] ? strlen(descs[r]) : 0) + (size_t) L + 6 * 12 + 40 + 16 /* tabs, newline */ + 2 * 12 + 16 + 12 + 5 * 40;
+		if(info) {
+			const bool ck = chi && b->hAlns[r].status == HU_READ_OK && chi[r].checked;
+			const int32_t t5 = ck ? chi[r].seg5.a_node : -1, t3 = ck ? chi[r].seg3.a_node : -1;
+			len += 2 * 12 + 40 + 8 + (t5 >= 0 ? (annos && annos[t5] ? strlen(annos[t5]) : 0) : 10) + (t3 >= 0 ? (annos && annos[t3] ? strlen(annos[t3]) : 0) : 10);
+		}
+		if(which == 0 && b->best[r].c_node >= 0) len += annos && annos[b->best[r].a_node] ? strlen(annos[b->best[r].a_node]) : 0;
+		else len += 48;
+		off[r + 1] = len;
+	});
+	for(size_t r = 0; r < n; ++r) off[r + 1] += off[r];
+	std::vector<char>& buf = b->tsvBuf;
+	if(buf.size() < off[n] + 1) buf.resize(off[n] + 1);
+	std::vector<size_t>& used = b->tsvLen;
+	used.assign(n, 0);
+	parallel_for(n, [&](size_t r) {
+		if(off[r + 1] == off[r]) return;
+		const HuAlnDev& a = b->hAlns[r];
+		char* p0 = buf.data() + off[r]; char* p = p0;
+		p = put_s(p, ids[r]); *p++ = '\t'; if(descs && descs[r]) p = put_s(p, descs[r]); *p++ = '\t';
+		p = put_int(p, a.seqStart); *p++ = '\t'; p = put_int(p, a.seqEnd); *p++ = '\t'; p = put_int(p, a.hmmStart); *p++ = '\t'; p = put_int(p, a.hmmEnd); *p++ = '\t';
+		p = put_int(p, a.csStart); *p++ = '\t'; p = put_int(p, a.csEnd); *p++ = '\t';
+		p = put_gd(p, a.cost); *p++ = '\t';
+		memcpy(p, &b->hRows[r * (size_t) L], (size_t) L); p += L; *p++ = '\t';
 		if(info) { /* CHIMERA_TSV_HEADER columns (src/hmmufotu.cpp:57, 701-705, 742-746); unchecked reads print default placements */
 			const bool ck = chi && a.status == HU_READ_OK && chi[r].checked;
 			const int32_t t5 = ck ? chi[r].seg5.a_node : -1, t3 = ck ? chi[r].seg3.a_node : -1;
-			o += std::to_string(t5) + "\t" + std::to_string(t3) + "\t";
-			if(t5 >= 0) { if(annos && annos[t5]) o += annos[t5]; } else o += "UNASSIGNED";
-			o += '\t';
-			if(t3 >= 0) { if(annos && annos[t3]) o += annos[t3]; } else o += "UNASSIGNED";
-			o += '\t';
-			put_g(o, ck ? chi[r].lod : NAN); o += '\t';
+			p = put_int(p, t5); *p++ = '\t'; p = put_int(p, t3); *p++ = '\t';
+			if(t5 >= 0) { if(annos && annos[t5]) p = put_s(p, annos[t5]); } else p = put_s(p, "UNASSIGNED");
+			*p++ = '\t';
+			if(t3 >= 0) { if(annos && annos[t3]) p = put_s(p, annos[t3]); } else p = put_s(p, "UNASSIGNED");
+			*p++ = '\t';
+			p = put_gd(p, ck ? chi[r].lod : NAN); *p++ = '\t';
 		}
 		hu_place_rec none; none.c_node = -1;
-		const hu_place_rec& p = which == 0 ? b->best[r] : none;
-		if(p.c_node >= 0) {
-			o += std::to_string(p.c_node) + "->" + std::to_string(p.p_node) + "\t"; put_g(o, p.ratio); o += '\t';
-			o += std::to_string(p.a_node) + "\t"; if(annos && annos[p.a_node]) o += annos[p.a_node]; o += '\t';
-			put_g(o, p.anno_dist); o += '\t'; put_g(o, p.loglik); o += '\t'; put_g(o, p.q_place); o += '\t'; put_g(o, p.q_taxon);
+		const hu_place_rec& pl = which == 0 ? b->best[r] : none;
+		if(pl.c_node >= 0) {
+			p = put_int(p, pl.c_node); *p++ = '-'; *p++ = '>'; p = put_int(p, pl.p_node); *p++ = '\t'; p = put_gd(p, pl.ratio); *p++ = '\t';
+			p = put_int(p, pl.a_node); *p++ = '\t'; if(annos && annos[pl.a_node]) p = put_s(p, annos[pl.a_node]); *p++ = '\t';
+			p = put_gd(p, pl.anno_dist); *p++ = '\t'; p = put_gd(p, pl.loglik); *p++ = '\t'; p = put_gd(p, pl.q_place); *p++ = '\t'; p = put_gd(p, pl.q_taxon);
 		}
-		else o += "NULL\tnan\t-1\tUNASSIGNED\tnan\tnan\tnan\tnan"; /* default-constructed PTPlacement (src/PhyloTreeUnrooted.cpp:60-65) */
-		o += '\n';
-	}
-	if(buf && cap > 0) { const size_t m = std::min<size_t>((size_t) cap, o.size()); memcpy(buf, o.data(), m); }
-	return (int64_t) o.size();
+		else p = put_s(p, "NULL\tnan\t-1\tUNASSIGNED\tnan\tnan\tnan\tnan"); /* default-constructed PTPlacement (src/PhyloTreeUnrooted.cpp:60-65) */
+		*p++ = '\n';
+		used[r] = (size_t)(p - p0);
+	});
+	/* close the gaps between the slices (each was sized by an upper bound) */
+	size_t w = 0;
+	for(size_t r = 0; r < n; ++r) { if(used[r]) { if(w != off[r]) memmove(buf.data() + w, buf.data() + off[r], used[r]); w += used[r]; } }
+	b->tsvSize = w;
+	return (int64_t) w;
+}
+static int64_t format_copy(hu_batch* b, int64_t need, char* buf, int64_t cap) {
+	if(need > 0 && buf && cap > 0) memcpy(buf, b->tsvBuf.data(), (size_t) std::min<int64_t>(cap, need));
+	return need;
 }
 extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		char* buf, int64_t cap) {
-	return format_tsv_impl(b, ids, descs, annos, nullptr, 0, 0, buf, cap);
+	return format_copy(b, format_tsv_impl(b, ids, descs, annos, nullptr, 0, 0), buf, cap);
 }
 extern "C" int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap) {
 	if(which < 0 || which > 2) { hu_set_error("hu_batch_format_tsv_chimera: which must be 0, 1 or 2"); return HU_ERR_ARG; }
-	return format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which, buf, cap);
+	return format_copy(b, format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which), buf, cap);
+}
+extern "C" int64_t hu_batch_format_tsv_ptr(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		const hu_chimera_rec* chi, int chimera_info, int which, const char** text) {
+	if(which < 0 || which > 2 || !text) { hu_set_error("hu_batch_format_tsv_ptr: bad argument"); return HU_ERR_ARG; }
+	const int64_t need = format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which);
+	*text = need >= 0 ? b->tsvBuf.data() : nullptr;
+	return need;
 }
 extern "C" const char* hu_tsv_header_chimera(void) {
 	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"

@@ -1,25 +1,43 @@
 // Host seed lookup: what CSFMIndex::locateOne + buildAlignPath give alignSeq
-// (src/HmmUFOtu_main.cpp:50-84, src/CSFMIndex.cpp:121-147,262-273, src/BandedHMMP7.cpp:894-941),
-// served by a plain hash index over the k-mers of the leaf sequences instead of the reference's
-// RRR-wavelet-tree FM-index (libcds).  Two deliberate differences: the k-mer length is fixed when
-// the index is built, and among several occurrences the FIRST (lowest leaf id, lowest position)
-// is taken where the reference draws one with rand() — deterministic output.
+// (src/HmmUFOtu_main.cpp:50-84, src/CSFMIndex.cpp:121-147, 252-273, src/BandedHMMP7.cpp:894-941).
+//
+// The reference indexes the concatenation of the gap-free MSA rows (one separator per sequence,
+// CSFMIndex::buildConcatSeq src/CSFMIndex.cpp:288-330) with an FM-index — suffix array by libdivsufsort, BWT in
+// an RRR wavelet tree, SA sampled every SA_SAMPLE_RATE — searches a seed backwards, and takes ONE hit of the
+// suffix-array range: a random one (locateOne, rand() under OpenMP tasks: SURVEY F7) or the first
+// (locateFirst, :92-119).  A hit is a start position in the concatenation; concat2CS maps it and its
+// last base to CS columns, extractCS rebuilds the gapped CS string between them.
+//
+// Here the same text is indexed by a PREFIX-SORTED position array: every position whose seed_len-mer lies
+// inside one sequence, ordered by the 32 symbols that start there (2 bits per base, zero-padded at the end of
+// its sequence), then by position — the suffix array of the reference truncated at depth 32 — plus a
+// directory over the first 12 bases.  A lookup is one directory read and a binary search that extracts the
+// k-mers it compares from the 2-bit text.  The hit taken is the FIRST of the range, i.e. locateFirst's
+// choice whenever the candidates differ within 32 symbols (else the lowest text position): deterministic, and
+// a member of the reference's own hit set.  Sequences are taken in node-id order of the leaves (the
+// reference: MSA row order; the .ptu keeps the map, the engine does not need it).
+// Resident: 4 B (position) + 2 B (CS column) + 0.25 B (text) per residue + 64 MiB of directory: 0.95 GB for the
+// 1.4 x 10^8 residues of a gg_97-scale MSA (the hash table this replaces held ~5 GB).
 #include <algorithm>
 #include <atomic>
 #include <thread>
 #include <cstring>
 #include <string>
-#include <unordered_map>
 #include <vector>
 #include "hu_common.h"
 
+#define HU_SX_DIRK 12      /* bases of the directory key */
+
 struct hu_seed_index {
 	int seedLen = 0, csLen = 0, K = 0;
+	int64_t nRes = 0;
 	std::vector<int32_t> cs2p;                       /* getProfileLoc */
-	std::vector<int32_t> leafStart;                  /* per indexed leaf: offset into cols/codes */
-	std::vector<uint16_t> cols;                      /* 0-based CS column of every residue, leaves concatenated */
-	std::vector<int8_t> codes;
-	std::unordered_map<uint64_t, uint64_t> first;    /* packed k-mer -> (leaf << 32 | pos), first occurrence */
+	std::vector<uint32_t> seqEnd;                    /* per indexed sequence: one past its last residue */
+	std::vector<uint16_t> cols;                      /* concat2CS (0-based here): CS column of every residue */
+	std::vector<uint64_t> text;                      /* residues, 2 bits each, 32 per word, first base in the top bits */
+	std::vector<uint32_t> sa;                        /* positions in (32-symbol prefix, position) order */
+	std::vector<uint32_t> dir;                       /* [4^12 + 1] first sa index of every 12-base prefix */
+	int64_t distinct = 0;
 };
 
 static int8_t sym_code(char c) {
@@ -32,10 +50,18 @@ static int8_t sym_code(char c) {
 	}
 }
 
+/* the 32 symbols starting at residue p, first base in the top bits (may run past the sequence: the caller masks) */
+static inline uint64_t window32(const std::vector<uint64_t>& text, uint64_t p) {
+	const uint64_t w = p >> 5; const unsigned s = (unsigned)(p & 31) * 2;
+	const uint64_t hi = text[w] << s;
+	return s ? hi | (text[w + 1] >> (64 - s)) : hi;
+}
+static inline uint64_t keep_top(uint64_t v, int nsym) { return nsym >= 32 ? v : nsym <= 0 ? 0 : v & ~((~0ull) >> (2 * nsym)); }
+
 extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
 		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) {
-	if(!parent || !seq || !p2cs || !out || n_nodes < 1 || cs_len < 1 || cs_len > 65535 || seed_len < 8 || seed_len > 31) {
-		hu_set_error("hu_seed_index_create: bad argument"); return HU_ERR_ARG;
+	if(!parent || !seq || !p2cs || !out || n_nodes < 1 || cs_len < 1 || cs_len > 65535 || seed_len < HU_SX_DIRK || seed_len > 31) {
+		hu_set_error("hu_seed_index_create: bad argument (seed length must be in %d..31)", HU_SX_DIRK); return HU_ERR_ARG;
 	}
 	hu_seed_index* ix = new hu_seed_index;
 	ix->seedLen = seed_len; ix->csLen = cs_len; ix->K = K;
@@ -44,55 +70,136 @@ extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32
 	for(int i = p2cs[K] + 1; i <= cs_len; ++i) ix->cs2p[i] = K;   /* extend_index */
 	std::vector<char> hasChild(n_nodes, 0);
 	for(int i = 0; i < n_nodes; ++i) if(parent[i] >= 0 && parent[i] < n_nodes) hasChild[parent[i]] = 1;
-	const uint64_t mask = (seed_len == 32) ? ~0ull : ((1ull << (2 * seed_len)) - 1);
+	/* residues of the leaves, concatenated (the CSFM index holds the MSA = leaf sequences only) */
+	int64_t total = 0;
+	for(int i = 0; i < n_nodes; ++i) if(!hasChild[i]) { const int8_t* s = seq + (size_t) i * cs_len; for(int c = 0; c < cs_len; ++c) total += s[c] >= 0; }
+	if(total >= (1ll << 32) - 64) { delete ix; hu_set_error("hu_seed_index_create: more than 2^32 residues"); return HU_ERR_ARG; }
+	ix->nRes = total;
+	ix->cols.resize((size_t) total);
+	ix->text.assign((size_t)(total / 32 + 3), 0);
+	int64_t at = 0;
 	for(int i = 0; i < n_nodes; ++i) {
-		if(hasChild[i]) continue; /* the CSFM index holds the MSA (= leaf) sequences only */
+		if(hasChild[i]) continue;
 		const int8_t* s = seq + (size_t) i * cs_len;
-		const int32_t leaf = (int32_t) ix->leafStart.size();
-		ix->leafStart.push_back((int32_t) ix->cols.size());
-		uint64_t key = 0; int run = 0; int pos = 0;
 		for(int c = 0; c < cs_len; ++c) {
 			if(s[c] < 0) continue;
-			ix->cols.push_back((uint16_t) c); ix->codes.push_back(s[c]);
-			key = ((key << 2) | (uint64_t) s[c]) & mask;
-			if(++run >= seed_len) ix->first.emplace(key, ((uint64_t) leaf << 32) | (uint32_t)(pos - seed_len + 1));
-			++pos;
+			ix->cols[(size_t) at] = (uint16_t) c;
+			ix->text[(size_t)(at >> 5)] |= (uint64_t)(s[c] & 3) << (62 - 2 * (int)(at & 31));
+			++at;
+		}
+		ix->seqEnd.push_back((uint32_t) at);
+	}
+	/* positions whose seed lies inside one sequence, with their masked 32-symbol keys */
+	struct Ent { uint64_t key; uint32_t pos; };
+	std::vector<Ent> ents;
+	ents.reserve((size_t) total);
+	{
+		uint32_t b = 0;
+		for(size_t q = 0; q < ix->seqEnd.size(); ++q) {
+			const uint32_t e = ix->seqEnd[q];
+			for(uint32_t p = b; p + (uint32_t) seed_len <= e; ++p) ents.push_back(Ent{keep_top(window32(ix->text, p), (int)(e - p)), p});
+			b = e;
 		}
 	}
-	ix->leafStart.push_back((int32_t) ix->cols.size());
+	/* sort by (key, pos): 256 buckets by the first four bases, sorted in parallel */
+	{
+		std::vector<size_t> cnt(257, 0);
+		for(const Ent& e : ents) cnt[(e.key >> 56) + 1]++;
+		for(int i = 0; i < 256; ++i) cnt[i + 1] += cnt[i];
+		std::vector<Ent> tmp(ents.size());
+		{ std::vector<size_t> w(cnt.begin(), cnt.end() - 1); for(const Ent& e : ents) tmp[w[e.key >> 56]++] = e; }
+		ents.swap(tmp);
+		tmp.clear(); tmp.shrink_to_fit();
+		unsigned nt = std::thread::hardware_concurrency(); if(nt > 16) nt = 16; if(nt < 1) nt = 1;
+		std::atomic<int> next{0};
+		auto work = [&] { for(;;) { const int b = next.fetch_add(1); if(b >= 256) break;
+			std::sort(ents.begin() + cnt[b], ents.begin() + cnt[b + 1], [](const Ent& x, const Ent& y) { return x.key != y.key ? x.key < y.key : x.pos < y.pos; }); } };
+		std::vector<std::thread> th;
+		for(unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for(auto& t : th) t.join();
+	}
+	ix->sa.resize(ents.size());
+	ix->dir.assign(((size_t) 1 << (2 * HU_SX_DIRK)) + 1, 0);
+	const uint64_t kmask = ~((~0ull) >> (2 * seed_len));
+	uint64_t lastK = ~0ull;
+	for(size_t i = 0; i < ents.size(); ++i) {
+		ix->sa[i] = ents[i].pos;
+		ix->dir[(size_t)(ents[i].key >> (64 - 2 * HU_SX_DIRK)) + 1]++;
+		const uint64_t km = ents[i].key & kmask;
+		if(km != lastK || i == 0) { ix->distinct++; lastK = km; }
+	}
+	for(size_t i = 1; i < ix->dir.size(); ++i) ix->dir[i] += ix->dir[i - 1];
 	*out = ix;
 	return HU_OK;
 }
 extern "C" void hu_seed_index_destroy(hu_seed_index* ix) { delete ix; }
-extern "C" int64_t hu_seed_index_size(const hu_seed_index* ix) { return ix ? (int64_t) ix->first.size() : 0; }
+/* number of distinct seed_len-mers indexed */
+extern "C" int64_t hu_seed_index_size(const hu_seed_index* ix) { return ix ? ix->distinct : 0; }
+/* resident bytes of the index; positions = number of indexed k-mer starts */
+extern "C" int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions) {
+	if(!ix) return 0;
+	if(positions) *positions = (int64_t) ix->sa.size();
+	return (int64_t)(ix->sa.size() * 4 + ix->dir.size() * 4 + ix->cols.size() * 2 + ix->text.size() * 8 + ix->seqEnd.size() * 4 + ix->cs2p.size() * 4);
+}
 
-/* locateOne + buildAlignPath for the k-mer read[from0 .. from0+seedLen): returns 1 and fills out6 when
+/* locateFirst + buildAlignPath for the k-mer read[from0 .. from0+seedLen): returns 1 and fills out6 when
  * the k-mer occurs and yields a valid path, else 0 */
 static int lookup_one(const hu_seed_index* ix, const char* read, int from0, int32_t* out6) {
+	const int k = ix->seedLen;
 	uint64_t key = 0;
-	for(int i = 0; i < ix->seedLen; ++i) { const int8_t c = sym_code(read[from0 + i]); if(c < 0) return 0; key = (key << 2) | (uint64_t) c; }
-	auto it = ix->first.find(key);
-	if(it == ix->first.end()) return 0;
-	const int32_t leaf = (int32_t)(it->second >> 32), pos = (int32_t)(it->second & 0xffffffffu);
-	const uint16_t* cols = &ix->cols[ix->leafStart[leaf] + pos];
-	/* CSLoc: 1-based start/end, CS string with '-' wherever the hit sequence has no residue; walked
+	for(int i = 0; i < k; ++i) { const int8_t c = sym_code(read[from0 + i]); if(c < 0) return 0; key |= (uint64_t) c << (62 - 2 * i); }
+	const size_t b = (size_t)(key >> (64 - 2 * HU_SX_DIRK));
+	size_t lo = ix->dir[b], hi = ix->dir[b + 1];
+	while(lo < hi) { /* first entry whose k-mer is >= the query (entries are ordered by their 32-symbol prefix, hence by k-mer) */
+		const size_t mid = (lo + hi) >> 1;
+		if(keep_top(window32(ix->text, ix->sa[mid]), k) < key) lo = mid + 1; else hi = mid;
+	}
+	if(lo >= ix->dir[b + 1] || keep_top(window32(ix->text, ix->sa[lo]), k) != key) return 0;
+	const uint16_t* cols = &ix->cols[ix->sa[lo]];
+	/* CSLoc: 1-based start/end, CS string with '-' wherever the hit sequence has no residue (extractCS); walked
 	 * exactly like buildAlignPath does (i over the read, j over CS columns) */
-	const int csStart = cols[0] + 1, csEnd = cols[ix->seedLen - 1] + 1;
+	const int csStart = cols[0] + 1, csEnd = cols[k - 1] + 1;
 	if(!(csStart > 0 && csStart < csEnd)) return 0; /* CSLoc::isValid */
 	int start = 0, end = 0, from = 0, to = 0, nIns = 0, nDel = 0;
 	int i = from0 + 1, r = 0;
 	for(int j = csStart; j <= csEnd; ++j) {
-		const int k = ix->cs2p[j];
+		const int kk = ix->cs2p[j];
 		const bool nonGap = (cols[r] + 1 == j);
 		if(from == 0 && nonGap) from = i;
 		if(nonGap) to = i;
-		if(k != 0) { if(start == 0) start = k; end = k; if(!nonGap) nDel++; }
+		if(kk != 0) { if(start == 0) start = kk; end = kk; if(!nonGap) nDel++; }
 		else if(nonGap) nIns++;
 		if(nonGap) { ++i; ++r; }
 	}
 	if(!(start > 0 && start <= end && from > 0 && from <= to)) return 0; /* ViterbiAlignPath::isValid */
 	out6[0] = start; out6[1] = end; out6[2] = from; out6[3] = to; out6[4] = nIns; out6[5] = nDel;
 	return 1;
+}
+
+/* every occurrence of one seed, in index order: (sequence, residue offset in it, first CS column 0-based); for tests of
+ * the hit semantics.  Returns the number of occurrences (cap entries written). */
+extern "C" int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap) {
+	if(!ix || !kmer) return 0;
+	const int k = ix->seedLen;
+	uint64_t key = 0;
+	for(int i = 0; i < k; ++i) { const int8_t c = sym_code(kmer[i]); if(c < 0) return 0; key |= (uint64_t) c << (62 - 2 * i); }
+	const size_t b = (size_t)(key >> (64 - 2 * HU_SX_DIRK));
+	int64_t n = 0;
+	for(size_t i = ix->dir[b]; i < ix->dir[b + 1]; ++i) {
+		const uint32_t p = ix->sa[i];
+		const uint64_t km = keep_top(window32(ix->text, p), k);
+		if(km < key) continue;
+		if(km > key) break;
+		if(n < cap) {
+			const size_t q = std::upper_bound(ix->seqEnd.begin(), ix->seqEnd.end(), p) - ix->seqEnd.begin();
+			if(seq_no) seq_no[n] = (int32_t) q;
+			if(offset) offset[n] = (int32_t)(p - (q ? ix->seqEnd[q - 1] : 0));
+			if(cs_col) cs_col[n] = ix->cols[p];
+		}
+		++n;
+	}
+	return n;
 }
 
 /* the two seed scans of alignSeq (src/HmmUFOtu_main.cpp:50-84) for n reads; vpaths [n][2][6] */

@@ -200,8 +200,19 @@ class SeedIndex:
         self.h = C.c_void_p()
         _chk(load_library().hu_seed_index_create(C.c_int32(n), C.c_int32(L), _p(self.parent, C.c_int32), _p(self.seq, C.c_int8),
                                                  C.c_int32(int(hmm.K)), _p(self.p2cs, C.c_int32), C.c_int32(seed_len), C.byref(self.h)))
-        lib = load_library(); lib.hu_seed_index_size.restype = C.c_int64
+        lib = load_library(); lib.hu_seed_index_size.restype = C.c_int64; lib.hu_seed_index_bytes.restype = C.c_int64
+        lib.hu_seed_index_occurrences.restype = C.c_int64
         self.size = int(lib.hu_seed_index_size(self.h))
+        npos = C.c_int64(0)
+        self.bytes = int(lib.hu_seed_index_bytes(self.h, C.byref(npos)))
+        self.positions = int(npos.value)
+
+    def occurrences(self, kmer: str, cap=4096):
+        """all occurrences of one seed in index order: (sequence number, offset in it, first CS column)"""
+        a = np.zeros(cap, np.int32); b = np.zeros(cap, np.int32); c = np.zeros(cap, np.int32)
+        n = int(load_library().hu_seed_index_occurrences(self.h, kmer.encode(), _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32), C.c_int64(cap)))
+        m = min(n, cap)
+        return n, a[:m], b[:m], c[:m]
 
     def lookup(self, reads, seed_region=50, align_mode=0):
         n = len(reads)
@@ -450,6 +461,26 @@ class Batch:
         return out
 
     def format_tsv(self, ids, descs=None, annos=None) -> str:
+        return self.format_tsv_chimera(ids, descs, annos, None, False, 0)
+
+    def format_tsv_chimera(self, ids, descs=None, annos=None, chimera=None, chimera_info=False, which=0) -> str:
+        """Assignment lines: which=0 the main file, which=1 --chimera-out, which=2 --align-only (src/hmmufotu.cpp:693-747)."""
+        lib = load_library()
+        lib.hu_batch_format_tsv_ptr.restype = C.c_int64
+        arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
+        a_ids, a_desc, a_anno = arr(ids), arr(descs), arr(annos)
+        cp = None
+        if chimera is not None:
+            chimera = np.ascontiguousarray(chimera, CHIMERA_DTYPE); assert len(chimera) == self.n
+            cp = chimera.ctypes.data_as(C.c_void_p)
+        txt = C.c_char_p()
+        need = lib.hu_batch_format_tsv_ptr(self.h, a_ids, a_desc, a_anno, cp, C.c_int(int(chimera_info)), C.c_int(which), C.byref(txt))
+        if need < 0:
+            _chk(int(need))
+        return C.string_at(txt, need).decode("latin1") if need else ""
+
+    def format_tsv_copy(self, ids, descs=None, annos=None) -> str:
+        """the (buf, cap) form of the ABI: size first, then the copy"""
         lib = load_library()
         lib.hu_batch_format_tsv.restype = C.c_int64
         arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
@@ -459,24 +490,6 @@ class Batch:
             _chk(int(need))
         buf = C.create_string_buffer(int(need) + 1)
         lib.hu_batch_format_tsv(self.h, a_ids, a_desc, a_anno, buf, C.c_int64(need))
-        return buf.raw[:need].decode("latin1")
-
-    def format_tsv_chimera(self, ids, descs=None, annos=None, chimera=None, chimera_info=False, which=0) -> str:
-        """Assignment lines with -C: which=0 the main file, which=1 --chimera-out (src/hmmufotu.cpp:693-747)."""
-        lib = load_library()
-        lib.hu_batch_format_tsv_chimera.restype = C.c_int64
-        arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
-        a_ids, a_desc, a_anno = arr(ids), arr(descs), arr(annos)
-        cp = None
-        if chimera is not None:
-            chimera = np.ascontiguousarray(chimera, CHIMERA_DTYPE); assert len(chimera) == self.n
-            cp = chimera.ctypes.data_as(C.c_void_p)
-        args = (self.h, a_ids, a_desc, a_anno, cp, C.c_int(int(chimera_info)), C.c_int(which))
-        need = lib.hu_batch_format_tsv_chimera(*args, None, C.c_int64(0))
-        if need < 0:
-            _chk(int(need))
-        buf = C.create_string_buffer(int(need) + 1)
-        lib.hu_batch_format_tsv_chimera(*args, buf, C.c_int64(need))
         return buf.raw[:need].decode("latin1")
 
     def close(self):

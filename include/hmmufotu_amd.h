@@ -182,14 +182,20 @@ int hu_tree_evaluate(int32_t n_nodes, int32_t cs_len, const int32_t* parent, con
 int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6);
 
 /* ---- host seed lookup -----------------------------------------------------
- * Stand-in for CSFMIndex::locateOne + BandedHMMP7::buildAlignPath as alignSeq uses them
- * (src/HmmUFOtu_main.cpp:50-84): a hash index over the seed_len-mers of the leaf sequences.  Takes the
- * FIRST occurrence where the reference draws a random one (src/CSFMIndex.cpp:139).  Host only. */
+ * CSFMIndex::locateOne + BandedHMMP7::buildAlignPath as alignSeq uses them (src/HmmUFOtu_main.cpp:50-84), over the same
+ * text as the reference's FM-index (the gap-free leaf sequences, src/CSFMIndex.cpp:288-330), indexed here by a position
+ * array sorted on the 32 symbols that follow (a depth-32 suffix array) with a 12-base directory.  The hit taken is the
+ * FIRST of the suffix-ordered range (the reference's locateFirst, :92-119; its locateOne draws a random member of the same
+ * range with rand(), src/CSFMIndex.cpp:139).  seed_len in 12..31 (CLI: 15..25).  Host only. */
 typedef struct hu_seed_index hu_seed_index;
 int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
 		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out);
 void hu_seed_index_destroy(hu_seed_index* ix);
-int64_t hu_seed_index_size(const hu_seed_index* ix);
+int64_t hu_seed_index_size(const hu_seed_index* ix);          /* distinct seed_len-mers */
+int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions /* indexed k-mer starts; may be NULL */);   /* resident bytes */
+/* every occurrence of one seed in index (suffix) order — the range locateOne draws from: sequence number (leaves in node-id
+ * order), residue offset inside it, 0-based CS column of its first base.  Returns the count; at most cap entries are written */
+int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap);
 /* the 5' and (GLOBAL mode) 3' seed scans for n reads -> vpaths [n][2][6] for hu_batch_set_reads */
 int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
 		int align_mode, int32_t* vpaths);
@@ -301,6 +307,11 @@ int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* con
  * hu_chimera_batch (NULL: nothing was checked) */
 int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap);
+/* the same without a copy: *text points at the batch's own buffer holding the lines (valid until the next format call on this
+ * batch); returns their length.  One pass — the (buf, cap) forms above format once per call, so "ask for the size, then fetch" costs
+ * two.  The lines of a batch are formatted on the host thread pool of the calling thread. */
+int64_t hu_batch_format_tsv_ptr(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
+		const hu_chimera_rec* chi, int chimera_info, int which, const char** text);
 /* header with the --chimera-info columns (src/hmmufotu.cpp:592-594 with CHIMERA_TSV_HEADER) */
 const char* hu_tsv_header_chimera(void);
 /* the header line of the assignment file (src/hmmufotu.cpp:592-594) */

@@ -465,6 +465,7 @@ def test_build_align_path_and_tsv():
     B.assign(E.default_opts())
     ids = ["r%d" % i for i in range(len(seqs))]
     tsv = B.format_tsv(ids, ["desc %d" % i for i in range(len(seqs))], db.annos)
+    assert B.format_tsv_copy(ids, ["desc %d" % i for i in range(len(seqs))], db.annos) == tsv     # the (buf, cap) form of the ABI: same bytes
     lines = tsv.strip("\n").split("\n")
     assert len(lines) == len(seqs) - 1 and all(not l.startswith("r2\t") for l in lines)
     best = B.placements(); alns = B.alignments()
@@ -557,6 +558,12 @@ def test_cli_end_to_end(tmp_path):
     outb = subprocess.run([cli, pre, fa, "-s", "1", "--batch", "5"], capture_output=True, text=True, timeout=300)
     assert outb.returncode == 0, outb.stderr
     assert [l for l in outb.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    # two database replicas x two batches in flight (here both replicas on the one device of the test box): same lines, same order
+    outm = subprocess.run([cli, pre, fa, "-s", "1", "--batch", "5", "--gpus", "2", "--inflight", "2", "-v"], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, HU_CLI_SHARE_GPU="1"))
+    assert outm.returncode == 0 and "2 device(s) x 2 batches in flight" in outm.stderr, outm.stderr
+    assert [l for l in outm.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    assert subprocess.run([cli, pre, fa, "--gpus", "9"], capture_output=True).returncode != 0          # more devices than the box has
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
     import gzip
     fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")
