@@ -329,8 +329,8 @@ def main():
     out = dict(metric=metric, value=value, unit="reads/s" if not args.paired else "pairs/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload="gg_97_otus-scale synthetic DB (%d nodes x %d CS columns, K=%d), GTR%s, %s %s reads, "
-                                    "batch %d reads/step/GPU, %d batches in flight" % (D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
+               config=dict(workload="%s synthetic DB (%d nodes x %d CS columns, K=%d), GTR%s, %s %s reads, "
+                                    "batch %d reads/step/GPU, %d batches in flight" % ("SILVA-scale" if args.leaves >= 150000 else "gg_97_otus-scale" if args.leaves >= 90000 else "reduced-scale", D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
                                                                                          shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
                rccl_ranks=rccl_ranks, backend=backend if world > 1 else None, gathered_records=(int(len(gathered)) if world > 1 else None),

@@ -994,3 +994,42 @@ def test_split_gap_base_placement_kernel(monkeypatch, capfd, read_len, lo, hi, g
         assert best[i]["n_cand"] == res["n"]
     assert worst < REL, worst
     B.close(); D.close()
+
+
+def test_streaming_kernels_on_a_large_tree():
+    """Regions beyond 3,072 columns (BASELINE config 5's 2 x 300 bp pairs span ~3,020 +- jitter) take the streaming estimate / place
+    kernels; here on a tree of 16,999 nodes, large enough for the sampled-threshold top-k path as well (config 5's own code path,
+    reduced in leaves only), against the oracle on the messages of the window the pairs touch."""
+    E = _engine()
+    import torch
+    from hmmufotu_amd import synth, synth_gpu
+    from oracle import oracle_py as O
+    db, up, down = synth_gpu.make_db_gpu(8500, 7682, "GTR", dg_k=4, seed=5, device="cuda:0", log=lambda *a: None)
+    ins = synth_gpu.simulate_reads_gpu(db, up, down, 12, 100000, seed=3, amplicon_start=1000, amplicon_cols=3300, jitter=20, device="cuda:0")
+    fw, mt = zip(*[synth.split_pair(r, 150) for r in ins])
+    vf = np.stack([synth.read_vpaths(db.hmm, r) for r in fw]); vr = np.stack([synth.read_vpaths(db.hmm, r) for r in mt])
+    lo, hi = 900, 4500
+    up_h = up[:, lo:hi].contiguous().cpu().numpy(); down_h = down[:, lo:hi].contiguous().cpu().numpy()
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+    D = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, db.anno_id, msgs_on_device=True)
+    assert D.n_nodes >= 16384
+    B = E.Batch(D, 16)
+    B.set_knob("trace", 1)
+    B.set_reads([r.seq for r in fw], vf, [r.seq for r in mt], vr); B.assign(E.default_opts())
+    recs = B.alignments(want_align=False)["recs"]; best = B.placements()
+    span = recs["cs_end"] - recs["cs_start"] + 1
+    assert (recs["status"] == 1).all() and span.max() > 3072, span
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
+    T = O.Tree(db.parent, db.blen, db.seq, up_h, down_h, db.height, m, db.dg_r, db.anno_id, win_start=lo, win_len=hi - lo)
+    assert recs["cs_start"].min() - 1 >= lo and recs["cs_end"].max() <= hi
+    ref = O.pipeline_batch(H, T, [r.seq for r in fw], vf, mates=[r.seq for r in mt], mvpaths=vr, threads=8, want_cands=True)
+    assert np.array_equal(recs["cost"], ref["cost"]) and (best["n_cand"] == ref["n_cand"]).all()
+    tot = classify_batch(ref, B.candidates(), best, db.parent)
+    assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
+    same = best["c_node"] == ref["best_nodes"][:, 0]
+    for name, col in (("ratio", 0), ("wnr", 1), ("est_loglik", 7)):
+        d = np.abs(best[name][same] - ref["best_vals"][same, col]) / np.maximum(np.abs(ref["best_vals"][same, col]), 1e-3)
+        assert d.max() < REL, (name, d.max())
+    print("large-tree streaming kernels:", tot, "widest region", int(span.max()))
+    B.close(); D.close()
