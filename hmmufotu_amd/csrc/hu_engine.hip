@@ -579,6 +579,7 @@ struct HuKnobs {
 	int vw_diag = 0;             /* k_viterbi_wave diagnostics variant                                               */
 	int viterbi_force_redo = 0;  /* flag every traceback "needs values": the redo pass runs for all sequences        */
 	int pdist_v1 = 0;            /* the per-read insert loop scan kernel                                             */
+	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
@@ -592,7 +593,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -616,6 +617,8 @@ struct hu_batch {
 	int maxReads = 0, n = 0, nSeq = 0, state = ST_NONE;
 	bool paired = false, fromCodes = false, profile = false;
 	HuKnobs knob;
+	int maxBases = 1 << 30;      /* most bases any read of the batch can have inside its region (set with the reads) */
+	bool pair16 = false;         /* the pair matrix of the last seed scan holds 16-bit pairs (maxBases <= 255) */
 	int seedCap = HU_MAX_SEEDS;   /* most seeds any read of the batch can have (seed stage) */
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[2 * HU_T_COUNT];
@@ -785,6 +788,11 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 	b->n = n; b->paired = mates != nullptr; b->nSeq = b->paired ? 2 * n : n; b->fromCodes = false;
 	b->hDescs.assign(b->nSeq, HuReadDesc());
 	b->hBases.clear();
+	b->maxBases = 0;
+	for(int r = 0; r < n; ++r) { /* a merged pair holds at most the bases of both mates */
+		const int64_t l = (offs[r + 1] - offs[r]) + (mates ? moffs[r + 1] - moffs[r] : 0);
+		if(l > b->maxBases) b->maxBases = (int) std::min<int64_t>(l, 1 << 30);
+	}
 	int64_t cells = 0, tr = 0, decs = 0;
 	for(int s = 0; s < b->nSeq; ++s) {
 		const bool isMate = s >= n;
@@ -837,11 +845,22 @@ static int ensure_read_buffers(hu_batch* b) {
 	return HU_OK;
 }
 
-static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKind kind, const int32_t* start, const int32_t* end) {
+static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKind kind, const int32_t* start, const int32_t* end, int maxBases = -1) {
 	if(!b || n < 0 || n > b->maxReads || (n > 0 && (!codes || !start || !end))) { hu_set_error("hu_batch_set_aligned: bad argument"); return HU_ERR_ARG; }
 	HIPCHK(hipSetDevice(b->db->device));
 	const HuDbDev& d = b->db->dev;
 	b->n = n; b->nSeq = n; b->paired = false; b->fromCodes = true;
+	if(maxBases >= 0) b->maxBases = maxBases;         /* device-to-device: the caller knows (segments of reads it holds) */
+	else { /* host codes: count */
+		int mb = 0;
+		for(int r = 0; r < n; ++r) {
+			if(!(start[r] >= 0 && start[r] <= end[r] && end[r] < d.csLen)) continue;
+			const int8_t* c = codes + (size_t) r * d.csLen; int k = 0;
+			for(int j = start[r]; j <= end[r]; ++j) k += c[j] >= 0;
+			mb = std::max(mb, k);
+		}
+		b->maxBases = mb;
+	}
 	int rc;
 	if((rc = ensure_read_buffers(b)) != HU_OK) return rc;
 	b->hAlns.assign(n, HuAlnDev());
@@ -1022,7 +1041,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	const HuDbDev& d = b->db->dev;
 	const size_t n = (size_t) b->n;
 	int rc;
-	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad)) != HU_OK) return rc;
+	b->pair16 = !b->knob.pairs32 && !b->knob.pdist_v1 && b->maxBases <= 255;       /* 16-bit pairs: half the matrix */
+	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (b->pair16 ? 2 : 1))) != HU_OK) return rc;
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
@@ -1032,11 +1052,13 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		{
 			Timer t(b, HU_T_SEED_PDIST);
 			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
-			else k_seed_pdist2<<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
+			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->n);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			k_seed_topk<<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
+			if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
+			else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
 		}
 		HIPCHK(hipGetLastError());
 	}
@@ -1046,13 +1068,13 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 }
 
 /* given seed nodes: (d, N) looked up in the pair matrix of the current regions */
-__global__ void k_seed_given(HuDbDev db, int n, const uint32_t* __restrict__ pairs, const int32_t* __restrict__ cnt, const int32_t* __restrict__ ids,
+__global__ void k_seed_given(HuDbDev db, int n, const void* __restrict__ pairs, int p16, const int32_t* __restrict__ cnt, const int32_t* __restrict__ ids,
 		const int32_t* __restrict__ distIds, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if(i >= n * HU_MAX_SEEDS) return;
 	const int r = i / HU_MAX_SEEDS, sl = i % HU_MAX_SEEDS;
 	if(sl == 0) seedCnt[r] = cnt[r];
-	if(sl < cnt[r]) { seedId[i] = ids[i]; seedDN[i] = pairs[(size_t) r * db.nNodesPad + (distIds ? distIds[i] : ids[i])]; }
+	if(sl < cnt[r]) { seedId[i] = ids[i]; seedDN[i] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + (distIds ? distIds[i] : ids[i]), p16); }
 }
 
 extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride) {
@@ -1075,7 +1097,8 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		}
 	}
 	int rc;
-	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad)) != HU_OK) return rc;
+	b->pair16 = !b->knob.pairs32 && b->maxBases <= 255;
+	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (b->pair16 ? 2 : 1))) != HU_OK) return rc;
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
@@ -1086,9 +1109,10 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		HIPCHK(hipMemcpyAsync(b->dGiven.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			k_seed_pdist2<<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
+			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->n);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
 		}
-		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->dGiven.p, b->dGiven.p + n,
+		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dGiven.p, b->dGiven.p + n,
 				dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
@@ -1120,7 +1144,7 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
 		const bool stream = b->knob.streaming_sep != 0;
-		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
+		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, (b->pair16 ? 1 : 0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
 		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
 		/* launch order of the table-driven kernels: by seed node */
 		const uint32_t* order = nullptr;
@@ -1469,7 +1493,7 @@ static bool cmpSegLoglik(const SegPlace& l, const SegPlace& r) { return l.p.logl
 static int segment_pass(hu_batch* w, hu_batch* b, const hu_opts* o, double maxError, const int32_t* st, const int32_t* en,
 		const int32_t* cnt, const int32_t* ids, const int32_t* distIds) {
 	int rc;
-	if((rc = set_aligned_impl(w, b->n, b->dCodes.p, hipMemcpyDeviceToDevice, st, en)) != HU_OK) return rc;
+	if((rc = set_aligned_impl(w, b->n, b->dCodes.p, hipMemcpyDeviceToDevice, st, en, b->maxBases)) != HU_OK) return rc;
 	if((rc = hu_seed_batch_given(w, cnt, ids, distIds, HU_MAX_SEEDS)) != HU_OK) return rc;
 	hu_opts so = *o; so.max_error = maxError;
 	if((rc = hu_estimate_batch(w, &so)) != HU_OK) return rc;
@@ -1730,8 +1754,16 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 	HIPCHK(hipSetDevice(b->db->device));
 	const int nn = b->db->dev.nNodes;
 	std::vector<uint32_t> v(nn);
-	HIPCHK(hipMemcpyAsync(v.data(), b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
-	HIPCHK(hipStreamSynchronize(b->stream));
+	if(b->pair16) {
+		std::vector<uint16_t> h(nn);
+		HIPCHK(hipMemcpyAsync(h.data(), (const uint16_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 2, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		for(int i = 0; i < nn; ++i) v[i] = ((uint32_t)(h[i] >> 8) << 16) | (h[i] & 0xffu);
+	}
+	else {
+		HIPCHK(hipMemcpyAsync(v.data(), b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
 	for(int i = 0; i < nn; ++i) { if(d) d[i] = (int32_t)(v[i] >> 16); if(N) N[i] = (int32_t)(v[i] & 0xffffu); }
 	return HU_OK;
 }

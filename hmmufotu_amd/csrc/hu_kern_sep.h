@@ -23,6 +23,31 @@
  * Per (node, read, 32 sites): 2 xor + or + 2 and + 2 popcount-accumulate.
  * Grid: x = read tile (fastest: consecutive workgroups re-use one node block from L2),
  *       y = node block of 256. */
+/* The (d, N) pair of a (read, node): 32 bits (d << 16 | N) or, when no read of the batch has more than 255 bases in its region
+ * (N <= 255: every single-end read of up to 255 bp), 16 bits (d << 8 | N) — half the bytes the scan writes and the top-k reads
+ * (6.5 + 7.7 GB per 8,192 reads at gg_97 scale with 32-bit pairs).  Everything downstream works on the canonical 32-bit form. */
+template<class PT> struct HuPair;
+template<> struct HuPair<uint32_t> {
+	static constexpr int PPV = 4;      /* pairs per 16-byte vector */
+	__device__ static inline uint32_t canon(uint32_t x) { return x; }
+	__device__ static inline uint32_t pack(uint32_t c) { return c; }
+	__device__ static inline void unpack(const uint4& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template<> struct HuPair<uint16_t> {
+	static constexpr int PPV = 8;
+	__device__ static inline uint32_t canon(uint32_t x) { return ((x >> 8) << 16) | (x & 0xffu); }
+	__device__ static inline uint16_t pack(uint32_t c) { return (uint16_t)(((c >> 16) << 8) | (c & 0xffu)); }
+	__device__ static inline void unpack(const uint4& v, uint32_t* o) {
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for(int e = 0; e < 8; ++e) o[e] = canon((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+	}
+};
+/* one pair, width chosen at run time (estimate kernels, given-seed lookup: one load per workgroup) */
+__device__ inline uint32_t hu_pair_load(const void* pairs, size_t idx, int p16) {
+	return p16 ? HuPair<uint16_t>::canon(((const uint16_t*) pairs)[idx]) : ((const uint32_t*) pairs)[idx];
+}
+
 /* T reads x M node blocks per workgroup: a lane owns M nodes (node, node + 256, ...) and T reads, so every
  * scalar load of a read's planes (48 B) feeds 24 M vector operations.  With M = 1 the kernel sat at ~50 % of the
  * integer issue rate behind `s_load -> s_waitcnt lgkmcnt(0)` pairs: the scalar cache, shared by several
@@ -124,8 +149,9 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
  * 3.68 ms.  Scalar loads return out of order, so a wait is always "all of them" and a request is covered by one vector block only;
  * the four register sets push the kernel to its 102 SGPRs (v_writelane spills) and the fake dependencies that keep the scheduler from
  * hoisting all sixteen request / wait pairs in front of the vector work cost more than the latency four waves per SIMD already hide. */
+template<class PT>
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, uint32_t* __restrict__ pairs, int nReads) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, int nReads) {
 	constexpr int T = HU_READ_TILE;
 	__shared__ uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = tile * T + t;
-		if(read < nReads) pairs[(size_t) read * np + node] = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
+		if(read < nReads) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
 	}
 }
 
@@ -191,7 +217,8 @@ __device__ inline uint32_t seed_bin(uint32_t d, uint32_t N, uint32_t limit) {
 	return (d << 12) / N;
 }
 
-__global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* __restrict__ pairs, double maxHeight,
+template<class PT>
+__global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restrict__ pairs, double maxHeight,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes) {
 	__shared__ unsigned long long keys[HU_TOPK_CAP];
 	static_assert(sizeof(unsigned long long) * HU_TOPK_CAP >= sizeof(uint32_t) * (HU_TOPK_BINS + 1), "histogram must fit the key buffer");
@@ -200,7 +227,8 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	__shared__ uint32_t chunk[256];
 	__shared__ uint32_t sh[5];
 	const int read = blockIdx.x, tid = threadIdx.x;
-	const uint32_t* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
+	constexpr int PPV = HuPair<PT>::PPV, NPI = 256 * HuPair<PT>::PPV;      /* pairs per 16-byte vector, nodes per workgroup pass */
+	const PT* __restrict__ pr = pairs + (size_t) read * db.nNodesPad;
 	const int per = (HU_TOPK_BINS + 1 + 255) / 256;
 	const bool useHeight = !(maxHeight == INFINITY);
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
@@ -216,14 +244,14 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 		for(int i = tid; i <= (int) limitS; i += 256) hist[i] = 0;
 		if(tid == 0) { sh[3] = 0; sh[4] = 0; }
 		__syncthreads();
-		const int nIt = (db.nNodes + 1023) / 1024;
-		for(int it = (8 - ((tid >> 3) & 7)) & 7; it < nIt; it += 8) { /* whole 128-byte lines (32 nodes, 8 lanes): iterations with (it + tid / 8) % 8 == 0 */
-			const int base = it * 1024 + tid * 4;
+		const int nIt = (db.nNodes + NPI - 1) / NPI;
+		for(int it = (8 - ((tid >> 3) & 7)) & 7; it < nIt; it += 8) { /* whole 128-byte lines (8 lanes x 16 B = 32 or 64 nodes): iterations with (it + tid / 8) % 8 == 0 */
+			const int base = it * NPI + tid * PPV;
 			if(base >= db.nNodes) break;
 			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
-			const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+			uint32_t vv[PPV]; HuPair<PT>::unpack(v4, vv);
 #pragma unroll
-			for(int e = 0; e < 4; ++e) {
+			for(int e = 0; e < PPV; ++e) {
 				const int node = base + e;
 				if(node >= db.nNodes || node == db.root) continue;
 				const uint32_t bin = seed_bin(vv[e] >> 16, vv[e] & 0xffffu, limitS);
@@ -252,15 +280,15 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 				uint4 v4[4];
 #pragma unroll
 				for(int k = 0; k < 4; ++k) {
-					const int base = (it0 + k) * 1024 + tid * 4;
+					const int base = (it0 + k) * NPI + tid * PPV;
 					v4[k] = base < db.nNodes ? *reinterpret_cast<const uint4*>(pr + base) : make_uint4(0, 0, 0, 0);
 				}
 #pragma unroll
 				for(int k = 0; k < 4; ++k) {
-					const int base = (it0 + k) * 1024 + tid * 4;
-					const uint32_t vv[4] = {v4[k].x, v4[k].y, v4[k].z, v4[k].w};
+					const int base = (it0 + k) * NPI + tid * PPV;
+					uint32_t vv[PPV]; HuPair<PT>::unpack(v4[k], vv);
 #pragma unroll
-					for(int e = 0; e < 4; ++e) {
+					for(int e = 0; e < PPV; ++e) {
 						const int node = base + e;
 						if(node >= db.nNodes || node == db.root) continue;
 						const uint32_t d = vv[e] >> 16, N = vv[e] & 0xffffu;
@@ -293,7 +321,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 					}
 				for(uint32_t i = tid; i < need; i += 256) {
 					uint32_t node = (uint32_t)(keys[i] & 0xffffffu);
-					outId[i] = (int32_t) node; outDN[i] = pr[node];
+					outId[i] = (int32_t) node; outDN[i] = HuPair<PT>::canon(pr[node]);
 				}
 				if(tid == 0) seedCnt[read] = (int32_t) need;
 				return;
@@ -308,11 +336,11 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 		for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
 		__syncthreads();
 		uint32_t over = 0;
-		for(int base = tid * 4; base < db.nNodes; base += 1024) {
+		for(int base = tid * PPV; base < db.nNodes; base += NPI) {
 			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
-			const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+			uint32_t vv[PPV]; HuPair<PT>::unpack(v4, vv);
 #pragma unroll
-			for(int e = 0; e < 4; ++e) {
+			for(int e = 0; e < PPV; ++e) {
 				const int node = base + e;
 				if(node >= db.nNodes || node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
 				const uint32_t bin = seed_bin(vv[e] >> 16, vv[e] & 0xffffu, limit);
@@ -348,11 +376,11 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 	const uint32_t need = sh[0], thr = sh[1], cntLE = sh[2];
 	if(need == 0) { if(tid == 0) seedCnt[read] = 0; return; }
 	if(cntLE <= HU_TOPK_CAP) {
-		for(int base = tid * 4; base < db.nNodes; base += 1024) {
+		for(int base = tid * PPV; base < db.nNodes; base += NPI) {
 			const uint4 v4 = *reinterpret_cast<const uint4*>(pr + base);
-			const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+			uint32_t vv[PPV]; HuPair<PT>::unpack(v4, vv);
 #pragma unroll
-			for(int e = 0; e < 4; ++e) {
+			for(int e = 0; e < PPV; ++e) {
 				const int node = base + e;
 				if(node >= db.nNodes || node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
 				const uint32_t d = vv[e] >> 16, N = vv[e] & 0xffffu;
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 			}
 		for(uint32_t i = tid; i < need; i += 256) {
 			uint32_t node = (uint32_t)(keys[i] & 0xffffffu);
-			outId[i] = (int32_t) node; outDN[i] = pr[node];
+			outId[i] = (int32_t) node; outDN[i] = HuPair<PT>::canon(pr[node]);
 		}
 	}
 	else { /* degenerate tie mass: one exact minimum per pass, bounded by max_nseed passes */
@@ -387,7 +415,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 			unsigned long long best = ~0ull;
 			for(int node = tid; node < db.nNodes; node += 256) {
 				if(node == db.root || (useHeight && !(db.height[node] <= maxHeight))) continue;
-				const uint32_t v = pr[node], d = v >> 16, N = v & 0xffffu;
+				const uint32_t v = HuPair<PT>::canon(pr[node]), d = v >> 16, N = v & 0xffffu;
 				if(seed_bin(d, N, thr + 1) > thr) continue;
 				unsigned long long k = seed_key(d, N, (uint32_t) node);
 				if((first || k > last) && k < best) best = k;
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const uint32_t* _
 			for(int wv = 1; wv < 4; ++wv) best = keys[wv] < best ? keys[wv] : best;
 			__syncthreads();
 			last = best; first = false;
-			if(tid == 0) { uint32_t node = (uint32_t)(best & 0xffffffu); outId[s] = (int32_t) node; outDN[s] = pr[node]; }
+			if(tid == 0) { uint32_t node = (uint32_t)(best & 0xffffffu); outId[s] = (int32_t) node; outDN[s] = HuPair<PT>::canon(pr[node]); }
 		}
 	}
 	if(tid == 0) seedCnt[read] = (int32_t) need;
@@ -531,7 +559,7 @@ struct HuEstOut { double ratio, wnr, loglik; };
  * latency x occupancy, not by bandwidth: measured by capping waves per CU). */
 template<int UNR>
 __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
 	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, lane = threadIdx.x;
@@ -539,7 +567,7 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int v = db.parent[u];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
-	const uint32_t pv = pairs[(size_t) read * db.nNodesPad + v];
+	const uint32_t pv = hu_pair_load(pairs, (size_t) read * db.nNodesPad + v, p16);
 	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
 	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
 	double ratio = cDist / (cDist + pDist);
@@ -629,10 +657,10 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 
 #define HU_EST_KERNEL(NAME, UNR, MINW) \
 __global__ __launch_bounds__(64, MINW) void NAME(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes, \
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ pairs, \
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16, \
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN, \
 		int weighted, HuEstOut* __restrict__ out) { \
-	estimate_body<UNR>(db, mdl, codes, rstart, rend, pairs, seedCnt, seedId, seedDN, weighted, out); \
+	estimate_body<UNR>(db, mdl, codes, rstart, rend, pairs, p16, seedCnt, seedId, seedDN, weighted, out); \
 }
 /* measured on MI355X (8192 reads, R = 1363): UNR 1 -> 12.3 ms, 2 -> 12.4, 4 -> 13.3 (register pressure
  * costs a wave per SIMD); forcing 5-6 waves per SIMD spills and doubles the time.  At UNR 1 the kernel

@@ -347,6 +347,38 @@ def test_seed_getters_respect_the_callers_stride():
     B.close(); D.close()
 
 
+@pytest.mark.parametrize("read_len", [150, 300])
+def test_pair_matrix_widths(read_len):
+    """(d, N) pairs are kept in 16 bits when no read of the batch has more than 255 bases in its region, else in 32 (reads of 300 bp
+    here); the knob forces 32.  Same (d, N) for every node (vs the oracle), same seeds, same estimates either way."""
+    E = _engine()
+    db = get_db(300, 2000, "GTR", dg_k=4, seed=7)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 6, read_len)
+    opts = E.default_opts()
+    res = []
+    for force32 in (0, 1):
+        D, B = _run_stages(E, db, reads, vps, opts)
+        B.set_knob("pairs32", force32)
+        B.get_seed(opts); B.estimate_seq(opts)
+        cd, st, en = B.codes()
+        pd = [B.pdist(i) for i in range(len(reads))]
+        res.append((B.seeds(), B.estimates(), pd))
+        if not force32:
+            nb = max(int((cd[i, st[i]:en[i] + 1] >= 0).sum()) for i in range(len(reads)))
+            assert (nb <= 255) == (read_len <= 255)
+            for i in range(len(reads)):
+                od, oN = T.pdist_all(cd[i], int(st[i]), int(en[i]))
+                assert (pd[i][0] == od).all() and (pd[i][1] == oN).all()
+        B.close(); D.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    for (d0, n0), (d1, n1) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
+
+
 def test_sep_weighted_and_maxheight():
     E = _engine()
     from oracle import oracle_py as O
