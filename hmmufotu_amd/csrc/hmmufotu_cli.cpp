@@ -93,6 +93,7 @@ static void usage(const char* p) {
 		"Options:    -o FILE  -L|--seed-len INT [20]  -R INT [50]  --single  -s|--strand INT [0]  -t|--test INT [100]\n"
 		"            -i|--ignore  -N INT [50]  -d|--max-diff DBL  -H|--max-height DBL  -e|--err DBL [20]\n"
 		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
+		"            --fix-root-loglik  rank candidates by the intended root log-likelihood (the reference returns a constant)\n"
 		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
@@ -134,6 +135,7 @@ int main(int argc, char** argv) {
 		else if(a == "-e" || a == "--err") o.max_error = atof(val());
 		else if(a == "-m" || a == "--method") method = val();
 		else if(a == "--ML") o.only_ml = 1;
+		else if(a == "--fix-root-loglik") o.fix_root_loglik = 1;      /* not in the reference: SURVEY.md F4 / H2 */
 		else if(a == "--prior") prior = val();
 		else if(a == "--fmt") fmt = val();
 		else if(a == "-C" || a == "--chimera") checkChimera = true;

@@ -564,7 +564,7 @@ extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent
 
 struct HostPlace {
 	int32_t seedIdx, cNode, pNode, aNode, iters;
-	double wuv, ratio, wnr, loglik, height, qPlace, qTaxon, estLoglik;
+	double wuv, ratio, wnr, loglik, height, qPlace, qTaxon, estLoglik, rootLoglik;
 	double annoDist() const { return aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr; }
 };
 
@@ -618,6 +618,7 @@ struct hu_batch {
 	bool paired = false, fromCodes = false, profile = false;
 	HuKnobs knob;
 	int maxBases = 1 << 30;      /* most bases any read of the batch can have inside its region (set with the reads) */
+	bool fixedRoot = false;      /* the last place call computed the intended root logliks (hu_opts.fix_root_loglik) */
 	bool pair16 = false;         /* the pair matrix of the last seed scan holds 16-bit pairs (maxBases <= 255) */
 	int seedCap = HU_MAX_SEEDS;   /* most seeds any read of the batch can have (seed stage) */
 	hipStream_t stream = nullptr;
@@ -645,6 +646,8 @@ struct hu_batch {
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
+	DBuf<double> dRootLL;
+	PinnedVec<double> hRootLL;
 	/* host */
 	std::vector<HuReadDesc> hDescs;
 	std::vector<char> hBases;
@@ -1376,9 +1379,17 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 		}
 		#undef PL_ARGS
 		HIPCHK(hipGetLastError());
+		if(o->fix_root_loglik) { /* the intended root log-likelihood at the optimised lengths (documented deviation, off by default) */
+			if((rc = b->dRootLL.ensure(nc)) != HU_OK) return rc;
+			b->hRootLL.resize(nc);
+			k_root_loglik<<<(unsigned) nc, 64, 0, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p, (int) nc, b->dRootLL.p);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(b->hRootLL.data(), b->dRootLL.p, nc * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+		}
 		HIPCHK(hipMemcpyAsync(b->hPlaceOut.data(), b->dPlaceOut.p, nc * sizeof(HuPlaceOut), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
 	}
+	b->fixedRoot = o->fix_root_loglik != 0 && nc > 0;
 	b->state = ST_PLACED;
 	return HU_OK;
 }
@@ -1403,7 +1414,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		static thread_local std::vector<double> pp, pr;
 		hu_place_rec& br = b->best[r];
 		br.c_node = br.p_node = br.a_node = -1; br.n_cand = 0;
-		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = NAN;
+		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = br.root_loglik = NAN;
 		const int64_t lo = b->candOffs[r], hi = b->candOffs[r + 1];
 		if(hi <= lo) return;
 		pl.assign(b->places.begin() + lo, b->places.begin() + hi);
@@ -1413,7 +1424,8 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		for(int64_t c = lo; c < hi; ++c) { /* PTUnrooted::placeSeq const (src/PhyloTreeUnrooted.cpp:936-952) */
 			HostPlace& p = pl[c - lo];
 			const HuPlaceOut& po = b->hPlaceOut[c];
-			p.loglik = ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
+			p.rootLoglik = b->fixedRoot ? b->hRootLL[c] : NAN;
+			p.loglik = b->fixedRoot ? p.rootLoglik : ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
 			p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
 			p.qPlace = p.qTaxon = NAN;     /* --ML computes none */
 			b->places[c] = p;
@@ -1454,7 +1466,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 		const HostPlace& p = pl[0];
 		br.c_node = p.cNode; br.p_node = p.pNode; br.a_node = p.aNode; br.n_cand = (int32_t) pl.size();
 		br.wuv = p.wuv; br.ratio = p.ratio; br.wnr = p.wnr; br.loglik = p.loglik; br.height = p.height;
-		br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik;
+		br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik; br.root_loglik = p.rootLoglik;
 	});
 	b->state = ST_FINISHED;
 	return HU_OK;
@@ -1525,7 +1537,7 @@ extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, cons
 		c.seg5_start = c.seg5_end = c.seg3_start = c.seg3_end = -1;
 		hu_place_rec none; memset(&none, 0, sizeof(none));
 		none.c_node = none.p_node = none.a_node = -1;
-		none.wuv = none.ratio = none.wnr = none.loglik = none.height = none.q_place = none.q_taxon = none.anno_dist = none.est_loglik = NAN;
+		none.wuv = none.ratio = none.wnr = none.loglik = none.height = none.q_place = none.q_taxon = none.anno_dist = none.est_loglik = none.root_loglik = NAN;
 		c.seg5 = c.seg3 = none; c.alt5_loglik = c.alt3_loglik = c.lod = NAN;
 		segLen[r] = b->hAlns[r].status == HU_READ_OK ? (b->hEnd[r] - b->hStart[r] + 1) / numSeg : 0;
 		if(segLen[r] < 1 || cnt[r] < 1) { segLen[r] = 0; cnt[r] = 0; }
@@ -1831,7 +1843,7 @@ static hu_place_rec to_rec(const HostPlace& p, int32_t nCand) {
 	hu_place_rec r;
 	r.c_node = p.cNode; r.p_node = p.pNode; r.a_node = p.aNode; r.n_cand = nCand;
 	r.wuv = p.wuv; r.ratio = p.ratio; r.wnr = p.wnr; r.loglik = p.loglik; r.height = p.height;
-	r.q_place = p.qPlace; r.q_taxon = p.qTaxon; r.anno_dist = p.annoDist(); r.est_loglik = p.estLoglik;
+	r.q_place = p.qPlace; r.q_taxon = p.qTaxon; r.anno_dist = p.annoDist(); r.est_loglik = p.estLoglik; r.root_loglik = p.rootLoglik;
 	return r;
 }
 extern "C" int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs) {

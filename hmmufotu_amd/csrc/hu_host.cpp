@@ -30,6 +30,8 @@ extern "C" void hu_default_opts(hu_opts* o) {
 	o->weighted = 0;
 	o->only_ml = 0;
 	o->prior = HU_PRIOR_UNIFORM;
+	o->fix_root_loglik = 0;
+	o->reserved0 = 0;
 	o->ignore_orient = 0;
 }
 

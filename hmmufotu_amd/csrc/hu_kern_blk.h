@@ -201,9 +201,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuMo
 	if(isnan(ratio)) ratio = 0.5;
 	const double w0 = db.blen[un];
 	const double wur = w0 * ratio, wvr = w0 - wur;
+	/* the six exponentials exp(lam_m w_ur), exp(lam_m w_vr), m = 1..3: ONE exp() per wave, lane l < 6 evaluating the l-th of them,
+	 * read back into scalar registers — every lane evaluating all six cost 5 x ~45 wave-instructions of the ~1,070 a wave executes */
 	double Eu[3], Ev[3];
+	{
+		const int l6 = lane < 6 ? lane : 0, m3 = l6 % 3;
+		const double e = exp((m3 == 0 ? mdl.lam[1] : m3 == 1 ? mdl.lam[2] : mdl.lam[3]) * (l6 < 3 ? wur : wvr));
+		const int lo = __double2loint(e), hi = __double2hiint(e);
 #pragma unroll
-	for(int k = 0; k < 3; ++k) { Eu[k] = exp(mdl.lam[k + 1] * wur); Ev[k] = exp(mdl.lam[k + 1] * wvr); }
+		for(int k = 0; k < 3; ++k) {
+			Eu[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
+			Ev[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, 3 + k), __builtin_amdgcn_readlane(lo, 3 + k));
+		}
+	}
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
 	const int8_t* __restrict__ cd = codes + (size_t) read * db.csLen + start;
 	const int64_t sOff = (int64_t) un * db.winLen + (start - db.winStart);

@@ -671,6 +671,67 @@ HU_EST_KERNEL(k_estimate, 1, 1)
 struct HuCand { int32_t read, node; double ratio0, wnr0; };
 struct HuPlaceOut { double wnr, wur; int32_t iters, pad; };
 
+/* k_root_loglik (hu_opts.fix_root_loglik): the log-likelihood the reference evidently meant placeSeq to return — the three
+ * messages of u, v and the read meeting at the new root r at the optimised branch lengths, sum_j log pi . exp(loglik(r, j)),
+ * loglik(r, j) with the dGamma averaging of src/PhyloTreeUnrooted.cpp:320-346 — instead of the constant it does return because the
+ * root message is re-initialised first (:918-922).  One wave per candidate, the sites strided over the lanes; per
+ * site and rate category two matvecs in the eigenbasis and a table look-up for the read's base (tab[k][b][i] = (P(w_nr r_k) c^b)_i,
+ * c^b = e_b or pi), one log per site.  Off the default path. */
+__global__ __launch_bounds__(64) void k_root_loglik(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const HuCand* __restrict__ cands,
+		const HuPlaceOut* __restrict__ po, int nc, double* __restrict__ out) {
+	__shared__ double Eu[HU_MAX_DGK][4], Ev[HU_MAX_DGK][4], tab[HU_MAX_DGK][5][4];
+	const int c = blockIdx.x, lane = threadIdx.x;
+	if(c >= nc) return;
+	const HuCand cd = cands[c];
+	const int read = cd.read, un = cd.node;
+	const int start = rstart[read], end = rend[read];
+	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
+	const double w0 = db.blen[un], wur = po[c].wur, wvr = w0 - wur, wnr = po[c].wnr;
+	for(int e = lane; e < Kc * 4; e += 64) {
+		const int k = e >> 2, m = e & 3;
+		Eu[k][m] = exp(mdl.lam[m] * (wur * mdl.rate[k])); Ev[k][m] = exp(mdl.lam[m] * (wvr * mdl.rate[k]));
+	}
+	for(int e = lane; e < Kc * 20; e += 64) { /* (P(t) c^b)_i = sum_m U_im exp(lam_m t) (U^-1 c^b)_m */
+		const int k = e / 20, b = (e % 20) >> 2, i = e & 3;
+		const double t = wnr * mdl.rate[k];
+		double v = 0;
+		if(t == 0) v = b < 4 ? (i == b ? 1.0 : 0.0) : mdl.pi[i];
+		else {
+			for(int m = 0; m < 4; ++m) {
+				double am = 0;
+				if(b < 4) am = mdl.U1[m * 4 + b];
+				else for(int x = 0; x < 4; ++x) am += mdl.U1[m * 4 + x] * mdl.pi[x];
+				v += mdl.U[i * 4 + m] * exp(mdl.lam[m] * t) * am;
+			}
+			v = fmax(v, 0.0);
+		}
+		tab[k][b][i] = v;
+	}
+	__syncthreads();
+	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen;
+	const int64_t sOff = (int64_t) un * db.winLen - db.winStart;
+	const double rK = 1.0 / (double) Kc;
+	double ll = 0; long long ksum = 0;
+	for(int j = start + lane; j <= end; j += 64) {
+		double aU[4], aV[4];
+		load4(db.up + (sOff + j) * 4, aU); load4(db.down + (sOff + j) * 4, aV);
+		const int b = cdr[j] >= 0 ? cdr[j] : 4;
+		double lik = 0;
+		for(int k = 0; k < Kc; ++k) {
+			double cu[4], cv[4];
+			conv_eig(mdl, Eu[k], aU, cu); conv_eig(mdl, Ev[k], aV, cv);
+			const double* cn = tab[k][b];
+			lik += (mdl.pi[0] * cu[0] * cv[0] * cn[0] + mdl.pi[2] * cu[2] * cv[2] * cn[2]) + (mdl.pi[1] * cu[1] * cv[1] * cn[1] + mdl.pi[3] * cu[3] * cv[3] * cn[3]);
+		}
+		ll += log(lik * rK);
+		ksum += (long long) db.upK[sOff + j] + (long long) db.downK[sOff + j];
+	}
+	ll = wave_sum(ll);
+	for(int m = 32; m > 0; m >>= 1) ksum += __shfl_xor(ksum, m);
+	if(lane == 0) out[c] = ll + (double) ksum * HU_LN2;
+}
+
 /* Felsenstein's EM for one branch (src/PhyloTreeUnrooted.cpp:749-798) on the per-site ratios
  * rho_j = A_j / B_j kept in LDS: p <- mean_j p0 / (rho_j q0 + p0); NaN sites are skipped (their count
  * does not change between iterations and is taken once).  The quotient is a reciprocal refined by two

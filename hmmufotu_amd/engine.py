@@ -46,7 +46,7 @@ class TreeDesc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("align_mode", C.c_int32), ("max_nseed", C.c_int32), ("max_diff", C.c_double), ("max_height", C.c_double),
                 ("max_error", C.c_double), ("weighted", C.c_int32), ("only_ml", C.c_int32), ("prior", C.c_int32),
-                ("ignore_orient", C.c_int32)]
+                ("ignore_orient", C.c_int32), ("fix_root_loglik", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AlignRec(C.Structure):
@@ -57,14 +57,15 @@ class AlignRec(C.Structure):
 class PlaceRec(C.Structure):
     _fields_ = [("c_node", C.c_int32), ("p_node", C.c_int32), ("a_node", C.c_int32), ("n_cand", C.c_int32),
                 ("wuv", C.c_double), ("ratio", C.c_double), ("wnr", C.c_double), ("loglik", C.c_double), ("height", C.c_double),
-                ("q_place", C.c_double), ("q_taxon", C.c_double), ("anno_dist", C.c_double), ("est_loglik", C.c_double)]
+                ("q_place", C.c_double), ("q_taxon", C.c_double), ("anno_dist", C.c_double), ("est_loglik", C.c_double),
+                ("root_loglik", C.c_double)]
 
 
 ALIGN_DTYPE = np.dtype([("seq_start", "i4"), ("seq_end", "i4"), ("hmm_start", "i4"), ("hmm_end", "i4"), ("cs_start", "i4"),
                         ("cs_end", "i4"), ("status", "i4"), ("used_full", "i4"), ("cost", "f8")])
 PLACE_DTYPE = np.dtype([("c_node", "i4"), ("p_node", "i4"), ("a_node", "i4"), ("n_cand", "i4"), ("wuv", "f8"), ("ratio", "f8"),
                         ("wnr", "f8"), ("loglik", "f8"), ("height", "f8"), ("q_place", "f8"), ("q_taxon", "f8"),
-                        ("anno_dist", "f8"), ("est_loglik", "f8")])
+                        ("anno_dist", "f8"), ("est_loglik", "f8"), ("root_loglik", "f8")])
 
 
 class ChimeraOpts(C.Structure):

@@ -110,6 +110,13 @@ typedef struct {
 	int32_t only_ml;          /* --ML                                                              */
 	int32_t prior;            /* --prior                                                           */
 	int32_t ignore_orient;    /* -i                                                                */
+	int32_t fix_root_loglik;  /* 0 [default]: placeSeq's loglik as the reference computes it — the constant
+	                           * (end - start + 1) log(sum_i pi_i e) of SURVEY.md F4 (src/PhyloTreeUnrooted.cpp:918-922), so every
+	                           * candidate ties and the pick follows the estimated order.  1 (--fix-root-loglik): the value evidently
+	                           * intended, sum_j log pi . exp(loglik(r, j)) at the optimised branch lengths; candidates are then
+	                           * ranked by it (q-values, --ML sort, chimera log-odds all become informative).  A documented
+	                           * deviation from the reference, off by default                                          */
+	int32_t reserved0;
 } hu_opts;
 
 /* BandedHMMP7::HmmAlignment minus the string (src/BandedHMMP7.h:74-130) */
@@ -125,6 +132,8 @@ typedef struct {
 	int32_t c_node, p_node, a_node;
 	int32_t n_cand;           /* candidates that survived filterPlacements                          */
 	double wuv, ratio, wnr, loglik, height, q_place, q_taxon, anno_dist, est_loglik;
+	double root_loglik;       /* with fix_root_loglik: the intended root log-likelihood (== loglik then); NaN otherwise.  The
+	                           * reference's constant is (cs_end - cs_start + 1) * log(sum_i pi_i e) either way           */
 } hu_place_rec;
 
 void hu_default_opts(hu_opts* o);

@@ -127,10 +127,10 @@ int orc_place(void* tr, const int8_t* seq, int start, int end, int cNode, double
 	return p.iters;
 }
 
-struct OrcOpts { double maxDiff, maxHeight, maxError; int maxNSeed, weighted, onlyML, prior, tieMode; };
+struct OrcOpts { double maxDiff, maxHeight, maxError; int maxNSeed, weighted, onlyML, prior, tieMode, fixRootLoglik; };
 static AssignOpts to_opts(const OrcOpts* o) {
 	AssignOpts a; a.maxDiff = o->maxDiff; a.maxHeight = o->maxHeight; a.maxError = o->maxError; a.maxNSeed = o->maxNSeed;
-	a.weighted = o->weighted; a.onlyML = o->onlyML; a.prior = o->prior; a.tieMode = o->tieMode; return a;
+	a.weighted = o->weighted; a.onlyML = o->onlyML; a.prior = o->prior; a.tieMode = o->tieMode; a.fixRootLoglik = o->fixRootLoglik; return a;
 }
 static void export_place(const Placement& p, int* ni, double* nd) {
 	ni[0] = p.cNode; ni[1] = p.pNode; ni[2] = p.aNode; ni[3] = p.iters;
@@ -250,7 +250,7 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			}
 			auto t3 = std::chrono::steady_clock::now();
 			loc[2] += std::chrono::duration<double>(t3 - t2).count();
-			for(Placement& p : places) placeSeq(*t, dseq.data(), p, opts.maxHeight);
+			for(Placement& p : places) placeSeq(*t, dseq.data(), p, opts.maxHeight, opts.fixRootLoglik != 0);
 			if(opts.onlyML)
 				std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; });
 			else {

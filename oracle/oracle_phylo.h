@@ -280,7 +280,18 @@ inline double optimizeBranchLength2(const Tree& t, const V4* U, const V4* V, int
 /* const placeSeq -> copySubTree -> mutable placeSeq -> joint optimizeBranchLength
  * (src/PhyloTreeUnrooted.cpp:925-954, 721-747, 879-923, 800-847).  The dead r->v message
  * of each outer iteration (:829-833) is not computed: nothing reads it. */
-inline void placeSeq(const Tree& t, const int8_t* seq, Placement& place, double maxHeight) {
+/* fixRoot: NOT the reference — the value placeSeq evidently meant to return: loglik(r, j) from the three
+ * children at the optimised lengths (src/PhyloTreeUnrooted.cpp:320-346 with dGamma), then treeLoglik */
+inline V4 nodeLoglik3(const Tree& t, const double* P1, const double* m1, const double* P2, const double* m2, const double* P3, const double* m3) {
+	const int Kc = t.dgK > 0 ? t.dgK : 1;
+	V4 X[16];
+	for(int k = 0; k < Kc; ++k) {
+		V4 a = dps_mat(P1 + 16 * k, m1), b = dps_mat(P2 + 16 * k, m2), c = dps_mat(P3 + 16 * k, m3);
+		for(int i = 0; i < 4; ++i) X[k].v[i] = ((0 + a.v[i]) + b.v[i]) + c.v[i];
+	}
+	return t.dgK == 0 ? X[0] : row_mean_exp_scaled(X, t.dgK);
+}
+inline void placeSeq(const Tree& t, const int8_t* seq, Placement& place, double maxHeight, bool fixRoot = false) {
 	const int u = place.cNode, v = place.pNode;
 	const int start = place.start, end = place.end, n = end - start + 1;
 	const double ratio0 = place.ratio, wnr0in = place.wnr;
@@ -315,6 +326,11 @@ inline void placeSeq(const Tree& t, const int8_t* seq, Placement& place, double 
 	double ones[4] = { INVALID_LOGLIK, INVALID_LOGLIK, INVALID_LOGLIK, INVALID_LOGLIK };
 	double ll = 0;
 	for(int j = start; j <= end; ++j) ll += dps_vec(t.model.pi, ones);
+	if(fixRoot) {
+		catP(t, lenUR, PU); catP(t, w0j - lenUR, PV); catP(t, lenNR, PN);
+		ll = 0;
+		for(int j = 0; j < n; ++j) { V4 r = nodeLoglik3(t, PU, Um[j].v, PV, Vm[j].v, PN, Nm[j].v); ll += dps_vec(t.model.pi, r.v); }
+	}
 	place.loglik = ll;
 	place.wnr = lenNR;
 	double wurF = lenUR;
@@ -373,6 +389,7 @@ struct AssignOpts {
 	int onlyML = 0;
 	int prior = 0;
 	int tieMode = TIE_STABLE;
+	int fixRootLoglik = 0;
 };
 
 /* the SEP part of the per-read task (src/hmmufotu.cpp:641-647,720-733); seq = DigitalSeq of
@@ -386,7 +403,7 @@ inline std::vector<Placement> assignSeq(const Tree& t, const int8_t* seq, int st
 	if(estOut) *estOut = places;
 	filterPlacements(places, o.maxError);
 	if(filtOut) { filtOut->clear(); for(const Placement& p : places) filtOut->push_back(p.cNode); }
-	for(Placement& p : places) placeSeq(t, seq, p, o.maxHeight);
+	for(Placement& p : places) placeSeq(t, seq, p, o.maxHeight, o.fixRootLoglik != 0);
 	if(o.onlyML)
 		std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; });
 	else {
@@ -421,7 +438,7 @@ inline ChimeraResult chimeraCheck(const Tree& t, const int8_t* seq, int start, i
 			segPlaces.push_back(estimateSeq(t, seq, l, o.weighted != 0));
 		}
 		filterPlacements(segPlaces, maxChimeraError);
-		for(Placement& p : segPlaces) placeSeq(t, seq, p, o.maxHeight);
+		for(Placement& p : segPlaces) placeSeq(t, seq, p, o.maxHeight, o.fixRootLoglik != 0);
 		std::vector<Placement>& pool = n < numSeg / 2 ? seg5 : seg3;
 		pool.insert(pool.end(), segPlaces.begin(), segPlaces.end());
 	}
@@ -432,11 +449,11 @@ inline ChimeraResult chimeraCheck(const Tree& t, const int8_t* seq, int start, i
 	PTLoc a5; a5.start = res.seg5.start; a5.end = res.seg5.end; a5.id = res.seg3.cNode; /* seg3's branch, distance to seg5's own node */
 	pdist_counts(seq, t.S(res.seg5.cNode), a5.start, a5.end, a5.d, a5.N); a5.dist = static_cast<double>(a5.d) / a5.N;
 	res.alt5 = estimateSeq(t, seq, a5, o.weighted != 0);
-	placeSeq(t, seq, res.alt5, o.maxHeight);
+	placeSeq(t, seq, res.alt5, o.maxHeight, o.fixRootLoglik != 0);
 	PTLoc a3; a3.start = res.seg3.start; a3.end = res.seg3.end; a3.id = res.seg5.cNode;
 	pdist_counts(seq, t.S(res.seg3.cNode), a3.start, a3.end, a3.d, a3.N); a3.dist = static_cast<double>(a3.d) / a3.N;
 	res.alt3 = estimateSeq(t, seq, a3, o.weighted != 0);
-	placeSeq(t, seq, res.alt3, o.maxHeight);
+	placeSeq(t, seq, res.alt3, o.maxHeight, o.fixRootLoglik != 0);
 	res.lod = res.seg5.loglik - res.alt5.loglik + res.seg3.loglik - res.alt3.loglik;
 	res.isChimera = res.seg5.aNode != res.seg3.aNode && res.lod > minChimeraLod; /* getTaxonId() = aNode id (src/PhyloTreeUnrooted.h:430-435) */
 	res.checked = true;

@@ -1065,3 +1065,55 @@ def test_streaming_kernels_on_a_large_tree():
         assert d.max() < REL, (name, d.max())
     print("large-tree streaming kernels:", tot, "widest region", int(span.max()))
     B.close(); D.close()
+
+
+@pytest.mark.parametrize("model,dg_k", [("GTR", 4), ("TN93", 0)])
+def test_fix_root_loglik_flag(model, dg_k):
+    """hu_opts.fix_root_loglik / --fix-root-loglik (a documented deviation, off by default): candidates ranked by the intended root
+    log-likelihood (k_root_loglik) against the oracle's fixRootLoglik; without the flag root_loglik is NaN and loglik the F4 constant."""
+    E = _engine()
+    from oracle import oracle_py as O
+    db = get_db(150, 700, model, dg_k=dg_k)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 16, 150)
+    opts = E.default_opts(fix_root_loglik=1)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+    cd, st, en = B.codes(); best = B.placements(); coffs, cpl = B.candidate_places()
+    oo = O.default_opts(fixRootLoglik=1)
+    differ = 0
+    for i in range(len(reads)):
+        res = T.assign(cd[i], int(st[i]), int(en[i]), oo)
+        oc = {int(n_[0]): v for n_, v in zip(res["nodes"], res["vals"])}
+        g = cpl[coffs[i]:coffs[i + 1]]
+        assert sorted(oc) == sorted(int(x) for x in g["c_node"])
+        for rec in g:
+            v = oc[int(rec["c_node"])]
+            assert _rel(rec["loglik"], v[2]) < 1e-9 and rec["root_loglik"] == rec["loglik"]
+            assert abs(rec["q_place"] - v[4]) <= 1e-5 * max(1.0, abs(v[4]))      # q = -10 log10(1 - p): p good to ~1e-7 from logliks good to 1e-9 of ~1e3
+        if int(best[i]["c_node"]) != int(res["nodes"][0][0]):                     # only when the oracle's own two best keys tie
+            differ += 1
+            assert abs(res["vals"][0][4] - res["vals"][1][4]) <= 1e-6 * max(1.0, abs(res["vals"][0][4])), (i, res["vals"][:2])
+        else:
+            assert _rel(best[i]["loglik"], res["vals"][0][2]) < 1e-9
+    opts0 = E.default_opts()
+    B.place_seq(opts0); B.calc_q_values(opts0)
+    b0 = B.placements()
+    assert np.isnan(b0["root_loglik"]).all()
+    const = (en - st + 1) * np.log((db.model.pi * np.e).sum())
+    assert _rel(b0["loglik"], const).max() < 1e-12
+    # the chimera check becomes informative: log-odds are no longer identically 0, and agree with the oracle's
+    W = E.Batch(D, len(reads))
+    B.set_aligned(cd, st, en); B.get_seed(opts)
+    cnt, ids, _, _ = B.seeds()
+    res = B.check_chimera(W, opts, num_seg=2)
+    lods = []
+    for i in range(len(reads)):
+        o = T.chimera(cd[i], int(st[i]), int(en[i]), oo, num_seg=2, seeds=ids[i, :cnt[i]])
+        assert bool(res[i]["checked"]) == o["checked"]
+        if (int(res[i]["seg5"]["c_node"]), int(res[i]["seg3"]["c_node"])) == (o["seg5"]["c"], o["seg3"]["c"]):
+            assert abs(res[i]["lod"] - o["lod"]) <= 1e-6 * max(1.0, abs(o["lod"])), (i, res[i]["lod"], o["lod"])
+            lods.append(o["lod"])
+    assert len(lods) >= len(reads) // 2 and max(abs(x) for x in lods) > 1e-3
+    print("fix-root-loglik: picks differing by an exact key tie:", differ, "; chimera log-odds compared:", len(lods))
+    W.close(); B.close(); D.close()

@@ -170,3 +170,38 @@ def test_chimera_check_restated_from_its_stages():
                     assert (got["c"], got["start"], got["end"]) == (sid, s0, e0)
                     assert got["ratio"] == p["ratio"] and got["wnr"] == p["wnr"] and got["a"] == p["aNode"]
                     assert got["loglik"] == p["loglik"]
+
+
+@pytest.mark.parametrize("model,dg_k", [("GTR", 4), ("HKY85", 0)])
+def test_fixed_root_loglik_is_the_star_tree_likelihood(model, dg_k):
+    """fixRootLoglik (NOT the reference: SURVEY F4 / H2): the log-likelihood of the four-node star {u, v, read} -> r at the optimised
+    branch lengths, recomputed here in probability space with numpy; by default the oracle returns the reference's constant."""
+    from conftest import get_db, oracle_objects, sim_reads
+    from oracle import oracle_py as O
+    from hmmufotu_amd import synth
+    db = get_db(80, 500, model, dg_k=dg_k)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 4, 100)
+    pi = db.model.pi
+    rates = db.dg_r if dg_k else np.ones(1)
+    for r, vp in zip(reads, vps):
+        a = H.align(r.seq, vp)
+        cd = O.digitize(a["align"]); s, e = a["csStart"] - 1, a["csEnd"] - 1
+        plain = T.assign(cd, s, e, O.default_opts())
+        fixed = T.assign(cd, s, e, O.default_opts(fixRootLoglik=1))
+        const = (e - s + 1) * np.log((pi * np.e).sum())
+        assert all(abs(v[2] - const) < 1e-9 * abs(const) for v in plain["vals"])
+        assert sorted(int(n_[0]) for n_ in plain["nodes"]) == sorted(int(n_[0]) for n_ in fixed["nodes"])
+        N = np.where(cd[s:e + 1, None] >= 0, np.eye(4)[np.maximum(cd[s:e + 1], 0)], pi[None, :])      # e^{leaf message}: unit vector or pi
+        for n_, v in zip(fixed["nodes"], fixed["vals"]):
+            u = int(n_[0]); w0 = db.blen[u]; ratio, wnr = v[0], v[1]
+            lik = 0
+            for rk in rates:
+                Pu = synth.model_P(db.model, np.array([w0 * ratio * rk]))[0]; Pv = synth.model_P(db.model, np.array([(w0 - w0 * ratio) * rk]))[0]
+                Pn = synth.model_P(db.model, np.array([wnr * rk]))[0]
+                lik = lik + ((np.exp(db.up[u, s:e + 1]) @ Pu.T) * (np.exp(db.down[u, s:e + 1]) @ Pv.T) * (N @ Pn.T) * pi).sum(-1)
+            want = np.log(lik / len(rates)).sum()
+            assert abs(v[2] - want) < 1e-9 * abs(want), (u, v[2], want)
+        # the final order is by q_place of the real logliks now: descending
+        q = [v[4] for v in fixed["vals"]]
+        assert all(q[i] >= q[i + 1] for i in range(len(q) - 1))
