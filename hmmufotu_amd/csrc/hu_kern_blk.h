@@ -992,3 +992,9 @@ __global__ __launch_bounds__(128, OCC) void k_place_w1(HuDbDev db, HuModelDev md
 		for(int i = 0; i < 8; ++i) dbg[((size_t) blockIdx.x * 2 + wave) * 8 + i] = tk[i];
 	}
 }
+
+/* Measured and not kept (round 2), both aimed at THREE waves per SIMD for the placement (k_place_blk issues VALU 49 % of the time at two):
+ * (a) the 12-slot kernel with the third components of both messages in LDS, the model constants through the scalar cache and the
+ *     gap-slot tables in scalar registers: the compiler reaches 168 VGPRs only with 288 B / lane of scratch: 12.0 ms against 8.9;
+ * (b) three waves x 8 slots per candidate (k_place_blk<8, 3, ...>, 168 VGPRs, 96 B of scratch, four workgroups per CU): 10.4 ms —
+ *     the three-wave reductions of every EM step cost more than the third wave per SIMD hides. */
