@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <chrono>
+#include <fstream>
 #include <sstream>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
@@ -385,6 +386,119 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	cleanup(rc == HU_OK);
 	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; (*out)->allocs.push_back(dUp); (*out)->allocs.push_back(dDown); }   /* the database owns them */
 	return rc;
+}
+
+/* PTUnrooted::save (src/PhyloTreeUnrooted.cpp:537-567 and :116-129, :595-603, :632-670, :672-697; src/DigitalSeq.cpp:96-104;
+ * src/util/ProgEnv.cpp:24-28): the database file hmmufotu / hu_db_load read.  The messages may live on the device (98 GB at
+ * gg_97 scale, straight out of hu_tree_evaluate): they go to the file edge by edge through a page-locked row. */
+static std::string model_text_of(const hu_model_desc& m) {
+	static const char* names[] = {"GTR", "TN93", "HKY85", "F81", "K80", "JC69"};
+	char t[64];
+	auto num = [&](double v) { snprintf(t, sizeof(t), "%.17g", v); return std::string(t); };
+	std::string o = std::string("# DNA Substitution Model\nType: ") + names[m.type] + "\n";
+	if(m.type != HU_K80 && m.type != HU_JC69) o += "pi: " + num(m.pi[0]) + " " + num(m.pi[1]) + " " + num(m.pi[2]) + " " + num(m.pi[3]) + "\n";
+	if(m.type == HU_GTR) {
+		o += "R:\n";
+		for(int i = 0; i < 4; ++i) o += num(m.par[4 * i]) + " " + num(m.par[4 * i + 1]) + " " + num(m.par[4 * i + 2]) + " " + num(m.par[4 * i + 3]) + "\n";
+		/* Q = R diag(pi), rows summing to 0, scaled to unit rate (GTR::setQfromParams, src/GTR.cpp:124-131); the reference's reader skips
+		 * these lines ("for human read only", :68-72) */
+		double Q[16], mu = 0;
+		for(int i = 0; i < 4; ++i) { double rs = 0; for(int j = 0; j < 4; ++j) { Q[4 * i + j] = i == j ? 0 : m.par[4 * i + j] * m.pi[j]; rs += Q[4 * i + j]; } Q[5 * i] = -rs; mu += m.pi[i] * rs; }
+		o += "Q:\n";
+		for(int i = 0; i < 4; ++i) o += num(Q[4 * i] / mu) + " " + num(Q[4 * i + 1] / mu) + " " + num(Q[4 * i + 2] / mu) + " " + num(Q[4 * i + 3] / mu) + "\n";
+	}
+	else if(m.type == HU_TN93) o += "kr: " + num(m.par[0]) + " ky: " + num(m.par[1]) + " beta: " + num(m.par[2]) + "\n";
+	else if(m.type == HU_HKY85) o += "kappa: " + num(m.par[0]) + " beta: " + num(m.par[1]) + "\n";
+	else if(m.type == HU_F81) o += "beta: " + num(m.par[0]) + "\n";
+	else if(m.type == HU_K80) o += "kappa: " + num(m.par[0]) + "\n";
+	return o;
+}
+extern "C" int hu_ptu_write(const char* path, const hu_tree_desc* t, const char* const* names, const char* const* annos, const hu_model_desc* model,
+		const char* model_text, double dg_alpha, const double* dg_breaks) {
+	if(!path || !t || !model || t->n_nodes < 2 || t->cs_len < 1 || !t->parent || !t->blen || !t->seq || !t->up || !t->down || !t->height) { hu_set_error("hu_ptu_write: bad argument"); return HU_ERR_ARG; }
+	if(model->type < 0 || model->type > HU_JC69 || model->dg_k < 0 || model->dg_k > HU_MAX_DGK) { hu_set_error("hu_ptu_write: bad model"); return HU_ERR_ARG; }
+	if(t->win_len > 0 && t->win_len != t->cs_len) { hu_set_error("hu_ptu_write: the file format holds whole messages, not a column window"); return HU_ERR_ARG; }
+	const int n = t->n_nodes, L = t->cs_len;
+	std::vector<std::vector<int32_t>> children(n);
+	int root = -1;
+	for(int i = 0; i < n; ++i) { if(t->parent[i] < 0) root = i; else if(t->parent[i] < n) children[t->parent[i]].push_back(i); else { hu_set_error("hu_ptu_write: parent out of range"); return HU_ERR_ARG; } }
+	if(root < 0) { hu_set_error("hu_ptu_write: tree has no root"); return HU_ERR_ARG; }
+	std::ofstream f(path, std::ios::binary);
+	if(!f) { hu_set_error("cannot write PTU file '%s'", path); return HU_ERR_IO; }
+	auto put = [&](const void* p, size_t k) { f.write((const char*) p, (std::streamsize) k); };
+	auto str = [&](const char* s_, size_t k) { const uint64_t len = k; put(&len, 8); if(k) put(s_, k); };
+	put("HmmUFOtu", 8); { const int32_t ver[3] = {1, 5, 1}; put(ver, 12); }
+	{ const uint64_t nn = (uint64_t) n; put(&nn, 8); const int32_t l = L; put(&l, 4); }
+	char tmp[32];
+	for(int i = 0; i < n; ++i) {
+		const int64_t id = i; put(&id, 8);
+		const char* nm = names && names[i] ? names[i] : (snprintf(tmp, sizeof(tmp), "n%d", i), tmp);
+		str(nm, strlen(nm));
+		const uint8_t withAbc = 0; put(&withAbc, 1);
+		str(nm, strlen(nm));
+		str((const char*)(t->seq + (size_t) i * L), (size_t) L);
+		const char* an = annos && annos[i] ? annos[i] : "";
+		str(an, strlen(an));
+		const double ad = t->anno_dist ? t->anno_dist[i] : 0.0; put(&ad, 8);
+	}
+	const uint64_t nEdges = 2ull * (n - 1); put(&nEdges, 8);
+	const size_t row = (size_t) L * 4;
+	double* stage = nullptr;
+	std::vector<double> hostRow;
+	if(t->msgs_on_device) { if(hipHostMalloc((void**) &stage, row * 8, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); hostRow.resize(row); stage = hostRow.data(); } }
+	auto msg = [&](const double* base, int node) -> const double* {
+		const double* p = base + (size_t) node * row;
+		if(!t->msgs_on_device) return p;
+		if(hipMemcpy(stage, p, row * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+		return stage;
+	};
+	bool ok = true;
+	for(int u = 0; u < n && ok; ++u) { /* both directions of every edge, grouped by their first node: parent first, then the children */
+		std::vector<int32_t> nb;
+		if(t->parent[u] >= 0) nb.push_back(t->parent[u]);
+		nb.insert(nb.end(), children[u].begin(), children[u].end());
+		for(int32_t v : nb) {
+			const bool uIsParent = t->parent[u] < 0 || v != t->parent[u];
+			const int child = uIsParent ? v : u;
+			const int64_t a = u, b2 = v; put(&a, 8); put(&b2, 8);
+			const uint8_t fl = uIsParent ? 1 : 0; put(&fl, 1);
+			const double len = t->blen[child]; put(&len, 8);
+			const uint64_t N = row; put(&N, 8);
+			const double* m = msg(uIsParent ? t->down : t->up, child);
+			if(!m) { ok = false; break; }
+			put(m, row * 8);
+		}
+	}
+	if(ok) {
+		const int64_t rid = root; put(&rid, 8);
+		const double* m = msg(t->up, root);
+		if(m) put(m, row * 8); else ok = false;
+	}
+	if(stage && hostRow.empty()) (void) hipHostFree(stage);
+	if(!ok) { hu_set_error("hu_ptu_write: copying a message from the device failed"); return HU_ERR_DEVICE; }
+	for(int i = 0; i < n; ++i) { const int64_t id = i; put(&id, 8); put(&t->height[i], 8); }
+	{ /* MSA index: the leaves in node order */
+		uint32_t nl = 0;
+		for(int i = 0; i < n; ++i) nl += children[i].empty();
+		put(&nl, 4);
+		uint32_t k = 0;
+		for(int i = 0; i < n; ++i) if(children[i].empty()) { put(&k, 4); const int64_t id = i; put(&id, 8); ++k; }
+	}
+	{
+		static const char* mnames[] = {"GTR", "TN93", "HKY85", "F81", "K80", "JC69"};
+		std::string mt = std::string(mnames[model->type]) + "\n" + (model_text ? std::string(model_text) : model_text_of(*model));
+		if(mt.empty() || mt.back() != '\n') mt += '\n';
+		put(mt.data(), mt.size());
+	}
+	const uint8_t hasDG = model->dg_k > 0; put(&hasDG, 1);
+	if(hasDG) {
+		const int32_t K = model->dg_k; put(&K, 4); put(&dg_alpha, 8);
+		for(int i = 0; i <= K; ++i) { const double b0 = dg_breaks ? dg_breaks[i] : 0.0; put(&b0, 8); }
+		put(model->dg_rate, (size_t) K * 8);
+	}
+	f.flush();
+	if(!f) { hu_set_error("writing PTU file '%s' failed", path); return HU_ERR_IO; }
+	return HU_OK;
 }
 
 /* the reference's own text forms, parsed from memory: what operator<<(ostream&, const BandedHMMP7&) and DNASubModel::write emit */

@@ -191,6 +191,28 @@ def tree_evaluate(parent, blen, seq, model: ModelDesc, up_ptr: int, down_ptr: in
     return seq, h
 
 
+def write_ptu(path, parent, blen, seq, up, down, height, model: ModelDesc, names=None, annos=None, anno_dist=None, model_text=None,
+              dg_alpha=0.0, dg_breaks=None, msgs_on_device=False):
+    """hu_ptu_write: the database file in the reference's .ptu format; up / down are [n][cs_len][4] arrays, or device pointers (ints)
+    with msgs_on_device=True."""
+    keep = dict(parent=np.ascontiguousarray(parent, np.int32), blen=np.ascontiguousarray(blen, np.float64), seq=np.ascontiguousarray(seq, np.int8),
+                height=np.ascontiguousarray(height, np.float64))
+    td = TreeDesc()
+    td.n_nodes, td.cs_len = keep["seq"].shape
+    td.parent = _p(keep["parent"], C.c_int32); td.blen = _p(keep["blen"], C.c_double); td.seq = _p(keep["seq"], C.c_int8); td.height = _p(keep["height"], C.c_double)
+    if msgs_on_device:
+        td.up = C.c_void_p(int(up)); td.down = C.c_void_p(int(down)); td.msgs_on_device = 1
+    else:
+        keep["up"] = np.ascontiguousarray(up, np.float64); keep["down"] = np.ascontiguousarray(down, np.float64)
+        td.up = keep["up"].ctypes.data_as(C.c_void_p); td.down = keep["down"].ctypes.data_as(C.c_void_p)
+    if anno_dist is not None:
+        keep["ad"] = np.ascontiguousarray(anno_dist, np.float64); td.anno_dist = _p(keep["ad"], C.c_double)
+    arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs]) if xs is not None else None
+    br = np.ascontiguousarray(dg_breaks, np.float64) if dg_breaks is not None else None
+    _chk(load_library().hu_ptu_write(path.encode(), C.byref(td), arr(names), arr(annos), C.byref(model), model_text.encode() if model_text else None,
+                                     C.c_double(dg_alpha), _p(br, C.c_double) if br is not None else None))
+
+
 class SeedIndex:
     """Host k-mer index standing in for the CSFM lookup of alignSeq (hu_seed_index_*)."""
 

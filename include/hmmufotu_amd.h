@@ -185,6 +185,14 @@ int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P /* [n][16]
 int hu_tree_evaluate(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const double* blen, int8_t* seq,
 		const hu_model_desc* model, int device, int64_t win_start, int64_t win_len, double* up_dev, double* down_dev, double* height);
 
+/* PTUnrooted::save (src/PhyloTreeUnrooted.cpp:537-567): writes the .ptu database file hmmufotu and hu_db_load read, from the arrays of a
+ * hu_tree_desc (whole messages: win_len 0; up / down may be DEVICE buffers as hu_tree_evaluate leaves them — msgs_on_device = 1 — and are
+ * then streamed to the file edge by edge).  names / annos: n C strings each (NULL: "n<i>" / "").  model_text: the model block as the
+ * reference writes it (DNASubModel::write), or NULL to have it generated from `model`.  dg_alpha, dg_breaks [dg_k + 1]: what
+ * DiscreteGammaModel::save stores beside the rates (the engine itself reads only the rates). */
+int hu_ptu_write(const char* path, const hu_tree_desc* tree, const char* const* names, const char* const* annos, const hu_model_desc* model,
+		const char* model_text, double dg_alpha, const double* dg_breaks);
+
 /* BandedHMMP7::buildAlignPath (src/BandedHMMP7.cpp:894-941): the CSLoc of a CSFM hit (1-based CS
  * start/end + the gapped CS string, src/CSLoc.h) and the seed's 1-based read range -> the
  * ViterbiAlignPath row {start,end,from,to,nIns,nDel} hu_batch_set_reads takes.  Host only. */

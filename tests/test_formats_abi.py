@@ -130,3 +130,26 @@ def test_seed_index_matches_generator_paths():
     assert not ix.lookup(["ACGT" * 30], 50, 0).any() or True
     vp2 = ix.lookup([reads[0][:30]], 50, 0)               # short read: only a 5' seed (len < 2 * region)
     assert vp2[0, 0, 0] > 0 and vp2[0, 1, 0] == 0
+
+
+def test_native_ptu_writer_matches_the_python_writer_byte_for_byte(tmp_path):
+    """hu_ptu_write (PTUnrooted::save restated in the library; host arrays here, no device needed) against synth.write_ptu, an
+    independent reading of SURVEY.md Appendix B; and the generated model block parses back to the same parameters"""
+    from hmmufotu_amd import engine as E, synth
+    import filecmp
+    for model, dg_k in (("GTR", 4), ("TN93", 0), ("K80", 2), ("JC69", 0), ("HKY85", 0), ("F81", 3)):
+        db = synth.make_db(24, 160, model, dg_k=dg_k, seed=5)
+        a, b, c = str(tmp_path / "py.ptu"), str(tmp_path / "native.ptu"), str(tmp_path / "gen.ptu")
+        synth.write_ptu(db, a)
+        md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if dg_k else None)
+        kw = dict(names=db.names, annos=db.annos, anno_dist=db.anno_dist, dg_alpha=db.dg_alpha, dg_breaks=db.dg_b if dg_k else None)
+        E.write_ptu(b, db.parent, db.blen, db.seq, db.up, db.down, db.height, md, model_text=db.model.text, **kw)
+        assert filecmp.cmp(a, b, shallow=False), model
+        E.write_ptu(c, db.parent, db.blen, db.seq, db.up, db.down, db.height, md, model_text=None, **kw)      # model block generated
+        got = E.parse_files(None, c)
+        assert got["model"].type == db.model.type_id and got["model"].dg_k == dg_k
+        if model not in ("K80", "JC69"):
+            assert np.allclose(list(got["model"].pi), db.model.pi, rtol=0, atol=1e-16)
+        npar = {"GTR": 16, "TN93": 3, "HKY85": 2, "F81": 1, "K80": 1, "JC69": 0}[model]
+        assert np.array_equal(np.array(list(got["model"].par))[:npar], np.asarray(db.model.par, float).ravel()[:npar])
+        assert np.array_equal(got["up"], db.up) and np.array_equal(got["parent"], db.parent)

@@ -1117,3 +1117,34 @@ def test_fix_root_loglik_flag(model, dg_k):
     assert len(lods) >= len(reads) // 2 and max(abs(x) for x in lods) > 1e-3
     print("fix-root-loglik: picks differing by an exact key tie:", differ, "; chimera log-odds compared:", len(lods))
     W.close(); B.close(); D.close()
+
+
+def test_build_database_on_device_and_write_it(tmp_path):
+    """the reduced hmmufotu-build path end to end on the device side: leaf rows -> hu_tree_evaluate (messages stay in HBM)
+    -> hu_ptu_write streaming them to a .ptu -> hu_db_load streaming them back: same file as the host-array route, same placements"""
+    E = _engine()
+    import filecmp
+    import torch
+    from hmmufotu_amd import synth
+    db = get_db(60, 400, "GTR", dg_k=4, seed=3)
+    n, L = db.seq.shape
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+    up = torch.zeros((n, L, 4), dtype=torch.float64, device="cuda:0"); down = torch.zeros_like(up)
+    leaf_only = np.where(db.is_leaf[:, None], db.seq, 0).astype(np.int8)
+    seq, h = E.tree_evaluate(db.parent, db.blen, leaf_only, md, up.data_ptr(), down.data_ptr())
+    torch.cuda.synchronize()
+    kw = dict(names=db.names, annos=db.annos, anno_dist=db.anno_dist, model_text=db.model.text, dg_alpha=db.dg_alpha, dg_breaks=db.dg_b)
+    a, b = str(tmp_path / "dev.ptu"), str(tmp_path / "host.ptu")
+    E.write_ptu(a, db.parent, db.blen, seq, up.data_ptr(), down.data_ptr(), h, md, msgs_on_device=True, **kw)
+    E.write_ptu(b, db.parent, db.blen, seq, up.cpu().numpy(), down.cpu().numpy(), h, md, **kw)
+    assert filecmp.cmp(a, b, shallow=False)
+    hp = str(tmp_path / "t.hmm"); synth.write_hmm(db.hmm, hp)
+    D1 = E.Database.load(hp, a); D2 = E.Database.from_synth(db)
+    reads, vps = sim_reads(db, 8, 100)
+    outs = []
+    for D in (D1, D2):
+        B = E.Batch(D, 8); B.set_reads([r.seq for r in reads], vps); B.assign(E.default_opts()); outs.append(B.placements().copy()); B.close()
+    for k in ("c_node", "a_node", "n_cand"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert np.allclose(outs[0]["ratio"], outs[1]["ratio"], rtol=1e-9, atol=1e-12)      # device-evaluated vs numpy-evaluated messages: 1e-9 apart
+    D1.close(); D2.close()
