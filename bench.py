@@ -333,6 +333,9 @@ def main():
                                     "batch %d reads/step/GPU, %d batches in flight" % ("SILVA-scale" if args.leaves >= 150000 else "gg_97_otus-scale" if args.leaves >= 90000 else "reduced-scale", D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
                                                                                          shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb),
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
+               timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
+                            "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: the product CLI's end-to-end rate is "
+                            "profiles/r02_cli_throughput.json",
                rccl_ranks=rccl_ranks, backend=backend if world > 1 else None, gathered_records=(int(len(gathered)) if world > 1 else None),
                roofline=roof, roofline_kernels=kern, roofline_path=path,
                kernel_ms={k: round(v, 3) for k, v in acc.items()}, kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},

@@ -13,6 +13,9 @@ cd /tmp; export TMPDIR=/tmp
 short="--steps 2 --warmup 0 --cpu-sample 0 --inflight 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --cpu-sample 0 "$@" > $out/bench_profiled.json 2> $out/stats.err || exit 1
 echo "stats pass done"
+# the same with ONE batch in flight: every launch alone on the GPU -> the average duration bench.py's `roofline.ms` (isolated) must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python3 $root/bench.py --cpu-sample 0 --inflight 1 --steps 8 --warmup 2 "$@" > $out/bench_profiled_inflight1.json 2> $out/stats1.err || exit 1
+echo "stats (one batch in flight) pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $root/bench.py $short "$@" > $out/fetch.json 2> $out/fetch.err || exit 1
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 $root/bench.py $short "$@" > $out/write.json 2> $out/write.err || exit 1
@@ -29,5 +32,6 @@ for d in fetch write sq valu; do
 	[ -n "$f" ] && (head -1 $f; grep -E '"(void )?k_' $f) > $out/${d}_engine.csv
 done
 f=$(ls $out/stats/*/*kernel_stats.csv $out/stats/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
-rm -rf $out/stats $out/fetch $out/write $out/sq $out/valu
+f=$(ls $out/stats1/*/*kernel_stats.csv $out/stats1/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_inflight1.csv
+rm -rf $out/stats $out/stats1 $out/fetch $out/write $out/sq $out/valu
 ls -la $out

@@ -64,6 +64,14 @@ mine = [r for r in rows if clean(r['Name']).startswith('k_')]
 with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); [w.writerow(r) for r in mine]
 shutil.copy(os.path.join(d, "bench_profiled.json"), "profiles/bench_%s_profiled.json" % tag)
+one = {}
+p1 = os.path.join(d, "kernel_stats_inflight1.csv")
+if os.path.exists(p1):
+    r1 = [r for r in csv.DictReader(open(p1)) if clean(r['Name']).startswith('k_')]
+    one = {clean(r['Name']): r for r in r1}
+    with open("profiles/%s_kernel_stats_inflight1.csv" % tag, "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(r1[0].keys())); w.writeheader(); [w.writerow(r) for r in r1]
+    shutil.copy(os.path.join(d, "bench_profiled_inflight1.json"), "profiles/bench_%s_profiled_inflight1.json" % tag)
 for x in ("fetch", "write", "sq", "valu"):
     shutil.copy(os.path.join(d, x + "_engine.csv"), "profiles/%s_pmc_%s.csv" % (tag, x))
 onetime = lambda nm: nm.startswith(('k_pack', 'k_tree', 'k_model', 'k_col'))
@@ -82,8 +90,8 @@ with open("profiles/%s_summary.md" % tag, "w") as f:
     f.write("# %s: rocprofv3 --kernel-trace --stats + PMC passes\n\n" % tag)
     f.write("Stats command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --cpu-sample 0 <workload flags>`; bench line of that (profiled) run: "
             "%.0f %s, %.2f ms/step.  Workload: %s\n\n" % (bench["value"], bench["unit"], bench["ms_per_step"], bench["config"]["workload"]))
-    f.write("| kernel | calls | rocprof avg ms (all calls: overlapping batches + batch alone) | bench.py HIP events: in the timed region / one batch alone | HBM GB per launch (PMC) | "
-            "HBM GB/s alone (% of 8 TB/s) | VALU wave-instr per launch (FP64 share) | VALU issue: % of the SIMDs' cycles alone | VALU active / wave cycle | L2 hit |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    f.write("| kernel | calls | rocprof avg ms, six batches in flight (+ the 3 isolated steps at the end) | rocprof avg ms, one batch in flight (`--inflight 1`) | bench.py HIP events: in the timed region / one batch alone | HBM GB per launch (PMC) | "
+            "HBM GB/s alone (% of 8 TB/s) | VALU wave-instr per launch (FP64 share) | VALU issue: % of the SIMDs' cycles alone | VALU active / wave cycle | L2 hit |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     for r in sorted(mine, key=lambda r: -int(r['TotalDurationNs'])):
         nm = clean(r['Name'])
         if onetime(nm):
@@ -91,8 +99,8 @@ with open("profiles/%s_summary.md" % tag, "w") as f:
         e = out.get(nm, {}); b = km.get(nm)
         ms = b["ms_isolated"] if b else None
         hb = e.get("hbm_bytes_per_launch")
-        f.write("| %s | %s | %.3f | %s | %s | %s | %s | %s | %s | %s |\n" % (
-            nm, r['Calls'], float(r['AverageNs']) / 1e6,
+        f.write("| %s | %s | %.3f | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
+            nm, r['Calls'], float(r['AverageNs']) / 1e6, "%.3f" % (float(one[nm]['AverageNs']) / 1e6) if nm in one else "",
             "%.2f / %.2f" % (b["ms_in_timed_region"], b["ms_isolated"]) if b else "",
             "%.2f" % (hb / 1e9) if hb else "",
             "%.0f (%.0f %%)" % (hb / ms / 1e6, hb / ms / 1e6 / 80) if hb and ms else "",
