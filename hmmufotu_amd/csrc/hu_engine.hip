@@ -693,6 +693,7 @@ struct HuKnobs {
 	int vw_diag = 0;             /* k_viterbi_wave diagnostics variant                                               */
 	int viterbi_force_redo = 0;  /* flag every traceback "needs values": the redo pass runs for all sequences        */
 	int pdist_v1 = 0;            /* the per-read insert loop scan kernel                                             */
+	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
@@ -707,7 +708,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -752,7 +753,7 @@ struct hu_batch {
 	DBuf<uint16_t> dPerm;
 	PinnedVec<int32_t> hPermCnt;
 	DBuf<uint32_t> dRp, dPairs, dSeedDN;
-	DBuf<int32_t> dTileQ;
+	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<int32_t> dIns, dTileIns;
 	DBuf<uint32_t> dSortK, dSortV;
@@ -956,9 +957,29 @@ static int ensure_read_buffers(hu_batch* b) {
 	if((rc = b->dEnd.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dRp.ensure(tiles * d.WQ * HU_READ_TILE * 16)) != HU_OK) return rc;
 	if((rc = b->dTileQ.ensure(tiles * (d.WQ + 1))) != HU_OK) return rc;
+	if((rc = b->dSlotRead.ensure(std::max<size_t>(tiles, 1) * HU_READ_TILE)) != HU_OK) return rc;
+	if((rc = b->dReadSlot.ensure(std::max<size_t>(n, 1))) != HU_OK) return rc;
 	if((rc = b->dRq.ensure(std::max<size_t>(n, 1) * ((d.WQ + 31) / 32))) != HU_OK) return rc;
 	if((rc = b->dIns.ensure(std::max<size_t>(n, 1) * (HU_MAX_INS + 1))) != HU_OK) return rc;
 	if((rc = b->dTileIns.ensure(std::max<size_t>(tiles, 1) * (HU_READ_TILE * HU_MAX_INS + 1))) != HU_OK) return rc;
+	return HU_OK;
+}
+
+/* the scan's tiling: reads sorted by the first column of their region (from the alignments, or from dStart / dEnd when alns is NULL) */
+static int tile_reads(hu_batch* b, const HuAlnDev* alns) {
+	const int n = b->n;
+	if(!n) return HU_OK;
+	const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
+	int rc;
+	if((rc = b->dSortK.ensure((size_t) n * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) n * 2)) != HU_OK) return rc;
+	size_t tb = 0;
+	HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + n, b->dSortV.p, b->dSortV.p + n, n, 0, 32, b->stream));
+	if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
+	k_tile_keys<<<(n + 255) / 256, 256, 0, b->stream>>>(n, alns, b->dStart.p, b->dEnd.p, b->dSortK.p, b->dSortV.p);
+	if(b->knob.tile_unsorted) HIPCHK(hipMemcpyAsync(b->dSortV.p + n, b->dSortV.p, (size_t) n * 4, hipMemcpyDeviceToDevice, b->stream));   /* tiles in read order */
+	else HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + n, b->dSortV.p, b->dSortV.p + n, n, 0, 32, b->stream));
+	k_tile_slots<<<(tiles * HU_READ_TILE + 255) / 256, 256, 0, b->stream>>>(n, tiles * HU_READ_TILE, b->dSortV.p + n, b->dSlotRead.p, b->dReadSlot.p);
+	HIPCHK(hipGetLastError());
 	return HU_OK;
 }
 
@@ -997,8 +1018,9 @@ static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKi
 		HIPCHK(hipMemcpyAsync(b->dEnd.p, b->hEnd.data(), (size_t) n * 4, hipMemcpyHostToDevice, b->stream));
 		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
 		HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
-		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
-		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p);
+		if((rc = tile_reads(b, nullptr)) != HU_OK) return rc;
+		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p);
+		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p);
 		HIPCHK(hipGetLastError());
 	}
 	b->state = ST_ALIGNED;
@@ -1133,8 +1155,9 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			if(b->paired) k_merge_rows<<<b->n, 256, 0, b->stream>>>(d, b->n, o->ignore_orient, b->dRows.p, b->dAlns.p);
 			const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 			HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
-			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p);
-			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p);
+			if((rc = tile_reads(b, b->dAlns.p)) != HU_OK) return rc;
+			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p);
+			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p);
 		}
 		HIPCHK(hipGetLastError());
 		b->hAlns.resize(b->nSeq);
@@ -1168,9 +1191,9 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->n);
-			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->n);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
+			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
+			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
@@ -1226,8 +1249,8 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		HIPCHK(hipMemcpyAsync(b->dGiven.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->n);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->n);
+			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
 		}
 		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dGiven.p, b->dGiven.p + n,
 				dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);

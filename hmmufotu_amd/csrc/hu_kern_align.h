@@ -1144,9 +1144,12 @@ __global__ __launch_bounds__(256) void k_merge_rows(HuDbDev db, int n, int ignor
 /* DigitalSeq codes of the aligned row + region + bit-planes for the seed scan (in scan order, see
  * HuDbDev::posCol) + the read's bitmap of quads that hold at least one of its bases.
  * rp layout: rp[((tile*WQ + q) * T + t) * 16 + p*4 + w], zero outside [csStart-1, csEnd-1]. */
-__device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restrict__ cd, int start, int end, int r, int lane,
+/* slot: the read's place in the scan's tiling — reads sorted by the first column of their region (k_tile_keys + radix sort), so that the
+ * sixteen reads of a tile cover the same few quads whatever order the reads came in (with uniform read starts a tile in read order
+ * is the union of sixteen unrelated windows: 10.4 ms against 3.6 ms for the scan); quad bitmap and insert list stay indexed by read */
+__device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restrict__ cd, int start, int end, int r, int slot, int lane,
 		uint32_t* __restrict__ rp, uint32_t* __restrict__ rq, int32_t* __restrict__ ins) {
-	const int tile = r / HU_READ_TILE, t = r % HU_READ_TILE;
+	const int tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
 	const int nw32 = (db.WQ + 31) / 32;
 	uint32_t* qbits = rq + (size_t) r * nw32;
 	int32_t* il = ins + (size_t) r * (HU_MAX_INS + 1);   /* [0] = count, then (scan position << 2 | base code) */
@@ -1189,7 +1192,7 @@ __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restri
 
 __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, HuAlnDev* __restrict__ alns,
 		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
-		int32_t* __restrict__ ins) {
+		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot) {
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const HuAlnDev a = alns[r];
 	const char* row = rows + (size_t) r * db.csLen;
@@ -1211,28 +1214,46 @@ __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __re
 		cd[c] = c_sym_map[(int) ch & 127];
 	}
 	__syncthreads();
-	planes_of_codes(db, cd, start, end, r, lane, rp, rq, ins);
+	planes_of_codes(db, cd, start, end, r, readSlot[r], lane, rp, rq, ins);
 }
 
 /* same, when the caller supplies DigitalSeq codes directly (hu_batch_set_aligned) */
 __global__ __launch_bounds__(64) void k_planes_from_codes(HuDbDev db, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
-		int32_t* __restrict__ ins) {
+		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot) {
 	const int r = blockIdx.x, lane = threadIdx.x;
-	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, lane, rp, rq, ins);
+	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, readSlot[r], lane, rp, rq, ins);
+}
+
+/* sort keys of the tiling: first column of the region, reads without one last; vals = read index */
+__global__ void k_tile_keys(int n, const HuAlnDev* __restrict__ alns, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
+		uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+	const int r = blockIdx.x * 256 + threadIdx.x;
+	if(r >= n) return;
+	uint32_t k;
+	if(alns) k = alns[r].status == HU_READ_OK ? (uint32_t) alns[r].csStart : 0x7fffffffu;
+	else k = rend[r] >= rstart[r] ? (uint32_t) rstart[r] + 1u : 0x7fffffffu;
+	key[r] = k; val[r] = (uint32_t) r;
+}
+/* slotRead[slot] = read (-1 past n), readSlot[read] = slot */
+__global__ void k_tile_slots(int n, int nSlots, const uint32_t* __restrict__ sortedRead, int32_t* __restrict__ slotRead, int32_t* __restrict__ readSlot) {
+	const int s = blockIdx.x * 256 + threadIdx.x;
+	if(s >= nSlots) return;
+	if(s < n) { const int r = (int) sortedRead[s]; slotRead[s] = r; readSlot[r] = s; }
+	else slotRead[s] = -1;
 }
 
 /* per scan tile: the quads in which any of its reads has a base -> tileQ[tile][0] = count, [1..] = quads; and the
  * reads' insert lists as one list, tileIns[tile][0] = count, [1..] = read t << 24 | (scan position << 2 | base) */
 __global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint32_t* __restrict__ rq, const int32_t* __restrict__ ins,
-		int32_t* __restrict__ tileQ, int32_t* __restrict__ tileIns) {
+		int32_t* __restrict__ tileQ, int32_t* __restrict__ tileIns, const int32_t* __restrict__ slotRead) {
 	const int tile = blockIdx.x, lane = threadIdx.x;
 	const int nw32 = (db.WQ + 31) / 32;
 	int32_t* out = tileQ + (size_t) tile * (db.WQ + 1);
 	int cnt = 0;
 	for(int w = 0; w < nw32; ++w) { /* WQ <= 512: at most 16 words; lane 0 writes the compacted list */
 		uint32_t m = 0;
-		if(lane < HU_READ_TILE) { const int r = tile * HU_READ_TILE + lane; if(r < n) m = rq[(size_t) r * nw32 + w]; }
+		if(lane < HU_READ_TILE) { const int r = slotRead[tile * HU_READ_TILE + lane]; if(r >= 0) m = rq[(size_t) r * nw32 + w]; }
 		for(int s = 32; s > 0; s >>= 1) m |= __shfl_xor(m, s);
 		if(lane == 0) while(m) { const int b = __ffs(m) - 1; m &= m - 1; out[1 + cnt++] = w * 32 + b; }
 	}
@@ -1241,8 +1262,8 @@ __global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint
 		int32_t* til = tileIns + (size_t) tile * (HU_READ_TILE * HU_MAX_INS + 1);
 		int ne = 0;
 		for(int t = 0; t < HU_READ_TILE; ++t) {
-			const int r = tile * HU_READ_TILE + t;
-			if(r >= n) break;
+			const int r = slotRead[tile * HU_READ_TILE + t];
+			if(r < 0) continue;
 			const int32_t* il = ins + (size_t) r * (HU_MAX_INS + 1);
 			for(int e = 0; e < il[0]; ++e) til[1 + ne++] = (t << 24) | il[1 + e];
 		}

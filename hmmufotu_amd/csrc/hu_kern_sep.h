@@ -54,7 +54,7 @@ __device__ inline uint32_t hu_pair_load(const void* pairs, size_t idx, int p16) 
  * CUs, was the limiter.  Reads [t0, t0 + T) of the 16-read layout tile blockIdx.x / (16 / T). */
 template<int T, int M, bool NOCOUNT = false>
 __global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ ins, uint32_t* __restrict__ pairs, int nReads) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ ins, uint32_t* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
 	constexpr int SPLIT = HU_READ_TILE / T;
 	const int tile = blockIdx.x / SPLIT, t0 = (blockIdx.x % SPLIT) * T;
 	const int node0 = blockIdx.y * (256 * M) + threadIdx.x;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* 
 	/* the reads' bases in non-profile columns (alignment inserts): one node word per listed position */
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
-		const int read = tile * HU_READ_TILE + t0 + t;
-		if(read >= nReads) continue;
+		const int read = slotRead[tile * HU_READ_TILE + t0 + t];
+		if(read < 0) continue;
 		const int32_t* __restrict__ il = ins + (size_t) read * (HU_MAX_INS + 1);
 		const int cnt = il[0];
 		for(int e = 0; e < cnt; ++e) {
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* 
 		if(node >= db.nNodesPad) continue;
 #pragma unroll
 		for(int t = 0; t < T; ++t) {
-			const int read = tile * HU_READ_TILE + t0 + t;
-			if(read < nReads) pairs[(size_t) read * np + node] = (d[m][t] << 16) | N[m][t];
+			const int read = slotRead[tile * HU_READ_TILE + t0 + t];
+			if(read >= 0) pairs[(size_t) read * np + node] = (d[m][t] << 16) | N[m][t];
 		}
 	}
 }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
  * hoisting all sixteen request / wait pairs in front of the vector work cost more than the latency four waves per SIMD already hide. */
 template<class PT>
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, int nReads) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
 	constexpr int T = HU_READ_TILE;
 	__shared__ uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 	}
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
-		const int read = tile * T + t;
-		if(read < nReads) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
+		const int read = slotRead[tile * T + t];
+		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
 	}
 }
 

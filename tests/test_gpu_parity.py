@@ -347,6 +347,33 @@ def test_seed_getters_respect_the_callers_stride():
     B.close(); D.close()
 
 
+def test_scan_tiling_is_invisible():
+    """the seed scan tiles sixteen reads that start at neighbouring columns (reads sorted by region start on the device); with reads
+    whose regions are scattered over the whole consensus the tiles differ completely from read order — the results must not"""
+    E = _engine()
+    db = get_db(300, 2000, "GTR", dg_k=4, seed=7)
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 40, 120, amplicon=False)             # uniform window starts (src/hmmufotu-sim.cpp:371)
+    opts = E.default_opts()
+    res = []
+    for unsorted in (0, 1):
+        D = E.Database.from_synth(db); B = E.Batch(D, 64)
+        B.set_knob("tile_unsorted", unsorted)
+        B.set_reads([r.seq for r in reads], vps); B.assign(opts)
+        cd, st, en = B.codes()
+        res.append((B.seeds(), B.placements().copy(), [B.pdist(i) for i in (0, 17, 39)]))
+        if not unsorted:
+            assert st.max() - st.min() > 800                        # really scattered
+            for k, i in enumerate((0, 17, 39)):
+                od, oN = T.pdist_all(cd[i], int(st[i]), int(en[i]))
+                assert (res[0][2][k][0] == od).all() and (res[0][2][k][1] == oN).all()
+        B.close(); D.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for k in ("c_node", "a_node", "ratio", "wnr", "q_place"):
+        assert np.array_equal(res[0][1][k], res[1][1][k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("read_len", [150, 300])
 def test_pair_matrix_widths(read_len):
     """(d, N) pairs are kept in 16 bits when no read of the batch has more than 255 bases in its region, else in 32 (reads of 300 bp
