@@ -1,8 +1,6 @@
 """End-to-end throughput of the product CLI (hmmufotu-amd: parse -> seed lookup -> engine -> TSV) on the GPU box.
-A 20,000-leaf x 7,682-column GTR+dGamma(4) database is built on the device, written in the reference's file formats to
-/dev/shm (a gg_97-scale .ptu is 98 GB: the box's scratch space is not known to hold it), 1 M SE 250 bp reads as FASTA.
-The smaller tree makes the ENGINE faster than at gg_97 scale, so this measures what the host pipeline can feed; the engine's
-own rate at gg_97 scale is bench.py's.  Usage: python profiles/measure_cli.py [leaves] [reads] -> JSON line"""
+A <leaves>-leaf x 7,682-column GTR+dGamma(4) database (default 99,322 = gg_97 scale: a 99 GB .ptu) is built on the device and written
+in the reference's file formats to /dev/shm straight from HBM (hu_ptu_write), 1 M SE 250 bp reads as FASTA.  Usage: python profiles/measure_cli.py [leaves] [reads] -> JSON line"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +8,7 @@ import numpy as np
 import torch
 from hmmufotu_amd import synth, synth_gpu
 
-leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 99322
 nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 tmp = os.environ.get("HU_CLI_TMP", "/dev/shm/hu_cli")
 os.makedirs(tmp, exist_ok=True)
@@ -21,11 +19,14 @@ reads = []
 for i in range(0, nreads, 65536):
     n = min(65536, nreads - i)
     reads += [r.seq for r in synth_gpu.simulate_reads_gpu(db, up, down, n, 250, seed=1 + i, amplicon_start=1000, amplicon_cols=1372, device="cuda:0")]
-db.up = up.cpu().numpy(); db.down = down.cpu().numpy()
-del up, down; torch.cuda.empty_cache()
-db.names = ["n%d" % i for i in range(db.n_nodes)]; db.annos = ["k__Synth;p__clade%d" % db.anno_id[i] for i in range(db.n_nodes)]
+from hmmufotu_amd import engine as E
+names = ["n%d" % i for i in range(db.n_nodes)]; annos = ["k__Synth;p__clade%d" % db.anno_id[i] for i in range(db.n_nodes)]
 pre = os.path.join(tmp, "db")
-synth.write_hmm(db.hmm, pre + ".hmm"); synth.write_ptu(db, pre + ".ptu")
+synth.write_hmm(db.hmm, pre + ".hmm")
+md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+E.write_ptu(pre + ".ptu", db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, names=names, annos=annos, model_text=db.model.text,
+            dg_alpha=db.dg_alpha, dg_breaks=db.dg_b, msgs_on_device=True)          # straight from HBM: no host copy of the messages
+del up, down; torch.cuda.empty_cache()
 fa = os.path.join(tmp, "reads.fasta")
 with open(fa, "w") as f:
     for i, r in enumerate(reads):
@@ -34,14 +35,14 @@ log("inputs written: ptu %.1f GB, fasta %.0f MB (%.0fs)" % (os.path.getsize(pre 
 del db
 cli = os.path.join(ROOT, "hmmufotu_amd", "bin", "hmmufotu-amd")
 res = {}
-for name, extra in (("devnull", ["-o", "/dev/null"]), ("shm_file", ["-o", os.path.join(tmp, "out.tsv")]), ("align_only_devnull", ["-o", "/dev/null", "--align-only"])):
+for name, extra in (("shm_file", ["-o", os.path.join(tmp, "out.tsv")]), ("devnull", ["-o", "/dev/null"])):
     t1 = time.time()
     p = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--inflight", os.environ.get("HU_CLI_INFLIGHT", "4")] + extra, capture_output=True, text=True)
     wall = time.time() - t1
     line = [l for l in p.stderr.splitlines() if l.startswith("read loop:")]
     log(name, "rc", p.returncode, "wall %.1fs" % wall, line)
     rate = float(line[0].split(" = ")[1].split()[0]) if line else None
-    res[name] = dict(rc=p.returncode, wall_s=round(wall, 1), read_loop_reads_per_s=rate, stderr_tail=p.stderr.splitlines()[-3:])
+    res[name] = dict(rc=p.returncode, wall_s=round(wall, 1), read_loop_reads_per_s=rate, stderr_tail=p.stderr.splitlines()[-6:])
     if name == "shm_file" and p.returncode == 0:
         res[name]["output_gb"] = os.path.getsize(os.path.join(tmp, "out.tsv")) / 1e9
         os.remove(os.path.join(tmp, "out.tsv"))
