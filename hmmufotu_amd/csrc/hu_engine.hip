@@ -1469,17 +1469,20 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			}
 			else if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				DBuf<long long> ddb;
-				if((rc = ddb.ensure(nc * 8)) != HU_OK) return rc;
+				if((rc = ddb.ensure(nc * 12)) != HU_OK) return rc;
 				long long* dd = ddb.p;
+				HIPCHK(hipMemsetAsync(dd, 0, nc * 12 * sizeof(long long), b->stream));
 				if(var == 99) k_place_blk<6, 4, 3, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
 				else k_place_blk<12, 2, 3, 0, 2, true, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, dd);
-				std::vector<long long> hd(nc * 8);
-				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 8 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+				std::vector<long long> hd(nc * 12);
+				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 12 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
 				HIPCHK(hipStreamSynchronize(b->stream));
-				double acc[8] = {0};
-				for(size_t c = 0; c < nc; ++c) for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i];
+				double acc[8] = {0}, ae[4] = {0};
+				for(size_t c = 0; c < nc; ++c) { for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i]; for(int i = 0; i < 4; ++i) ae[i] += (double) hd[nc * 8 + c * 4 + i]; }
 				fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
 						acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
+				fprintf(stderr, "[place dbg] inside the EM steps, per step: arithmetic %.0f wave reduction %.0f exchange between the waves %.0f tail %.0f\n",
+						ae[0] / acc[6], ae[1] / acc[6], ae[2] / acc[6], ae[3] / acc[6]);
 			}
 			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
 			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);

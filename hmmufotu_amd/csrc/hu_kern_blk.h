@@ -384,10 +384,18 @@ __device__ __attribute__((noinline)) double hu_exp_call(double x) { return exp(x
 __device__ __attribute__((noinline)) double hu_log_call(double x) { return log(x); }
 
 /* EMV: Newton steps on v_rcp_f64 (2^-23 or better): 1 -> 2^-46 per term (a 1e-14 relative bias on the branch
- * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: 0 = DPP butterfly, 1 = MFMA. */
+ * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: 0 = DPP butterfly, 1 = MFMA.
+ * Measured and not kept (round 2): s_memtime stamps put a step of the 12-site kernel at 680 ticks of arithmetic + 378 of wave reduction and
+ * exchange + 200 of tail.  Shortening the second half — row sums only on the DPP network, the 4 NW row sums handed over through LDS as a
+ * broadcast read, the tail's factors computed before the exchange — changed nothing (8.80 against 8.86 ms), nor did the stage-by-stage
+ * arithmetic below (8.90 against 8.87): a step lasts as long as the SLOWER of the two waves needs for its arithmetic beside whatever shares
+ * its SIMD; the chain behind it is waiting for the partner, not instruction latency. */
 template<int SPT, int NW, int EMV, int RED>
 __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave, double w0, double maxL,
-		double* red, double* redc, int& phase, int& emIters) {
+		double* red, double* redc, int& phase, int& emIters, long long* st = nullptr) {
+	/* st (diagnostic build only): s_memtime ticks of a step's arithmetic, wave reduction, exchange between the waves, tail */
+	long long tl = st ? (long long) __builtin_amdgcn_s_memtime() : 0;
+	auto stamp = [&](int i) { if(st) { const long long t = (long long) __builtin_amdgcn_s_memtime(); st[i] += t - tl; tl = t; } };
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	double q0 = hu_exp_call(-w0), p0 = 1 - q0, p = p0, q = q0, rc = 0;
 	if(lane == 0) redc[(phase & 1) * NW + wave] = (double) nvalidWave;
@@ -396,15 +404,30 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 		const bool fast = q0 >= 1e-30 && p0 >= 1e-30; /* x = rho q0 + p0 in [1e-30, 1e60]; skipped sites add < 1e-30 */
 		if(fast) {
 			if(EMV == 3 && SPT % 4 == 0) { /* one reciprocal per four sites: 1/a + 1/b + 1/c + 1/d = ((a + b) cd + (c + d) ab) / (abcd);
-				                             * a .. d in [1e-30, 1e60] (skipped sites: 1e60 q0 + p0), so the products stay in range */
+				                             * a .. d in [1e-30, 1e60] (skipped sites: 1e60 q0 + p0), so the products stay in range.
+				                             * Written STAGE BY STAGE over the groups of four (same operations, same order of the sum): left to
+				                             * itself the compiler emits one group after the other, each a chain of ~8 dependent FP64
+				                             * operations, and an in-order wave with one partner on its SIMD stalls at every link */
+				constexpr int G = SPT / 4;
+				double x[SPT], ab[G], cd[G], X[G], nm[G], y[G], w[G];
 #pragma unroll
-				for(int t = 0; t < SPT; t += 4) {
-					const double a = fma(rho[t], q0, p0), bb = fma(rho[t + 1], q0, p0), c = fma(rho[t + 2], q0, p0), d = fma(rho[t + 3], q0, p0);
-					const double ab = a * bb, cd = c * d, x = ab * cd;
-					const double num = fma(a + bb, cd, (c + d) * ab);
-					const double y = __builtin_amdgcn_rcp(x);
-					s = fma(num * y, fma(-x, y, 2.0), s);
-				}
+				for(int t = 0; t < SPT; ++t) x[t] = fma(rho[t], q0, p0);
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for(int g = 0; g < G; ++g) { ab[g] = x[4 * g] * x[4 * g + 1]; cd[g] = x[4 * g + 2] * x[4 * g + 3]; }
+#pragma unroll
+				for(int g = 0; g < G; ++g) { X[g] = ab[g] * cd[g]; x[4 * g] += x[4 * g + 1]; x[4 * g + 2] += x[4 * g + 3]; }
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for(int g = 0; g < G; ++g) { y[g] = __builtin_amdgcn_rcp(X[g]); nm[g] = x[4 * g + 2] * ab[g]; }
+#pragma unroll
+				for(int g = 0; g < G; ++g) nm[g] = fma(x[4 * g], cd[g], nm[g]);
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for(int g = 0; g < G; ++g) { w[g] = fma(-X[g], y[g], 2.0); nm[g] *= y[g]; }
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for(int g = 0; g < G; ++g) s = fma(nm[g], w[g], s);
 			}
 			else if(EMV == 4 && SPT % 2 == 0) { /* one reciprocal per two sites: 1/a + 1/b = (a + b) / (ab) */
 #pragma unroll
@@ -432,7 +455,10 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 				s += r == HU_RHO_SKIP ? 0.0 : tt;
 			}
 		}
+		if(st) { if(s == 1.2345e-300) st[7] = 1; }   /* wait for the arithmetic */
+		stamp(0);
 		s = RED ? wave_sum_mfma(s) : wave_sum_uniform(s);
+		stamp(1);
 		double* r = red + (phase & 1) * NW;
 		if(lane == 0) r[wave] = s;
 		lds_barrier();
@@ -447,11 +473,14 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 			rc = 1.0 / cnt;
 		}
 		phase ^= 1;
+		if(st) { if(s == 1.2345e-300) st[7] = 1; }
+		stamp(2);
 		if(fast) s *= p0;
 		p = s * rc; q = 1 - p;
 		++emIters;
-		if(q0 * HU_EXP_MEPS < q && q < q0 * HU_EXP_PEPS) break; /* |log q - log q0| < BRANCH_EPS */
+		if(q0 * HU_EXP_MEPS < q && q < q0 * HU_EXP_PEPS) { stamp(3); break; } /* |log q - log q0| < BRANCH_EPS */
 		p0 = p; q0 = q;
+		stamp(3);
 	}
 	double w = -hu_log_call(q);
 	if(w > maxL) w = maxL;
@@ -510,6 +539,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 		const uint16_t* __restrict__ perm = nullptr, const int32_t* __restrict__ permCnt = nullptr, int xmap = 0) {
 	constexpr int THREADS = 64 * NW;
 	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
+	long long te[8] = {0, 0, 0, 0, 0, 0, 0, 0};        /* DBG: inside the EM steps */
 	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
 	if(DBG) { t0 = tl = (long long) __builtin_amdgcn_s_memtime(); }
 	__shared__ double red[2 * NW], redc[2 * NW];
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			}
 		}
 		stamp(2);
-		wnr = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenNR, 1.0, red, redc, phase, emIters);
+		wnr = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenNR, 1.0, red, redc, phase, emIters, DBG ? te : nullptr);
 		lenNR = wnr;
 		stamp(3);
 		if(vt < 4 * Kc) {
@@ -688,7 +718,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 			}
 		}
 		stamp(2);
-		wur = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenUR, w0j, red, redc, phase, emIters);
+		wur = em_branch_blk<SPT, NW, EMV, RED>(rho, nv, lenUR, w0j, red, redc, phase, emIters, DBG ? te : nullptr);
 		lenUR = wur;
 		lenVR = w0j - wur;
 		stamp(3);
@@ -699,6 +729,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	if(DBG && tid == 0) {
 		tk[4] = (long long) __builtin_amdgcn_s_memtime() - t0; tk[5] = iter; tk[6] = emIters;
 		for(int i = 0; i < 8; ++i) dbg[(size_t) blockIdx.x * 8 + i] = tk[i];
+		for(int i = 0; i < 4; ++i) dbg[(size_t) gridDim.x * 8 + (size_t) blockIdx.x * 4 + i] = te[i];
 	}
 }
 
