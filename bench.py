@@ -233,12 +233,16 @@ def main():
     for i in range(nb):
         timed_ms[i].clear(); timed_n[i] = 0
     barrier()
+    cpu0 = os.times()
     t1 = time.perf_counter()
     recs = run(args.steps)[-1]
     if world > 1:                                           # the one collective: final result gather over RCCL
         gathered = gather_records(recs, cdev)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t1)
+    dt_local = time.perf_counter() - t1
+    cpu1 = os.times()
+    host_cores_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / dt_local      # this rank's host threads, averaged over the timed region
+    dt = max_over_ranks(dt_local)
     total_reads = args.batch * args.steps * world
     value = total_reads / dt
 
@@ -336,6 +340,7 @@ def main():
                timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
                             "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: the product CLI's end-to-end rate is "
                             "profiles/r02_cli_throughput.json",
+               host_cores_busy_per_rank=round(host_cores_busy, 1), host_cpus=os.cpu_count(),
                rccl_ranks=rccl_ranks, backend=backend if world > 1 else None, gathered_records=(int(len(gathered)) if world > 1 else None),
                roofline=roof, roofline_kernels=kern, roofline_path=path,
                kernel_ms={k: round(v, 3) for k, v in acc.items()}, kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},
