@@ -696,6 +696,7 @@ struct HuKnobs {
 	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
+	int topk_noblocks = 0;       /* no per-block lower bounds: the top-k reads the whole pair matrix                  */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
 	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
@@ -708,7 +709,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"topk_noblocks", &HuKnobs::topk_noblocks}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -752,7 +753,7 @@ struct hu_batch {
 	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven, dPermCnt;
 	DBuf<uint16_t> dPerm;
 	PinnedVec<int32_t> hPermCnt;
-	DBuf<uint32_t> dRp, dPairs, dSeedDN;
+	DBuf<uint32_t> dRp, dPairs, dSeedDN, dBmin;
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<int32_t> dIns, dTileIns;
@@ -1186,21 +1187,37 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	/* per-(read, 256-node block) lower bounds for the top-k: only where the block path of k_seed_topk can run */
+	const int nBlk = d.nNodesPad / 256;
+	uint32_t* bmin = nullptr;
+	if(!b->knob.topk_noblocks && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048) {
+		if((rc = b->dBmin.ensure(std::max<size_t>(n, 1) * nBlk + 16)) != HU_OK) return rc;
+		bmin = b->dBmin.p;
+	}
+	uint32_t* stat = bmin && b->knob.trace ? bmin + n * nBlk : nullptr;      /* block path: reads served, blocks read, candidates, reads passed on */
+	if(stat) HIPCHK(hipMemsetAsync(stat, 0, 64, b->stream));
 	(void) hipGetLastError();
 	if(n) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		{
 			Timer t(b, HU_T_SEED_PDIST);
 			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
-			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
+			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p, bmin);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
-			else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
+			if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min, bmin, stat);
+			else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min, bmin, stat);
 		}
 		HIPCHK(hipGetLastError());
+		if(stat) {
+			uint32_t h[16];
+			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
+			fprintf(stderr, "[hu] top-k block path: %u of %zu reads, %.1f blocks and %.1f candidates per read; %u reads passed on; ticks per read: bounds %.0f choice %.0f histogram %.0f bin %.0f list %.0f keys %.0f\n",
+				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3],
+				16.0 * h[4] / n, 16.0 * h[5] / n, 16.0 * h[6] / n, 16.0 * h[7] / n, 16.0 * h[8] / n, 16.0 * h[9] / n);
+		}
 	}
 	b->seedCap = o->max_nseed;
 	b->state = ST_SEEDED;
@@ -1249,8 +1266,8 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		HIPCHK(hipMemcpyAsync(b->dGiven.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
+			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, nullptr);
+			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p, nullptr);
 		}
 		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dGiven.p, b->dGiven.p + n,
 				dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);

@@ -149,11 +149,25 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
  * 3.68 ms.  Scalar loads return out of order, so a wait is always "all of them" and a request is covered by one vector block only;
  * the four register sets push the kernel to its 102 SGPRs (v_writelane spills) and the fake dependencies that keep the scheduler from
  * hoisting all sixteen request / wait pairs in front of the vector work cost more than the latency four waves per SIMD already hide. */
+/* fp32 image of dist = d / N used for the per-block lower bounds (k_seed_pdist2 -> k_seed_topk): non-negative, so its bit pattern
+ * orders like the value; within 2^-22 relative of the true quotient (v_rcp_f32 is good to 1 ulp), N == 0 (the reference's NaN) = +inf */
+#define HU_BMIN_INF 0x7f800000u
+__device__ inline uint32_t seed_dist_bits(uint32_t d, uint32_t N) {
+	return __float_as_uint((float) d * __builtin_amdgcn_rcpf((float) N));    /* N == 0: +inf, or 0 x inf = NaN (0x7fc00000): both sort last */
+}
+template<int CTRL>
+__device__ inline uint32_t dpp_min_full(uint32_t v) {
+	const uint32_t o = (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xf, 0xf, true);
+	return o < v ? o : v;
+}
+/* `bmin` (optional): per (read, block of 256 nodes) the minimum of seed_dist_bits over the block's nodes other than the root — a lower
+ * bound that lets k_seed_topk read ~max_nseed blocks of the pair matrix per read instead of all of it. */
 template<class PT>
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead,
+		uint32_t* __restrict__ bmin) {
 	constexpr int T = HU_READ_TILE;
-	__shared__ uint32_t acc[T][256];
+	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
 	const int node = blockIdx.y * 256 + tid;
 	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
@@ -194,10 +208,25 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 			atomicAdd(&acc[t][tid], add);     /* own slot: no contention, a plain ds_add_u32 */
 		}
 	}
+	const uint32_t skip = node < db.nNodes && node != db.root ? 0u : 0xffffffffu;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
-		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
+		const uint32_t v = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
+		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(v);
+		if(bmin) acc[t][tid] = seed_dist_bits(v >> 16, v & 0xffffu) | skip;        /* own slot: nobody else has read or written it yet */
+	}
+	if(bmin) { /* minimum over the block's 256 nodes, read by read: sixteen lanes take sixteen nodes each of one read, then a row of the DPP network */
+		static_assert(T == 16, "sixteen lanes x sixteen values per read");
+		__syncthreads();
+		const int t = tid >> 4, sg = tid & 15;
+		const uint4* row = reinterpret_cast<const uint4*>(&acc[t][sg * 16]);
+		const uint4 a = row[0], b = row[1], c = row[2], e = row[3];
+		uint32_t m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+		m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
+		m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m); m = dpp_min_full<0x141>(m); m = dpp_min_full<0x140>(m);
+		const int read = slotRead[tile * T + t];
+		if(sg == 0 && read >= 0) bmin[(size_t) read * gridDim.y + blockIdx.y] = m;
 	}
 }
 
@@ -218,8 +247,9 @@ __device__ inline uint32_t seed_bin(uint32_t d, uint32_t N, uint32_t limit) {
 }
 
 template<class PT>
-__global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restrict__ pairs, double maxHeight,
-		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes) {
+__global__ __launch_bounds__(256, 4) void k_seed_topk(HuDbDev db, const PT* __restrict__ pairs, double maxHeight,
+		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes,
+		const uint32_t* __restrict__ bmin, uint32_t* __restrict__ stat) {
 	__shared__ unsigned long long keys[HU_TOPK_CAP];
 	static_assert(sizeof(unsigned long long) * HU_TOPK_CAP >= sizeof(uint32_t) * (HU_TOPK_BINS + 1), "histogram must fit the key buffer");
 	uint32_t* hist = reinterpret_cast<uint32_t*>(keys);   /* the histogram is dead once the threshold bin is known: the keys take its
@@ -233,6 +263,142 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restr
 	const bool useHeight = !(maxHeight == INFINITY);
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
 	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
+	/* Block path (the scan left per-block lower bounds): the max_nseed-th smallest block minimum U bounds the max_nseed-th smallest
+	 * distance from above (that many blocks each hold a node at or below U), so every wanted node — all ties of the last distance
+	 * included — sits in a block whose minimum is <= U; the fp32 images are within 2^-22 of the quotients, hence the 2^-19 of slack.
+	 * Only those blocks of the pair matrix are read (~max_nseed x 512 B instead of nNodes x 2 B).  Everything is arranged around
+	 * latency, one workgroup per read: U by a bitwise selection in the registers of one wave (no sort), the chosen blocks loaded with
+	 * sixteen loads in flight per thread, the few survivors ranked by counting.
+	 * Falls through to the paths below if the survivors do not fit. */
+	const int nBlk = db.nNodesPad / 256;
+	long long tstamp = stat ? (long long) __builtin_readcyclecounter() : 0;
+#define STAMP(i) do { if(stat && tid == 0) { const long long t_ = (long long) __builtin_readcyclecounter(); atomicAdd(&stat[4 + i], (uint32_t)((t_ - tstamp) >> 4)); tstamp = t_; } } while(0)
+	if(bmin && !useHeight && nBlk >= 2 * maxNSeed && nBlk <= 2048 && db.nNodes - 1 >= maxNSeed) {
+		constexpr uint32_t FINCAP = 1024;
+		uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                               /* [2048] block minima (first 8 KB)        */
+		unsigned short* sel = reinterpret_cast<unsigned short*>(keys + HU_TOPK_CAP - 512); /* [2048] chosen blocks (last 4 KB)     */
+		uint32_t* bhist = reinterpret_cast<uint32_t*>(keys);                            /* [1024] histogram, once bm is dead       */
+		unsigned long long* ent = keys + 1024;                                          /* [FINCAP] (d, N, node) of the survivors  */
+		const int per = (nBlk + 63) / 64;                                               /* block minima per lane of wave 0: <= 32  */
+		for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bmin[(size_t) read * nBlk + i] : 0xffffffffu;
+		if(tid == 0) { sh[0] = 0x7fffffffu; sh[2] = 0; sh[3] = 0; }
+		__syncthreads();
+		if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
+			uint32_t x[32];
+#pragma unroll
+			for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : 0xffffffffu;
+			uint32_t res = 0;
+			if(per <= 16) {
+				for(int bit = 30; bit >= 0; --bit) {
+					const uint32_t trial = res | (1u << bit);
+					int cnt = 0;
+#pragma unroll
+					for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
+					if(cnt < maxNSeed) res = trial;
+				}
+			} else {
+				for(int bit = 30; bit >= 0; --bit) {
+					const uint32_t trial = res | (1u << bit);
+					int cnt = 0;
+#pragma unroll
+					for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
+					if(cnt < maxNSeed) res = trial;
+				}
+			}
+			if(tid == 0) sh[0] = res;
+		}
+		__syncthreads();
+		const uint32_t U = sh[0];
+		STAMP(0);
+		if(U < HU_BMIN_INF) {
+			const uint32_t thr = __float_as_uint(__uint_as_float(U) * (1.0f + 0x1p-19f));
+			for(int i = tid; i < nBlk; i += 256)
+				if(bm[i] <= thr) sel[atomicAdd(&sh[2], 1u)] = (unsigned short) i;
+			__syncthreads();                       /* bm is dead from here: the histogram takes its place */
+			const int nsel = (int) sh[2];
+			for(int i = tid; i < 1024; i += 256) bhist[i] = 0;
+			__syncthreads();
+			STAMP(1);
+			/* The chosen blocks hold relatives of the read, so far more nodes at or below U than wanted (~1,200 for 50 at gg_97 scale):
+			 * a first pass histograms the fp32 images (1,024 bins up to U), the second lists the (d, N, node) of the bins up to one past
+			 * the bin that completes max_nseed — a bin is ~10^-3 of U wide, the images are good to 2^-22, so no wanted node is lost to
+			 * the rounding of an image. */
+			const float bscale = thr ? 1023.0f / __uint_as_float(thr) : 0.0f;
+			uint32_t binMax = 0;
+			auto visit = [&](uint32_t raw, int node, int pass) {
+				if(node >= db.nNodes || node == db.root) return;
+				const uint32_t c = HuPair<PT>::canon(raw), f = seed_dist_bits(c >> 16, c & 0xffffu);
+				if((c & 0xffffu) == 0 || f > thr) return;
+				const uint32_t bin = min(1023u, (uint32_t)(__uint_as_float(f) * bscale));
+				if(pass == 0) atomicAdd(&bhist[bin], 1u);
+				else if(bin <= binMax) {
+					const uint32_t slot = atomicAdd(&sh[3], 1u);
+					if(slot < FINCAP) ent[slot] = ((unsigned long long) c << 32) | (uint32_t) node;
+				}
+			};
+#pragma unroll 1
+			for(int pass = 0; pass < 2; ++pass) {          /* the blocks come from L2 the second time */
+#pragma unroll 1
+				for(int s0 = 0; s0 < nsel; s0 += 16) {    /* sixteen loads in flight per thread: scalar block base + one lane offset */
+					uint32_t pv[16];
+#pragma unroll
+					for(int k = 0; k < 16; ++k) pv[k] = s0 + k < nsel ? (uint32_t) (pr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : 0u;
+#pragma unroll
+					for(int k = 0; k < 16; ++k)
+						if(s0 + k < nsel) visit(pv[k], __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid, pass);
+				}
+				if(pass == 0) {
+					__syncthreads();
+					STAMP(2);
+					chunk[tid] = bhist[tid * 4] + bhist[tid * 4 + 1] + bhist[tid * 4 + 2] + bhist[tid * 4 + 3];
+					__syncthreads();
+					if(tid < 64) { /* prefix over the 64 x 16 bins on one wave */
+						const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
+						uint32_t inc = c16;
+						for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
+						const unsigned long long reached = __ballot(inc >= (uint32_t) maxNSeed);
+						if(!reached) { if(tid == 0) sh[1] = 1023; }
+						else if(tid == __ffsll((long long) reached) - 1) {
+							uint32_t cum = inc - c16; int bb = tid * 16;
+							while(bb < tid * 16 + 15 && cum + bhist[bb] < (uint32_t) maxNSeed) { cum += bhist[bb]; ++bb; }
+							sh[1] = (uint32_t) min(1023, bb + 1);
+						}
+					}
+					__syncthreads();
+					binMax = sh[1];
+					STAMP(3);
+				}
+			}
+			__syncthreads();
+			STAMP(4);
+			const uint32_t got = sh[3], need = (uint32_t) maxNSeed;
+			if(got >= need && got <= FINCAP) {
+				unsigned long long mine[FINCAP / 256];
+#pragma unroll
+				for(int q = 0; q < (int)(FINCAP / 256); ++q) {
+					const uint32_t i = q * 256 + tid;
+					mine[q] = ~0ull;
+					if(i < got) { const unsigned long long e = ent[i]; const uint32_t c = (uint32_t)(e >> 32); mine[q] = seed_key(c >> 16, c & 0xffffu, (uint32_t) e); keys[i] = mine[q]; }
+				}
+				__syncthreads();
+				/* the keys are distinct (node id in the low bits): the rank of a key is the number of smaller ones */
+#pragma unroll
+				for(int q = 0; q < (int)(FINCAP / 256); ++q) {
+					const uint32_t i = q * 256 + tid;
+					if(i >= got) continue;
+					uint32_t rank = 0;
+					for(uint32_t j = 0; j < got; ++j) rank += keys[j] < mine[q] ? 1u : 0u;
+					if(rank < need) { const unsigned long long e = ent[i]; outId[rank] = (int32_t)(uint32_t) e; outDN[rank] = (uint32_t)(e >> 32); }
+				}
+				STAMP(5);
+				if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel); atomicAdd(&stat[2], got); } }
+				return;
+			}
+		}
+		if(tid == 0 && stat) atomicAdd(&stat[3], 1u);
+		__syncthreads();
+	}
+#undef STAMP
 	/* Fast path (large trees, no height filter): the threshold bin is ESTIMATED from a histogram of one eighth
 	 * of the pairs (every eighth 128-byte line: 32 consecutive nodes, the phase advancing line by line), aiming at ~200
 	 * survivors; the exact pass then collects every pair at or below that bin.  The result is exact whenever

@@ -1,0 +1,88 @@
+// Issue rate of vector instructions on gfx950 (the instructions the seed scan, the top-k and the FP64 kernels are made of):
+// W waves per SIMD, each a stream of independent instructions on 16 accumulators.  Prints cycles per wave-instruction per SIMD
+// at the nominal clock.   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHK(x) do { hipError_t e = (x); if(e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while(0)
+
+#define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+/* 32-bit forms: %0 accumulator, %1 / %2 vector operands, s4 a scalar operand */
+#define OPS32(X) \
+	X(0, "v_xor_b32 %0, %1, %0") X(1, "v_xor_b32 %0, s4, %0") X(2, "v_and_b32 %0, %1, %0") X(3, "v_and_b32 %0, s4, %0") \
+	X(4, "v_or_b32 %0, %1, %0") X(5, "v_bitop3_b32 %0, %1, %2, %0 bitop3:0xc8") X(6, "v_bitop3_b32 %0, %1, s4, %0 bitop3:0xc8") \
+	X(7, "v_bcnt_u32_b32 %0, %1, %0") X(8, "v_bcnt_u32_b32 %0, s4, %0") X(9, "v_and_or_b32 %0, %1, %2, %0") X(10, "v_or3_b32 %0, %1, %2, %0") \
+	X(11, "v_mov_b32 %0, %1") X(12, "v_mov_b32 %0, s4") X(13, "v_cndmask_b32 %0, %1, %0, vcc") X(14, "v_add_u32 %0, %1, %0") X(15, "v_sub_u32 %0, %1, %0") \
+	X(16, "v_add3_u32 %0, %1, %2, %0") X(17, "v_lshlrev_b32 %0, 1, %0") X(18, "v_lshl_add_u32 %0, %1, 1, %0") X(19, "v_lshl_or_b32 %0, %1, 1, %0") \
+	X(20, "v_min_u32 %0, %1, %0") X(21, "v_max_i32 %0, %1, %0") X(22, "v_mul_u32_u24 %0, %1, %0") X(23, "v_mad_u32_u24 %0, %1, %1, %0") X(24, "v_mul_lo_u32 %0, %1, %0") \
+	X(25, "v_bfe_u32 %0, %0, 3, 8") X(26, "v_bfi_b32 %0, %1, %2, %0") X(27, "v_perm_b32 %0, %1, %0, %2") X(28, "v_alignbit_b32 %0, %1, %0, 5") \
+	X(29, "v_pk_add_u16 %0, %1, %0") X(30, "v_cvt_f32_u32 %0, %0") X(31, "v_cvt_f32_ubyte1 %0, %0") X(32, "v_rcp_f32 %0, %0") X(33, "v_exp_f32 %0, %0") \
+	X(34, "v_add_f32 %0, %1, %0") X(35, "v_mul_f32 %0, %1, %0") X(36, "v_fma_f32 %0, %1, %2, %0") X(37, "v_min_f32 %0, %1, %0") \
+	X(39, "v_cmp_lt_u32 vcc, %1, %0") X(40, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") X(41, "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+	X(42, "v_xor_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") X(43, "v_sad_u32 %0, %1, %2, %0") X(44, "v_mbcnt_lo_u32_b32 %0, %1, %0") X(45, "v_readlane_b32 s6, %0, 3")
+#define OPS64(X) \
+	X(100, "v_add_f64 %0, %1, %0") X(101, "v_mul_f64 %0, %1, %0") X(102, "v_fma_f64 %0, %1, %2, %0") X(103, "v_min_f64 %0, %1, %0") X(104, "v_rcp_f64 %0, %0") \
+	X(105, "v_lshlrev_b64 %0, 1, %0") X(107, "v_cmp_lt_f64 vcc, %1, %0") X(109, "v_ldexp_f64 %0, %0, 1")
+
+template<int OP>
+__global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t seed) {
+	uint32_t a[16];
+	for(int i = 0; i < 16; ++i) a[i] = seed * (i + 1) + threadIdx.x;
+	uint32_t x = seed ^ threadIdx.x, y = seed * 3 + blockIdx.x;
+	asm volatile("s_mov_b32 s4, %0" : : "s"(seed) : "s4");
+	for(int it = 0; it < iters; ++it) {
+#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "s4", "s6", "vcc"); } }
+		OPS32(X)
+#undef X
+	}
+	uint32_t s = y;
+	for(int i = 0; i < 16; ++i) s ^= a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template<int OP>
+__global__ __launch_bounds__(256) void k64(uint32_t* out, int iters, uint32_t seed) {
+	double a[16];
+	for(int i = 0; i < 16; ++i) a[i] = 1.0 + 1e-9 * (seed * (i + 1) + threadIdx.x);
+	double x = 1.0 + 1e-12 * (seed ^ threadIdx.x), y = 1e-13 * blockIdx.x;
+	for(int it = 0; it < iters; ++it) {
+#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "vcc"); } }
+		OPS64(X)
+#undef X
+	}
+	double s = y;
+	for(int i = 0; i < 16; ++i) s += a[i];
+	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t) __double2loint(s);
+}
+
+static int g_clk = 0;
+template<class K>
+static void run(K kern, const char* name, int wavesPerSimd) {
+	const int iters = 2000, perIter = 32;
+	const int blocks = 256 * wavesPerSimd;                 /* 4 waves per block: one per SIMD; `wavesPerSimd` blocks per CU */
+	uint32_t* out; CHK(hipMalloc(&out, (size_t) blocks * 256 * 4));
+	hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+	kern<<<blocks, 256>>>(out, 10, 1u);
+	CHK(hipDeviceSynchronize());
+	float best = 1e30f;
+	for(int r = 0; r < 3; ++r) {
+		CHK(hipEventRecord(e0)); kern<<<blocks, 256>>>(out, iters, 12345u + r); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if(ms < best) best = ms;
+	}
+	const double instrPerSimd = (double) iters * perIter * wavesPerSimd;
+	printf("%-72s %d waves/SIMD  %6.2f cycles per wave-instruction\n", name, wavesPerSimd, best * 1e-3 * g_clk * 1e3 / instrPerSimd);
+	CHK(hipFree(out)); CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
+int main() {
+	CHK(hipDeviceGetAttribute(&g_clk, hipDeviceAttributeClockRate, 0));
+	printf("nominal clock %d MHz; cycles below are at that clock (the chip may run lower under load)\n", g_clk / 1000);
+	for(int w : {8, 2, 1}) {
+#define X(id, txt) run(k32<id>, txt, w);
+		OPS32(X)
+#undef X
+#define X(id, txt) run(k64<id>, txt, w);
+		OPS64(X)
+#undef X
+	}
+	return 0;
+}

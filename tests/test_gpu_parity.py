@@ -754,6 +754,29 @@ def test_topk_sampled_threshold_path(monkeypatch):
     test_topk_degenerate_tie_mass()
 
 
+@pytest.mark.parametrize("mean_blen,max_nseed", [(0.05, 10), (0.05, 3), (1e-9, 10), (0.002, 8)])
+def test_topk_block_path(mean_blen, max_nseed):
+    """the scan's per-block lower bounds let k_seed_topk read only the blocks of the pair matrix that can hold a wanted node: seed
+    ids, their order and (d, N) equal the oracle's and the full-matrix paths', with ordinary distances, with distances that tie across
+    many blocks, and with every node at distance 0 (candidates overflow: the other paths take over)"""
+    E = _engine()
+    db = get_db(2600, 200, "JC69", dg_k=0, seed=11, mean_blen=mean_blen, n_match=120)      # 5,199 nodes = 21 blocks of 256
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db, 24, 60, amplicon=True, cols=140)
+    opts = E.default_opts(max_nseed=max_nseed)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    assert D.n_nodes // 256 >= 2 * max_nseed
+    B.get_seed(opts)
+    cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
+    for i in range(len(reads)):
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=max_nseed)
+        assert cnt[i] == len(oid) == max_nseed and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
+    B.set_knob("topk_noblocks", 1); B.get_seed(opts)
+    c2, i2, d2, n2 = B.seeds()
+    assert np.array_equal(c2, cnt) and np.array_equal(i2[:, :max_nseed], ids[:, :max_nseed]) and np.array_equal(d2[:, :max_nseed], sd[:, :max_nseed])
+    B.close(); D.close()
+
+
 def test_streaming_sep_kernels(monkeypatch):
     """the one-wave-per-unit streaming estimate / place kernels (regions beyond 3,072 columns) and the per-site
     log() estimate kernel give the same placements as the table-driven workgroup kernels"""
