@@ -696,7 +696,7 @@ struct HuKnobs {
 	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
-	int topk_noblocks = 0;       /* no per-block lower bounds: the top-k reads the whole pair matrix                  */
+	int scan_pairs = 0;          /* the full (d, N) pair matrix + k_seed_topk on large trees too (default there: distance-only scan) */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
 	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
@@ -709,7 +709,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"topk_noblocks", &HuKnobs::topk_noblocks}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -736,6 +736,8 @@ struct hu_batch {
 	int maxBases = 1 << 30;      /* most bases any read of the batch can have inside its region (set with the reads) */
 	bool fixedRoot = false;      /* the last place call computed the intended root logliks (hu_opts.fix_root_loglik) */
 	bool pair16 = false;         /* the pair matrix of the last seed scan holds 16-bit pairs (maxBases <= 255) */
+	int scanWidth = 0;           /* bytes per distance of the distance-only scan's matrix in dPairs (0 = none) */
+	int pairsKind = 0;           /* what dPairs holds after the last seed stage: 16 / 32-bit (d, N) pairs, or 0 = no pair matrix (distance-only scan, given seeds) */
 	int seedCap = HU_MAX_SEEDS;   /* most seeds any read of the batch can have (seed stage) */
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[2 * HU_T_COUNT];
@@ -753,7 +755,7 @@ struct hu_batch {
 	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven, dPermCnt;
 	DBuf<uint16_t> dPerm;
 	PinnedVec<int32_t> hPermCnt;
-	DBuf<uint32_t> dRp, dPairs, dSeedDN, dBmin;
+	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin;
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<int32_t> dIns, dTileIns;
@@ -1174,6 +1176,8 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	return HU_OK;
 }
 
+static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p}; }
+
 extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch: reads are not aligned"); return HU_ERR_STATE; }
@@ -1182,15 +1186,21 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	const HuDbDev& d = b->db->dev;
 	const size_t n = (size_t) b->n;
 	int rc;
-	b->pair16 = !b->knob.pairs32 && !b->knob.pdist_v1 && b->maxBases <= 255;       /* 16-bit pairs: half the matrix */
-	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (b->pair16 ? 2 : 1))) != HU_OK) return rc;
+	/* Large trees without a height filter: the distance-only scan + the top-k that recomputes the (d, N) of its few candidates
+	 * (k_seed_dscan, k_seed_topk_d).  Otherwise the full (d, N) pair matrix and k_seed_topk. */
+	const int nBlk = d.nNodesPad / 256;
+	const bool dOnly = !b->knob.scan_pairs && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
+	const bool narrow = !b->knob.pairs32 && b->maxBases <= 255;      /* 8-bit distances / 16-bit pairs */
+	b->pair16 = !dOnly && narrow && !b->knob.pdist_v1;
+	b->pairsKind = dOnly ? 0 : (b->pair16 ? 16 : 32);
+	b->scanWidth = dOnly ? (narrow ? 1 : 2) : 0;
+	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (dOnly ? (narrow ? 4 : 2) : (b->pair16 ? 2 : 1)))) != HU_OK) return rc;
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
-	/* per-(read, 256-node block) lower bounds for the top-k: only where the block path of k_seed_topk can run */
-	const int nBlk = d.nNodesPad / 256;
+	if((rc = b->dParDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	uint32_t* bmin = nullptr;
-	if(!b->knob.topk_noblocks && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048) {
+	if(dOnly) {
 		if((rc = b->dBmin.ensure(std::max<size_t>(n, 1) * nBlk + 16)) != HU_OK) return rc;
 		bmin = b->dBmin.p;
 	}
@@ -1199,24 +1209,31 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	(void) hipGetLastError();
 	if(n) {
 		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
+		const dim3 grid(tiles, d.nNodesPad / 256);
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
-			else if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p, bmin);
+			if(dOnly && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else if(dOnly) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
+			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
+			else k_seed_pdist2<uint32_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min, bmin, stat);
-			else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min, bmin, stat);
+			if(dOnly && narrow) k_seed_topk_d<uint8_t><<<b->n, 256, 0, b->stream>>>(d, (const uint8_t*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat);
+			else if(dOnly) k_seed_topk_d<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat);
+			else {
+				if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
+				else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
+				k_parent_pairs<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dSeedCnt.p, b->dSeedId.p, b->dParDN.p);
+			}
 		}
 		HIPCHK(hipGetLastError());
 		if(stat) {
-			uint32_t h[16];
-			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
-			fprintf(stderr, "[hu] top-k block path: %u of %zu reads, %.1f blocks and %.1f candidates per read; %u reads passed on; ticks per read: bounds %.0f choice %.0f histogram %.0f bin %.0f list %.0f keys %.0f\n",
-				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3],
-				16.0 * h[4] / n, 16.0 * h[5] / n, 16.0 * h[6] / n, 16.0 * h[7] / n, 16.0 * h[8] / n, 16.0 * h[9] / n);
+			uint32_t h[4];
+			HIPCHK(hipMemcpyAsync(h, stat, 16, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
+			fprintf(stderr, "[hu] top-k after the distance-only scan: %u of %zu reads on the block path (%.1f blocks, %.1f candidates per read), %u by the exact recomputation\n",
+				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3]);
 		}
 	}
 	b->seedCap = o->max_nseed;
@@ -1224,14 +1241,18 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	return HU_OK;
 }
 
-/* given seed nodes: (d, N) looked up in the pair matrix of the current regions */
-__global__ void k_seed_given(HuDbDev db, int n, const void* __restrict__ pairs, int p16, const int32_t* __restrict__ cnt, const int32_t* __restrict__ ids,
-		const int32_t* __restrict__ distIds, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN) {
+/* given seed nodes: their (d, N) and their parents' over the current regions, straight from the bit-planes (no scan) */
+__global__ void k_seed_given(HuDbDev db, HuReadPlanes R, int n, const int32_t* __restrict__ cnt, const int32_t* __restrict__ ids,
+		const int32_t* __restrict__ distIds, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if(i >= n * HU_MAX_SEEDS) return;
 	const int r = i / HU_MAX_SEEDS, sl = i % HU_MAX_SEEDS;
 	if(sl == 0) seedCnt[r] = cnt[r];
-	if(sl < cnt[r]) { seedId[i] = ids[i]; seedDN[i] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + (distIds ? distIds[i] : ids[i]), p16); }
+	if(sl < cnt[r]) {
+		seedId[i] = ids[i];
+		seedDN[i] = pair_exact(db, R, r, distIds ? distIds[i] : ids[i]);
+		parDN[i] = pair_exact(db, R, r, db.parent[ids[i]]);
+	}
 }
 
 extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride) {
@@ -1254,23 +1275,20 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 		}
 	}
 	int rc;
-	b->pair16 = !b->knob.pairs32 && b->maxBases <= 255;
-	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (b->pair16 ? 2 : 1))) != HU_OK) return rc;
+	b->pair16 = false; b->pairsKind = 0; b->scanWidth = 0;    /* no pair matrix: the pairs of the given nodes come straight from the planes */
 	if((rc = b->dSeedCnt.ensure(n)) != HU_OK) return rc;
 	if((rc = b->dSeedId.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dSeedDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
+	if((rc = b->dParDN.ensure(n * HU_MAX_SEEDS)) != HU_OK) return rc;
 	if((rc = b->dGiven.ensure(pk.size())) != HU_OK) return rc;
 	(void) hipGetLastError();
 	if(n) {
-		const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 		HIPCHK(hipMemcpyAsync(b->dGiven.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, b->stream));
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(b->pair16) k_seed_pdist2<uint16_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, nullptr);
-			else k_seed_pdist2<uint32_t><<<dim3(tiles, d.nNodesPad / 256), 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p, nullptr);
+			k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, read_planes(b), b->n, b->dGiven.p, b->dGiven.p + n,
+					dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p);
 		}
-		k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dGiven.p, b->dGiven.p + n,
-				dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
 	}
@@ -1301,7 +1319,7 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
 		const bool stream = b->knob.streaming_sep != 0;
-		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPairs.p, (b->pair16 ? 1 : 0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
+		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dParDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
 		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
 		/* launch order of the table-driven kernels: by seed node */
 		const uint32_t* order = nullptr;
@@ -1923,7 +1941,28 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 	HIPCHK(hipSetDevice(b->db->device));
 	const int nn = b->db->dev.nNodes;
 	std::vector<uint32_t> v(nn);
-	if(b->pair16) {
+	if(b->pairsKind == 0) {
+		/* no pair matrix (distance-only scan or given seeds): the pairs straight from the planes; where the scan left its
+		 * distance matrix, that row is checked against them (saturated at the matrix's width) */
+		DBuf<uint32_t> tmp;
+		int rc;
+		if((rc = tmp.ensure((size_t) nn)) != HU_OK) return rc;
+		k_pairs_of_read<<<(nn + 255) / 256, 256, 0, b->stream>>>(b->db->dev, read_planes(b), read, tmp.p);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(v.data(), tmp.p, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		if(b->scanWidth) {
+			std::vector<uint8_t> row((size_t) nn * b->scanWidth);
+			HIPCHK(hipMemcpyAsync(row.data(), (const uint8_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad * b->scanWidth, row.size(), hipMemcpyDeviceToHost, b->stream));
+			HIPCHK(hipStreamSynchronize(b->stream));
+			const uint32_t sat = b->scanWidth == 1 ? 255u : 65535u;
+			for(int i = 0; i < nn; ++i) {
+				const uint32_t got = b->scanWidth == 1 ? row[i] : ((const uint16_t*) row.data())[i];
+				if(got != std::min(v[i] >> 16, sat)) { hu_set_error("hu_batch_get_pdist: the distance-only scan holds %u for read %d, node %d; the planes give %u", got, read, i, v[i] >> 16); return HU_ERR_STATE; }
+			}
+		}
+	}
+	else if(b->pair16) {
 		std::vector<uint16_t> h(nn);
 		HIPCHK(hipMemcpyAsync(h.data(), (const uint16_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 2, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));

@@ -44,7 +44,7 @@ __device__ inline long long block_sum_ll(long long v, long long* red, int& phase
 
 template<int SPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ parDN,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
 	__shared__ double red[2 * THREADS / 64];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
 	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int v = db.parent[u];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
-	const uint32_t pv = hu_pair_load(pairs, (size_t) read * db.nNodesPad + v, p16);
+	const uint32_t pv = parDN[(size_t) read * HU_MAX_SEEDS + s];       /* (d, N) against the parent's sequence */
 	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
 	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
 	double ratio = cDist / (cDist + pDist);
@@ -179,7 +179,7 @@ __device__ inline uint32_t hu_xcd_pos(uint32_t b, uint32_t nb, int xmap) {
 
 template<int SPT, int NW, int OCC = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ parDN,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out, const uint32_t* __restrict__ order, int xmap = 0) {
 	constexpr int THREADS = 64 * NW;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuMo
 	const int un = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int vn = db.parent[un];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
-	const uint32_t pv = hu_pair_load(pairs, (size_t) read * db.nNodesPad + vn, p16);
+	const uint32_t pv = parDN[(size_t) read * HU_MAX_SEEDS + s];      /* (d, N) against the parent's sequence */
 	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
 	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
 	double ratio = cDist / (cDist + pDist);

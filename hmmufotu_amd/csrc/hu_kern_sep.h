@@ -149,25 +149,16 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
  * 3.68 ms.  Scalar loads return out of order, so a wait is always "all of them" and a request is covered by one vector block only;
  * the four register sets push the kernel to its 102 SGPRs (v_writelane spills) and the fake dependencies that keep the scheduler from
  * hoisting all sixteen request / wait pairs in front of the vector work cost more than the latency four waves per SIMD already hide. */
-/* fp32 image of dist = d / N used for the per-block lower bounds (k_seed_pdist2 -> k_seed_topk): non-negative, so its bit pattern
- * orders like the value; within 2^-22 relative of the true quotient (v_rcp_f32 is good to 1 ulp), N == 0 (the reference's NaN) = +inf */
-#define HU_BMIN_INF 0x7f800000u
-__device__ inline uint32_t seed_dist_bits(uint32_t d, uint32_t N) {
-	return __float_as_uint((float) d * __builtin_amdgcn_rcpf((float) N));    /* N == 0: +inf, or 0 x inf = NaN (0x7fc00000): both sort last */
-}
 template<int CTRL>
 __device__ inline uint32_t dpp_min_full(uint32_t v) {
 	const uint32_t o = (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xf, 0xf, true);
 	return o < v ? o : v;
 }
-/* `bmin` (optional): per (read, block of 256 nodes) the minimum of seed_dist_bits over the block's nodes other than the root — a lower
- * bound that lets k_seed_topk read ~max_nseed blocks of the pair matrix per read instead of all of it. */
 template<class PT>
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead,
-		uint32_t* __restrict__ bmin) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
 	constexpr int T = HU_READ_TILE;
-	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
+	__shared__ uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
 	const int node = blockIdx.y * 256 + tid;
 	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
@@ -208,26 +199,85 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 			atomicAdd(&acc[t][tid], add);     /* own slot: no contention, a plain ds_add_u32 */
 		}
 	}
+#pragma unroll
+	for(int t = 0; t < T; ++t) {
+		const int read = slotRead[tile * T + t];
+		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The distance-only scan (large trees).  Measured on gfx950 (profiles/ubench/valu_rate.hip): a vector instruction with a scalar
+ * operand issues in 4 cycles, v_xor / v_and / v_bitop3 on vector registers alone in 2, v_bcnt_u32_b32 in 4.  The read's planes are
+ * wave-uniform (scalar), so a (node, read, 32 sites) step of k_seed_pdist2 costs and(s) + xor(s) + xor(s) + bitop3 + 2 x bcnt = 22
+ * cycles, 6 of them for N.  Here N is not computed at all: three operations with one scalar operand each (the floor for six
+ * inputs) and one population count, 16 cycles,
+ *     a = n0 ^ r0;   b = a | (n1 ^ r1);   x = b & nv & rv;   d += popc(x)
+ * and the matrix holds d alone, saturated to DT.  d / N >= d / (bases of the read) bounds the distance from below, which is all
+ * the selection of the blocks needs (k_seed_topk_d); the exact (d, N) of the few candidates are recomputed there from the planes.
+ * `bminD`: per (read, block of 256 nodes) the minimum d over the block's nodes other than the root. */
+template<class DT>
+__global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_t* __restrict__ rp,
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, DT* __restrict__ dm, const int32_t* __restrict__ slotRead,
+		uint32_t* __restrict__ bminD) {
+	constexpr int T = HU_READ_TILE;
+	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
+	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
+	const int tile = blockIdx.x, tid = threadIdx.x;
+	const int node = blockIdx.y * 256 + tid;
+	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
+	const int32_t* __restrict__ til = tileIns + (size_t) tile * (T * HU_MAX_INS + 1);
+	const int nq = ql[0], ne = til[0];
+	uint32_t d[T];
+#pragma unroll
+	for(int t = 0; t < T; ++t) d[t] = 0;
+	if(ne) {
+#pragma unroll
+		for(int t = 0; t < T; ++t) acc[t][tid] = 0;
+	}
+	const size_t np = (size_t) db.nNodesPad;
+	for(int qi = 0; qi < nq; ++qi) {
+		const int q = ql[1 + qi];
+		const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node], n1 = db.planes[((size_t) q * 3 + 1) * np + node], nv = db.planes[((size_t) q * 3 + 2) * np + node];
+		const uint32_t* __restrict__ r = rp + (((size_t) tile * db.WQ + q) * T) * 16;
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const uint32_t* rt = r + t * 16;
+#define HU_DSTEP(W, I) d[t] += __popc(__builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n0.W ^ rt[I], n1.W, rt[4 + I], 0xf6), nv.W, rt[8 + I], 0x80));
+			HU_DSTEP(x, 0) HU_DSTEP(y, 1) HU_DSTEP(z, 2) HU_DSTEP(w, 3)
+#undef HU_DSTEP
+		}
+	}
+	{ /* inserts: as in k_seed_pdist2, the mismatch bit only */
+		const size_t npw = np / 64;
+		const int nb = __builtin_amdgcn_readfirstlane(node >> 6), lane = tid & 63;
+		for(int e = 0; e < ne; ++e) {
+			const int ent = til[1 + e];
+			const int t = ent >> 24, pos = (ent >> 2) & 0x3fffff, code = ent & 3;
+			const unsigned long long* cp = db.colPlanes + ((size_t)(pos - db.QM * 128) * 3) * npw + nb;
+			const unsigned long long W0 = cp[0], W1 = cp[npw], Wv = cp[2 * npw];
+			const uint32_t valid = (uint32_t)(Wv >> lane) & 1u, nc = ((uint32_t)(W0 >> lane) & 1u) | (((uint32_t)(W1 >> lane) & 1u) << 1);
+			atomicAdd(&acc[t][tid], valid & (nc != (uint32_t) code ? 1u : 0u));
+		}
+	}
 	const uint32_t skip = node < db.nNodes && node != db.root ? 0u : 0xffffffffu;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
-		const uint32_t v = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
-		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(v);
-		if(bmin) acc[t][tid] = seed_dist_bits(v >> 16, v & 0xffffu) | skip;        /* own slot: nobody else has read or written it yet */
+		const uint32_t v = min(d[t] + (ne ? acc[t][tid] : 0u), DMAX);
+		if(read >= 0) dm[(size_t) read * np + node] = (DT) v;
+		acc[t][tid] = v | skip;                   /* own slot: nobody else has read or written it yet */
 	}
-	if(bmin) { /* minimum over the block's 256 nodes, read by read: sixteen lanes take sixteen nodes each of one read, then a row of the DPP network */
-		static_assert(T == 16, "sixteen lanes x sixteen values per read");
-		__syncthreads();
-		const int t = tid >> 4, sg = tid & 15;
-		const uint4* row = reinterpret_cast<const uint4*>(&acc[t][sg * 16]);
-		const uint4 a = row[0], b = row[1], c = row[2], e = row[3];
-		uint32_t m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
-		m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
-		m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m); m = dpp_min_full<0x141>(m); m = dpp_min_full<0x140>(m);
-		const int read = slotRead[tile * T + t];
-		if(sg == 0 && read >= 0) bmin[(size_t) read * gridDim.y + blockIdx.y] = m;
-	}
+	static_assert(T == 16, "sixteen lanes x sixteen values per read");
+	__syncthreads();
+	const int t = tid >> 4, sg = tid & 15;
+	const uint4* row = reinterpret_cast<const uint4*>(&acc[t][sg * 16]);
+	const uint4 a = row[0], b = row[1], c = row[2], e = row[3];
+	uint32_t m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+	m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
+	m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m); m = dpp_min_full<0x141>(m); m = dpp_min_full<0x140>(m);
+	const int read = slotRead[tile * T + t];
+	if(sg == 0 && read >= 0) bminD[(size_t) read * gridDim.y + blockIdx.y] = m;
 }
 
 /* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
@@ -247,9 +297,8 @@ __device__ inline uint32_t seed_bin(uint32_t d, uint32_t N, uint32_t limit) {
 }
 
 template<class PT>
-__global__ __launch_bounds__(256, 4) void k_seed_topk(HuDbDev db, const PT* __restrict__ pairs, double maxHeight,
-		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes,
-		const uint32_t* __restrict__ bmin, uint32_t* __restrict__ stat) {
+__global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restrict__ pairs, double maxHeight,
+		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, int fastMinNodes) {
 	__shared__ unsigned long long keys[HU_TOPK_CAP];
 	static_assert(sizeof(unsigned long long) * HU_TOPK_CAP >= sizeof(uint32_t) * (HU_TOPK_BINS + 1), "histogram must fit the key buffer");
 	uint32_t* hist = reinterpret_cast<uint32_t*>(keys);   /* the histogram is dead once the threshold bin is known: the keys take its
@@ -263,142 +312,6 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk(HuDbDev db, const PT* __re
 	const bool useHeight = !(maxHeight == INFINITY);
 	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
 	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
-	/* Block path (the scan left per-block lower bounds): the max_nseed-th smallest block minimum U bounds the max_nseed-th smallest
-	 * distance from above (that many blocks each hold a node at or below U), so every wanted node — all ties of the last distance
-	 * included — sits in a block whose minimum is <= U; the fp32 images are within 2^-22 of the quotients, hence the 2^-19 of slack.
-	 * Only those blocks of the pair matrix are read (~max_nseed x 512 B instead of nNodes x 2 B).  Everything is arranged around
-	 * latency, one workgroup per read: U by a bitwise selection in the registers of one wave (no sort), the chosen blocks loaded with
-	 * sixteen loads in flight per thread, the few survivors ranked by counting.
-	 * Falls through to the paths below if the survivors do not fit. */
-	const int nBlk = db.nNodesPad / 256;
-	long long tstamp = stat ? (long long) __builtin_readcyclecounter() : 0;
-#define STAMP(i) do { if(stat && tid == 0) { const long long t_ = (long long) __builtin_readcyclecounter(); atomicAdd(&stat[4 + i], (uint32_t)((t_ - tstamp) >> 4)); tstamp = t_; } } while(0)
-	if(bmin && !useHeight && nBlk >= 2 * maxNSeed && nBlk <= 2048 && db.nNodes - 1 >= maxNSeed) {
-		constexpr uint32_t FINCAP = 1024;
-		uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                               /* [2048] block minima (first 8 KB)        */
-		unsigned short* sel = reinterpret_cast<unsigned short*>(keys + HU_TOPK_CAP - 512); /* [2048] chosen blocks (last 4 KB)     */
-		uint32_t* bhist = reinterpret_cast<uint32_t*>(keys);                            /* [1024] histogram, once bm is dead       */
-		unsigned long long* ent = keys + 1024;                                          /* [FINCAP] (d, N, node) of the survivors  */
-		const int per = (nBlk + 63) / 64;                                               /* block minima per lane of wave 0: <= 32  */
-		for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bmin[(size_t) read * nBlk + i] : 0xffffffffu;
-		if(tid == 0) { sh[0] = 0x7fffffffu; sh[2] = 0; sh[3] = 0; }
-		__syncthreads();
-		if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
-			uint32_t x[32];
-#pragma unroll
-			for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : 0xffffffffu;
-			uint32_t res = 0;
-			if(per <= 16) {
-				for(int bit = 30; bit >= 0; --bit) {
-					const uint32_t trial = res | (1u << bit);
-					int cnt = 0;
-#pragma unroll
-					for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
-					if(cnt < maxNSeed) res = trial;
-				}
-			} else {
-				for(int bit = 30; bit >= 0; --bit) {
-					const uint32_t trial = res | (1u << bit);
-					int cnt = 0;
-#pragma unroll
-					for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
-					if(cnt < maxNSeed) res = trial;
-				}
-			}
-			if(tid == 0) sh[0] = res;
-		}
-		__syncthreads();
-		const uint32_t U = sh[0];
-		STAMP(0);
-		if(U < HU_BMIN_INF) {
-			const uint32_t thr = __float_as_uint(__uint_as_float(U) * (1.0f + 0x1p-19f));
-			for(int i = tid; i < nBlk; i += 256)
-				if(bm[i] <= thr) sel[atomicAdd(&sh[2], 1u)] = (unsigned short) i;
-			__syncthreads();                       /* bm is dead from here: the histogram takes its place */
-			const int nsel = (int) sh[2];
-			for(int i = tid; i < 1024; i += 256) bhist[i] = 0;
-			__syncthreads();
-			STAMP(1);
-			/* The chosen blocks hold relatives of the read, so far more nodes at or below U than wanted (~1,200 for 50 at gg_97 scale):
-			 * a first pass histograms the fp32 images (1,024 bins up to U), the second lists the (d, N, node) of the bins up to one past
-			 * the bin that completes max_nseed — a bin is ~10^-3 of U wide, the images are good to 2^-22, so no wanted node is lost to
-			 * the rounding of an image. */
-			const float bscale = thr ? 1023.0f / __uint_as_float(thr) : 0.0f;
-			uint32_t binMax = 0;
-			auto visit = [&](uint32_t raw, int node, int pass) {
-				if(node >= db.nNodes || node == db.root) return;
-				const uint32_t c = HuPair<PT>::canon(raw), f = seed_dist_bits(c >> 16, c & 0xffffu);
-				if((c & 0xffffu) == 0 || f > thr) return;
-				const uint32_t bin = min(1023u, (uint32_t)(__uint_as_float(f) * bscale));
-				if(pass == 0) atomicAdd(&bhist[bin], 1u);
-				else if(bin <= binMax) {
-					const uint32_t slot = atomicAdd(&sh[3], 1u);
-					if(slot < FINCAP) ent[slot] = ((unsigned long long) c << 32) | (uint32_t) node;
-				}
-			};
-#pragma unroll 1
-			for(int pass = 0; pass < 2; ++pass) {          /* the blocks come from L2 the second time */
-#pragma unroll 1
-				for(int s0 = 0; s0 < nsel; s0 += 16) {    /* sixteen loads in flight per thread: scalar block base + one lane offset */
-					uint32_t pv[16];
-#pragma unroll
-					for(int k = 0; k < 16; ++k) pv[k] = s0 + k < nsel ? (uint32_t) (pr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : 0u;
-#pragma unroll
-					for(int k = 0; k < 16; ++k)
-						if(s0 + k < nsel) visit(pv[k], __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid, pass);
-				}
-				if(pass == 0) {
-					__syncthreads();
-					STAMP(2);
-					chunk[tid] = bhist[tid * 4] + bhist[tid * 4 + 1] + bhist[tid * 4 + 2] + bhist[tid * 4 + 3];
-					__syncthreads();
-					if(tid < 64) { /* prefix over the 64 x 16 bins on one wave */
-						const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
-						uint32_t inc = c16;
-						for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
-						const unsigned long long reached = __ballot(inc >= (uint32_t) maxNSeed);
-						if(!reached) { if(tid == 0) sh[1] = 1023; }
-						else if(tid == __ffsll((long long) reached) - 1) {
-							uint32_t cum = inc - c16; int bb = tid * 16;
-							while(bb < tid * 16 + 15 && cum + bhist[bb] < (uint32_t) maxNSeed) { cum += bhist[bb]; ++bb; }
-							sh[1] = (uint32_t) min(1023, bb + 1);
-						}
-					}
-					__syncthreads();
-					binMax = sh[1];
-					STAMP(3);
-				}
-			}
-			__syncthreads();
-			STAMP(4);
-			const uint32_t got = sh[3], need = (uint32_t) maxNSeed;
-			if(got >= need && got <= FINCAP) {
-				unsigned long long mine[FINCAP / 256];
-#pragma unroll
-				for(int q = 0; q < (int)(FINCAP / 256); ++q) {
-					const uint32_t i = q * 256 + tid;
-					mine[q] = ~0ull;
-					if(i < got) { const unsigned long long e = ent[i]; const uint32_t c = (uint32_t)(e >> 32); mine[q] = seed_key(c >> 16, c & 0xffffu, (uint32_t) e); keys[i] = mine[q]; }
-				}
-				__syncthreads();
-				/* the keys are distinct (node id in the low bits): the rank of a key is the number of smaller ones */
-#pragma unroll
-				for(int q = 0; q < (int)(FINCAP / 256); ++q) {
-					const uint32_t i = q * 256 + tid;
-					if(i >= got) continue;
-					uint32_t rank = 0;
-					for(uint32_t j = 0; j < got; ++j) rank += keys[j] < mine[q] ? 1u : 0u;
-					if(rank < need) { const unsigned long long e = ent[i]; outId[rank] = (int32_t)(uint32_t) e; outDN[rank] = (uint32_t)(e >> 32); }
-				}
-				STAMP(5);
-				if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel); atomicAdd(&stat[2], got); } }
-				return;
-			}
-		}
-		if(tid == 0 && stat) atomicAdd(&stat[3], 1u);
-		__syncthreads();
-	}
-#undef STAMP
 	/* Fast path (large trees, no height filter): the threshold bin is ESTIMATED from a histogram of one eighth
 	 * of the pairs (every eighth 128-byte line: 32 consecutive nodes, the phase advancing line by line), aiming at ~200
 	 * survivors; the exact pass then collects every pair at or below that bin.  The result is exact whenever
@@ -599,6 +512,321 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk(HuDbDev db, const PT* __re
 	if(tid == 0) seedCnt[read] = (int32_t) need;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The exact (d, N) of one (read, node) from the bit-planes: what k_seed_pdist2 writes for every pair, here on demand for the few
+ * pairs the distance-only path needs (candidates of the top-k, the seeds' parents, given seeds).  The read's planes are found
+ * through its slot in the scan's tiling, its quads through its quad bitmap, its listed inserts through `ins`. */
+struct HuReadPlanes { const uint32_t* rp; const uint32_t* rq; const int32_t* ins; const int32_t* readSlot; };
+__device__ inline uint32_t pair_exact(const HuDbDev& db, const HuReadPlanes& R, int r, int node) {
+	const int slot = R.readSlot[r], tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
+	const int nw32 = (db.WQ + 31) / 32;
+	const size_t np = (size_t) db.nNodesPad;
+	uint32_t d = 0, N = 0;
+	for(int w = 0; w < nw32; ++w) {
+		uint32_t m = R.rq[(size_t) r * nw32 + w];
+		while(m) {
+			const int q = w * 32 + __ffs(m) - 1; m &= m - 1;
+			const uint32_t* __restrict__ rt = R.rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
+			const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node], n1 = db.planes[((size_t) q * 3 + 1) * np + node], nv = db.planes[((size_t) q * 3 + 2) * np + node];
+			uint32_t k, x;
+			k = nv.x & rt[8];  x = ((n0.x ^ rt[0]) | (n1.x ^ rt[4])) & k; d += __popc(x); N += __popc(k);
+			k = nv.y & rt[9];  x = ((n0.y ^ rt[1]) | (n1.y ^ rt[5])) & k; d += __popc(x); N += __popc(k);
+			k = nv.z & rt[10]; x = ((n0.z ^ rt[2]) | (n1.z ^ rt[6])) & k; d += __popc(x); N += __popc(k);
+			k = nv.w & rt[11]; x = ((n0.w ^ rt[3]) | (n1.w ^ rt[7])) & k; d += __popc(x); N += __popc(k);
+		}
+	}
+	const int32_t* __restrict__ il = R.ins + (size_t) r * (HU_MAX_INS + 1);
+	const int cnt = il[0];
+	for(int e = 0; e < cnt; ++e) {
+		const int ent = il[1 + e], pos = ent >> 2, code = ent & 3;
+		const int q = pos >> 7, w = (pos >> 5) & 3, bit = pos & 31;
+		const uint32_t* pw = reinterpret_cast<const uint32_t*>(db.planes + ((size_t) q * 3) * np + node) + w;
+		const uint32_t w0 = pw[0], w1 = pw[np * 4], wv = pw[np * 8];
+		const uint32_t valid = (wv >> bit) & 1u, nc = ((w0 >> bit) & 1u) | (((w1 >> bit) & 1u) << 1);
+		N += valid; d += valid & (nc != (uint32_t) code ? 1u : 0u);
+	}
+	return (d << 16) | N;
+}
+/* bases of the read inside its region: an upper bound of every N of the read */
+__device__ inline uint32_t read_bases(const HuDbDev& db, const HuReadPlanes& R, int r) {
+	const int slot = R.readSlot[r], tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
+	const int nw32 = (db.WQ + 31) / 32;
+	uint32_t L = (uint32_t) R.ins[(size_t) r * (HU_MAX_INS + 1)];
+	for(int w = 0; w < nw32; ++w) {
+		uint32_t m = R.rq[(size_t) r * nw32 + w];
+		while(m) {
+			const int q = w * 32 + __ffs(m) - 1; m &= m - 1;
+			const uint32_t* __restrict__ rt = R.rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t) * 16;
+			L += __popc(rt[8]) + __popc(rt[9]) + __popc(rt[10]) + __popc(rt[11]);
+		}
+	}
+	return L;
+}
+
+/* every (d, N) of one read (hu_batch_get_pdist after the distance-only scan) */
+__global__ __launch_bounds__(256) void k_pairs_of_read(HuDbDev db, HuReadPlanes R, int read, uint32_t* __restrict__ out) {
+	const int node = blockIdx.x * 256 + threadIdx.x;
+	if(node < db.nNodes) out[node] = pair_exact(db, R, read, node);
+}
+/* (d, N) of the seeds' parents from the pair matrix (the paths that keep one): estimateSeq's pDist(v.seq) */
+__global__ void k_parent_pairs(HuDbDev db, int n, const void* __restrict__ pairs, int p16, const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId,
+		uint32_t* __restrict__ parDN) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i >= n * HU_MAX_SEEDS) return;
+	const int r = i / HU_MAX_SEEDS, sl = i % HU_MAX_SEEDS;
+	if(sl < seedCnt[r]) parDN[i] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + db.parent[seedId[i]], p16);
+}
+
+/* The exact selection over ALL nodes with the pairs recomputed from the planes — for the reads the block path of k_seed_topk_d cannot
+ * serve (ties beyond its buffers, a saturated distance).  Histogram of floor(4096 d / N), keys of the bins up to the one that
+ * completes max_nseed, sorted; with more ties than the buffer holds, one exact minimum per pass (as in k_seed_topk). */
+__device__ inline void topk_exact_recompute(const HuDbDev& db, const HuReadPlanes& R, int read, int maxNSeed, unsigned long long* keys, uint32_t* chunk,
+		uint32_t* sh, int32_t* outId, uint32_t* outDN, uint32_t* outPar, int32_t* seedCnt) {
+	const int tid = threadIdx.x;
+	uint32_t* hist = reinterpret_cast<uint32_t*>(keys);
+	const int per = (HU_TOPK_BINS + 1 + 255) / 256;
+	__syncthreads();
+	for(int i = tid; i <= HU_TOPK_BINS; i += 256) hist[i] = 0;
+	__syncthreads();
+	for(int node = tid; node < db.nNodes; node += 256) {
+		if(node == db.root) continue;
+		const uint32_t c = pair_exact(db, R, read, node);
+		atomicAdd(&hist[seed_bin(c >> 16, c & 0xffffu, HU_TOPK_BINS)], 1u);
+	}
+	__syncthreads();
+	{
+		uint32_t sm = 0;
+		for(int i = tid * per; i < (tid + 1) * per && i <= HU_TOPK_BINS; ++i) sm += hist[i];
+		chunk[tid] = sm;
+	}
+	__syncthreads();
+	if(tid == 0) {
+		uint32_t total = 0;
+		for(int i = 0; i < 256; ++i) total += chunk[i];
+		const uint32_t need = total < (uint32_t) maxNSeed ? total : (uint32_t) maxNSeed;
+		uint32_t cum = 0; int c = 0;
+		while(c < 255 && cum + chunk[c] < need) { cum += chunk[c]; ++c; }
+		int b = c * per;
+		while(b < HU_TOPK_BINS && cum + hist[b] < need) { cum += hist[b]; ++b; }
+		sh[0] = need; sh[1] = (uint32_t) b; sh[2] = cum + hist[b]; sh[3] = 0;
+	}
+	__syncthreads();
+	const uint32_t need = sh[0], thr = sh[1], cntLE = sh[2];
+	if(need == 0) { if(tid == 0) seedCnt[read] = 0; return; }
+	__syncthreads();
+	if(cntLE <= HU_TOPK_CAP) {
+		for(int node = tid; node < db.nNodes; node += 256) {
+			if(node == db.root) continue;
+			const uint32_t c = pair_exact(db, R, read, node), d = c >> 16, N = c & 0xffffu;
+			if(seed_bin(d, N, thr + 1) <= thr) { const uint32_t slot = atomicAdd(&sh[3], 1u); keys[slot] = seed_key(d, N, (uint32_t) node); }
+		}
+		__syncthreads();
+		uint32_t n2 = 1;
+		while(n2 < cntLE) n2 <<= 1;
+		for(uint32_t i = cntLE + tid; i < n2; i += 256) keys[i] = ~0ull;
+		__syncthreads();
+		for(uint32_t k = 2; k <= n2; k <<= 1)
+			for(uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for(uint32_t i = tid; i < n2; i += 256) {
+					const uint32_t l = i ^ j;
+					if(l > i) {
+						const unsigned long long a = keys[i], b = keys[l];
+						const bool up = (i & k) == 0;
+						if((a > b) == up) { keys[i] = b; keys[l] = a; }
+					}
+				}
+				__syncthreads();
+			}
+		for(uint32_t i = tid; i < need; i += 256) {
+			const int node = (int)(keys[i] & 0xffffffu);
+			outId[i] = node; outDN[i] = pair_exact(db, R, read, node); outPar[i] = pair_exact(db, R, read, db.parent[node]);
+		}
+	}
+	else {
+		unsigned long long last = 0; bool first = true;
+		for(uint32_t s = 0; s < need; ++s) {
+			unsigned long long best = ~0ull;
+			for(int node = tid; node < db.nNodes; node += 256) {
+				if(node == db.root) continue;
+				const uint32_t c = pair_exact(db, R, read, node), d = c >> 16, N = c & 0xffffu;
+				if(seed_bin(d, N, thr + 1) > thr) continue;
+				const unsigned long long k = seed_key(d, N, (uint32_t) node);
+				if((first || k > last) && k < best) best = k;
+			}
+			for(int m = 32; m > 0; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o < best ? o : best; }
+			if((tid & 63) == 0) keys[tid >> 6] = best;
+			__syncthreads();
+			best = keys[0];
+			for(int wv = 1; wv < 4; ++wv) best = keys[wv] < best ? keys[wv] : best;
+			__syncthreads();
+			last = best; first = false;
+			if(tid == 0) { const int node = (int)(best & 0xffffffu); outId[s] = node; outDN[s] = pair_exact(db, R, read, node); outPar[s] = pair_exact(db, R, read, db.parent[node]); }
+		}
+	}
+	if(tid == 0) seedCnt[read] = (int32_t) need;
+}
+
+/* std::sort + truncation to max_nseed after the distance-only scan: one workgroup per read.
+ *   L = bases of the read >= every N, so d / N >= d / L: a node at distance x has d <= x L.
+ *   1. Dsel = the max_nseed-th smallest block minimum of d (bitwise selection on one wave): at least max_nseed blocks hold a node
+ *      with d <= Dsel; no other block does.
+ *   2. histogram of d over those blocks -> Dk, the max_nseed-th smallest d overall; C1 = {d <= Dk} (>= max_nseed nodes).
+ *   3. exact (d, N) of C1 from the planes; (d1, N1) = its max_nseed-th smallest key, an upper bound of the wanted distance.
+ *   4. every wanted node has d <= D1 = floor(d1 L / N1); if D1 > Dk the nodes with Dk < d <= D1 join (blocks with minimum <= D1).
+ *   5. the candidates ranked by counting on their exact keys (dist, node id); (d, N) of the seeds and of their parents written.
+ * Comparisons on the saturated matrix are valid below the saturation value; a read that reaches it, or whose ties overflow the
+ * buffers, takes topk_exact_recompute.  stat (optional): reads served here, blocks, candidates, reads passed on. */
+template<class DT>
+__global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __restrict__ dm, const uint32_t* __restrict__ bminD, HuReadPlanes R,
+		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
+		uint32_t* __restrict__ stat) {
+	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
+	constexpr int NBITS = 8 * (int) sizeof(DT);
+	constexpr uint32_t CAP = 1024, HB = 1024;
+	__shared__ unsigned long long keys[HU_TOPK_CAP];        /* 32 KB, carved up below */
+	__shared__ uint32_t chunk[256];
+	__shared__ uint32_t sh[8];
+	uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                                   /* [2048] block minima          0 ..  8 KB */
+	unsigned short* sel = reinterpret_cast<unsigned short*>(keys + 1024);               /* [2048] chosen blocks         8 .. 12 KB */
+	uint32_t* hist = reinterpret_cast<uint32_t*>(keys + 1536);                          /* [HB] histogram of d         12 .. 16 KB */
+	unsigned long long* ck = keys + 2048;                                               /* [CAP] candidate keys        16 .. 24 KB */
+	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
+	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
+	const int read = blockIdx.x, tid = threadIdx.x;
+	const size_t np = (size_t) db.nNodesPad;
+	const DT* __restrict__ dr = dm + (size_t) read * np;
+	const int nBlk = db.nNodesPad / 256;
+	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
+	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
+	uint32_t* outPar = parDN + (size_t) read * HU_MAX_SEEDS;
+	const uint32_t need = (uint32_t) maxNSeed;
+	const int per = (nBlk + 63) / 64;                                                   /* block minima per lane of wave 0: <= 32 */
+	for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bminD[(size_t) read * nBlk + i] : 0xffffffffu;
+	if(tid == 0) { sh[0] = 0xffffffffu; sh[2] = 0; sh[3] = 0; sh[4] = 0; sh[5] = read_bases(db, R, read); }
+	__syncthreads();
+	if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
+		uint32_t x[32];
+#pragma unroll
+		for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : 0xffffffffu;
+		uint32_t res = 0;
+		if(per <= 16) {
+			for(int bit = NBITS; bit >= 0; --bit) {
+				const uint32_t trial = res | (1u << bit);
+				int cnt = 0;
+#pragma unroll
+				for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
+				if(cnt < maxNSeed) res = trial;
+			}
+		} else {
+			for(int bit = NBITS; bit >= 0; --bit) {
+				const uint32_t trial = res | (1u << bit);
+				int cnt = 0;
+#pragma unroll
+				for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
+				if(cnt < maxNSeed) res = trial;
+			}
+		}
+		if(tid == 0) sh[0] = res;
+	}
+	__syncthreads();
+	const uint32_t Dsel = sh[0], L = sh[5];
+	bool served = false;
+	if(Dsel < DMAX && Dsel < HB) {
+		/* one pass over the blocks with minimum <= lim: histogram (pass 0: d <= lim) or list (pass 1: lo < d <= lim) */
+		auto sweep = [&](uint32_t lo, uint32_t lim, int pass) {
+			if(tid == 0) sh[2] = 0;
+			__syncthreads();
+			for(int i = tid; i < nBlk; i += 256)
+				if(bm[i] <= lim) sel[atomicAdd(&sh[2], 1u)] = (unsigned short) i;
+			__syncthreads();
+			const int nsel = (int) sh[2];
+#pragma unroll 1
+			for(int s0 = 0; s0 < nsel; s0 += 16) {     /* sixteen loads in flight per thread: scalar block base + one lane offset */
+				uint32_t pv[16];
+#pragma unroll
+				for(int k = 0; k < 16; ++k) pv[k] = s0 + k < nsel ? (uint32_t) (dr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : 0xffffffffu;
+#pragma unroll
+				for(int k = 0; k < 16; ++k) {
+					if(s0 + k >= nsel) continue;
+					const int node = __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid;
+					if(node >= db.nNodes || node == db.root || pv[k] > lim) continue;
+					if(pass == 0) atomicAdd(&hist[pv[k]], 1u);
+					else if(pv[k] > lo || lo == 0xffffffffu) { const uint32_t slot = atomicAdd(&sh[3], 1u); if(slot < CAP) cn[slot] = (uint32_t) node; }
+				}
+			}
+			__syncthreads();
+			return nsel;
+		};
+		for(int i = tid; i < (int) HB; i += 256) hist[i] = 0;
+		__syncthreads();
+		const int nsel0 = sweep(0, Dsel, 0);
+		chunk[tid] = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+		__syncthreads();
+		if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk */
+			const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
+			uint32_t inc = c16;
+			for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
+			const unsigned long long reached = __ballot(inc >= need);
+			if(!reached) { if(tid == 0) sh[1] = 0xffffffffu; }
+			else if(tid == __ffsll((long long) reached) - 1) {
+				uint32_t cum = inc - c16; int bb = tid * 16;
+				while(bb < tid * 16 + 15 && cum + hist[bb] < need) { cum += hist[bb]; ++bb; }
+				sh[1] = (uint32_t) bb;
+			}
+		}
+		__syncthreads();
+		const uint32_t Dk = sh[1];
+		if(Dk <= Dsel) {
+			sweep(0xffffffffu, Dk, 1);                             /* C1 = every node with d <= Dk */
+			uint32_t c1 = sh[3];
+			if(c1 >= need && c1 <= CAP) {
+				for(uint32_t i = tid; i < c1; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
+				__syncthreads();
+				/* (d1, N1): the key of rank max_nseed - 1 among C1 (keys are distinct) */
+				for(uint32_t i = tid; i < c1; i += 256) {
+					const unsigned long long mine = ck[i];
+					uint32_t rank = 0;
+					for(uint32_t j = 0; j < c1; ++j) rank += ck[j] < mine ? 1u : 0u;
+					if(rank == need - 1) sh[4] = cp[i];
+				}
+				__syncthreads();
+				const uint32_t c1p = sh[4], d1 = c1p >> 16, N1 = c1p & 0xffffu;
+				if(N1 != 0) {
+					const unsigned long long D1l = (unsigned long long) d1 * L / N1;
+					const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
+					bool ok = true;
+					uint32_t c2 = c1;
+					if(D1 > Dk) {
+						if(D1 >= DMAX) ok = false;
+						else {
+							sweep(Dk, D1, 1);
+							c2 = sh[3];
+							if(c2 > CAP) ok = false;
+							else {
+								for(uint32_t i = c1 + tid; i < c2; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
+								__syncthreads();
+							}
+						}
+					}
+					if(ok) {
+						for(uint32_t i = tid; i < c2; i += 256) {
+							const unsigned long long mine = ck[i];
+							uint32_t rank = 0;
+							for(uint32_t j = 0; j < c2; ++j) rank += ck[j] < mine ? 1u : 0u;
+							if(rank < need) { outId[rank] = (int32_t) cn[i]; outDN[rank] = cp[i]; outPar[rank] = pair_exact(db, R, read, db.parent[cn[i]]); }
+						}
+						if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], c2); } }
+						served = true;
+					}
+				}
+			}
+		}
+	}
+	if(served) return;
+	if(tid == 0 && stat) atomicAdd(&stat[3], 1u);
+	topk_exact_recompute(db, R, read, maxNSeed, keys, chunk, sh, outId, outDN, outPar, seedCnt);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 __device__ inline double wave_sum(double x) {
 	for(int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m);
@@ -725,7 +953,7 @@ struct HuEstOut { double ratio, wnr, loglik; };
  * latency x occupancy, not by bandwidth: measured by capping waves per CU). */
 template<int UNR>
 __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ parDN,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
 	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, lane = threadIdx.x;
@@ -733,7 +961,7 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int v = db.parent[u];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
-	const uint32_t pv = hu_pair_load(pairs, (size_t) read * db.nNodesPad + v, p16);
+	const uint32_t pv = parDN[(size_t) read * HU_MAX_SEEDS + s];       /* (d, N) against the parent's sequence */
 	const double cDist = (double)(dn >> 16) / (double)(dn & 0xffffu);
 	const double pDist = (double)(pv >> 16) / (double)(pv & 0xffffu);
 	double ratio = cDist / (cDist + pDist);
@@ -823,10 +1051,10 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 
 #define HU_EST_KERNEL(NAME, UNR, MINW) \
 __global__ __launch_bounds__(64, MINW) void NAME(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes, \
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const void* __restrict__ pairs, int p16, \
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ parDN, \
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN, \
 		int weighted, HuEstOut* __restrict__ out) { \
-	estimate_body<UNR>(db, mdl, codes, rstart, rend, pairs, p16, seedCnt, seedId, seedDN, weighted, out); \
+	estimate_body<UNR>(db, mdl, codes, rstart, rend, parDN, seedCnt, seedId, seedDN, weighted, out); \
 }
 /* measured on MI355X (8192 reads, R = 1363): UNR 1 -> 12.3 ms, 2 -> 12.4, 4 -> 13.3 (register pressure
  * costs a wave per SIMD); forcing 5-6 waves per SIMD spills and doubles the time.  At UNR 1 the kernel

@@ -24,6 +24,7 @@
 	X(100, "v_add_f64 %0, %1, %0") X(101, "v_mul_f64 %0, %1, %0") X(102, "v_fma_f64 %0, %1, %2, %0") X(103, "v_min_f64 %0, %1, %0") X(104, "v_rcp_f64 %0, %0") \
 	X(105, "v_lshlrev_b64 %0, 1, %0") X(107, "v_cmp_lt_f64 vcc, %1, %0") X(109, "v_ldexp_f64 %0, %0, 1")
 
+static int g_clk = 0;
 template<int OP>
 __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t seed) {
 	uint32_t a[16];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void k64(uint32_t* out, int iters, uint32_t se
 	out[blockIdx.x * 256 + threadIdx.x] = (uint32_t) __double2loint(s);
 }
 
-static int g_clk = 0;
+
 template<class K>
 static void run(K kern, const char* name, int wavesPerSimd) {
 	const int iters = 2000, perIter = 32;
@@ -73,9 +74,58 @@ static void run(K kern, const char* name, int wavesPerSimd) {
 	CHK(hipFree(out)); CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
 }
 
+
+/* the (node, read, 32 sites) step of the seed scans as instruction mixes: cycles per STEP */
+template<int MIX>
+__global__ __launch_bounds__(256) void kmix(uint32_t* out, int iters, uint32_t seed) {
+	uint32_t a[16], b[16];
+	for(int i = 0; i < 16; ++i) { a[i] = seed * (i + 1) + threadIdx.x; b[i] = a[i] ^ 77u; }
+	uint32_t x = seed ^ threadIdx.x, y = seed * 3 + blockIdx.x, z = seed * 7 + threadIdx.x * 3;
+	asm volatile("s_mov_b32 s4, %0\n s_add_u32 s5, %0, 17\n s_add_u32 s6, %0, 99" : : "s"(seed) : "s4", "s5", "s6");
+	for(int it = 0; it < iters; ++it) {
+#pragma unroll
+		for(int i = 0; i < 16; ++i) {
+			uint32_t t1, t2, t3;
+			if(MIX == 0) asm volatile("v_and_b32 %2, s4, %5\n v_xor_b32 %3, s5, %6\n v_xor_b32 %4, s6, %7\n v_bitop3_b32 %3, %4, %2, %3 bitop3:0xc8\n v_bcnt_u32_b32 %0, %3, %0\n v_bcnt_u32_b32 %1, %2, %1"
+				: "+v"(a[i]), "+v"(b[i]), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x), "v"(y), "v"(z) : "s4", "s5", "s6");
+			if(MIX == 1) asm volatile("v_xor_b32 %2, s4, %5\n v_bitop3_b32 %2, %2, %6, s5 bitop3:0xf6\n v_bitop3_b32 %2, %2, %7, s6 bitop3:0x80\n v_bcnt_u32_b32 %0, %2, %0"
+				: "+v"(a[i]), "+v"(b[i]), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x), "v"(y), "v"(z) : "s4", "s5", "s6");
+			if(MIX == 2) asm volatile("v_xor_b32 %2, %5, %6\n v_bitop3_b32 %2, %2, %6, %7 bitop3:0xf6\n v_bitop3_b32 %2, %2, %7, %5 bitop3:0x80\n v_bcnt_u32_b32 %0, %2, %0"
+				: "+v"(a[i]), "+v"(b[i]), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x), "v"(y), "v"(z) : "s4", "s5", "s6");
+			if(MIX == 3) asm volatile("v_xor_b32 %2, %5, %6\n v_bitop3_b32 %2, %2, %6, %7 bitop3:0xf6\n v_bitop3_b32 %2, %2, %7, %5 bitop3:0x80\n v_add_u32 %0, %2, %0"
+				: "+v"(a[i]), "+v"(b[i]), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x), "v"(y), "v"(z) : "s4", "s5", "s6");
+		}
+	}
+	uint32_t s2 = y;
+	for(int i = 0; i < 16; ++i) s2 ^= a[i] ^ b[i];
+	out[blockIdx.x * 256 + threadIdx.x] = s2;
+}
+template<class K>
+static void runmix(K kern, const char* name, int wavesPerSimd) {
+	const int iters = 2000, perIter = 16;
+	const int blocks = 256 * wavesPerSimd;
+	uint32_t* out; CHK(hipMalloc(&out, (size_t) blocks * 256 * 4));
+	hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+	kern<<<blocks, 256>>>(out, 10, 1u);
+	CHK(hipDeviceSynchronize());
+	float best = 1e30f;
+	for(int r = 0; r < 3; ++r) {
+		CHK(hipEventRecord(e0)); kern<<<blocks, 256>>>(out, iters, 12345u + r); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if(ms < best) best = ms;
+	}
+	printf("%-72s %d waves/SIMD  %6.2f cycles per step\n", name, wavesPerSimd, best * 1e-3 * g_clk * 1e3 / ((double) iters * perIter * wavesPerSimd));
+	CHK(hipFree(out)); CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
 int main() {
 	CHK(hipDeviceGetAttribute(&g_clk, hipDeviceAttributeClockRate, 0));
 	printf("nominal clock %d MHz; cycles below are at that clock (the chip may run lower under load)\n", g_clk / 1000);
+	for(int w : {8, 4}) {
+		runmix(kmix<0>, "scan step with N: and(s) xor(s) xor(s) bitop3 bcnt bcnt", w);
+		runmix(kmix<1>, "scan step, d only: xor(s) bitop3(s) bitop3(s) bcnt", w);
+		runmix(kmix<2>, "the same on vector registers only", w);
+		runmix(kmix<3>, "the same with v_add_u32 in place of v_bcnt", w);
+	}
 	for(int w : {8, 2, 1}) {
 #define X(id, txt) run(k32<id>, txt, w);
 		OPS32(X)

@@ -269,15 +269,18 @@ def test_pe_merge_parity():
                                  dict(model="GTR", dg_k=0, n_leaves=150, cs_len=700, read_len=150),
                                  dict(model="JC69", dg_k=0, n_leaves=100, cs_len=700, read_len=150),
                                  dict(model="HKY85", dg_k=4, n_leaves=100, cs_len=700, read_len=100),
-                                 dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100)])
+                                 dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100),
+                                 # 5,199 nodes = 21 blocks of 256 >= 2 x max_nseed: the distance-only scan and its top-k (the gg_97-scale path)
+                                 dict(model="GTR", dg_k=4, n_leaves=2600, cs_len=300, read_len=100, max_nseed=10, n_reads=24, db_kw=dict(n_match=200)),
+                                 dict(model="HKY85", dg_k=0, n_leaves=2600, cs_len=700, read_len=300, max_nseed=8, n_reads=12, db_kw=dict(n_match=450))])
 def test_sep_parity(cfg):
     """seed scan, top-k, estimate, filter, place, q-values vs the oracle, stage by stage."""
     E = _engine()
     from oracle import oracle_py as O
-    db = get_db(cfg["n_leaves"], cfg["cs_len"], cfg["model"], dg_k=cfg["dg_k"])
+    db = get_db(cfg["n_leaves"], cfg["cs_len"], cfg["model"], dg_k=cfg["dg_k"], **cfg.get("db_kw", {}))
     _, H, T = oracle_objects(db)
-    reads, vps = sim_reads(db, 40, cfg["read_len"])
-    opts = E.default_opts()
+    reads, vps = sim_reads(db, cfg.get("n_reads", 40), cfg["read_len"])
+    opts = E.default_opts(max_nseed=cfg.get("max_nseed", 50))
     D, B = _run_stages(E, db, reads, vps, opts)
     B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
     cd, st, en = B.codes()
@@ -286,7 +289,7 @@ def test_sep_parity(cfg):
     cand = B.candidates()
     best = B.placements()
     coffs, cpl = B.candidate_places()
-    oo = O.default_opts()
+    oo = O.default_opts(maxNSeed=cfg.get("max_nseed", 50))
     worst = dict(est=0.0, ratio=0.0, wnr=0.0)
     stats = dict(reads=0, near_tie_swaps=0, best_differs_by_tie=0)
     for i in range(len(reads)):
@@ -754,26 +757,37 @@ def test_topk_sampled_threshold_path(monkeypatch):
     test_topk_degenerate_tie_mass()
 
 
-@pytest.mark.parametrize("mean_blen,max_nseed", [(0.05, 10), (0.05, 3), (1e-9, 10), (0.002, 8)])
-def test_topk_block_path(mean_blen, max_nseed):
-    """the scan's per-block lower bounds let k_seed_topk read only the blocks of the pair matrix that can hold a wanted node: seed
-    ids, their order and (d, N) equal the oracle's and the full-matrix paths', with ordinary distances, with distances that tie across
-    many blocks, and with every node at distance 0 (candidates overflow: the other paths take over)"""
+@pytest.mark.parametrize("mean_blen,max_nseed,read_len,wide", [(0.05, 10, 60, 0), (0.05, 3, 60, 1), (1e-9, 10, 60, 0), (0.002, 8, 60, 0), (0.05, 10, 300, 0), (0.0005, 10, 120, 0)])
+def test_distance_only_scan_and_its_topk(mean_blen, max_nseed, read_len, wide):
+    """Large trees: the scan keeps the distance d alone (8 bits, 16 when a read has more than 255 bases or on request) and per-block
+    minima; the top-k recomputes the (d, N) of its candidates from the bit-planes.  Seed ids, their order and (d, N) equal the oracle's
+    and the pair-matrix path's — with ordinary distances, with distances that tie across many blocks, and with every node at distance 0
+    (the exact recomputation takes over); hu_batch_get_pdist checks the scan's matrix against the planes, node by node."""
     E = _engine()
-    db = get_db(2600, 200, "JC69", dg_k=0, seed=11, mean_blen=mean_blen, n_match=120)      # 5,199 nodes = 21 blocks of 256
+    long_ = read_len > 255
+    db = get_db(2600, 700 if long_ else 200, "JC69", dg_k=0, seed=11, mean_blen=mean_blen, n_match=450 if long_ else 120)      # 5,199 nodes = 21 blocks of 256
     _, H, T = oracle_objects(db)
-    reads, vps = sim_reads(db, 24, 60, amplicon=True, cols=140)
+    reads, vps = sim_reads(db, 12 if long_ else 24, read_len, amplicon=True, cols=650 if long_ else 140)
     opts = E.default_opts(max_nseed=max_nseed)
     D, B = _run_stages(E, db, reads, vps, opts)
     assert D.n_nodes // 256 >= 2 * max_nseed
+    B.set_knob("pairs32", wide)
     B.get_seed(opts)
     cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
     for i in range(len(reads)):
         oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=max_nseed)
         assert cnt[i] == len(oid) == max_nseed and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
-    B.set_knob("topk_noblocks", 1); B.get_seed(opts)
+    for i in (0, len(reads) - 1):
+        d, N = B.pdist(i)                      # from the planes, and the scan's row checked against them inside
+        od, oN = T.pdist_all(cd[i], int(st[i]), int(en[i]))
+        assert (d == od).all() and (N == oN).all()
+    B.estimate_seq(opts); e1 = B.estimates()
+    B.set_knob("scan_pairs", 1); B.get_seed(opts)
     c2, i2, d2, n2 = B.seeds()
     assert np.array_equal(c2, cnt) and np.array_equal(i2[:, :max_nseed], ids[:, :max_nseed]) and np.array_equal(d2[:, :max_nseed], sd[:, :max_nseed])
+    B.estimate_seq(opts); e2 = B.estimates()
+    for a, b in zip(e1, e2):
+        assert np.array_equal(a[:, :max_nseed], b[:, :max_nseed], equal_nan=True)      # the parents' (d, N): same ratios either way
     B.close(); D.close()
 
 
