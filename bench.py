@@ -284,8 +284,8 @@ def main():
     # measured HBM traffic + VALU issue per kernel: from the newest committed PMC summary that was taken on THIS workload
     # (rocprofv3 --pmc passes of this same command, profiles/make_pmc_summary.py); tagged with its source, null otherwise
     stages = ("viterbi", "seed_pdist", "seed_topk", "estimate", "place")
-    pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_pdist2", "k_seed_pdist"),
-                      seed_topk=("k_seed_topk",), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
+    pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_dscan4", "k_seed_dscan", "k_seed_pdist2", "k_seed_pdist"),
+                      seed_topk=("k_seed_topk_d", "k_seed_topk"), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
     workload_key = dict(leaves=args.leaves, cs_len=args.cs_len, read_len=args.read_len, batch=args.batch, dg_k=args.dg_k, paired=bool(args.paired),
                         uniform_starts=bool(args.uniform_starts), win=args.win)
     pmc, pmc_src = {}, None
@@ -313,7 +313,7 @@ def main():
         e = dict(stage=k, kernel=name, ms_isolated=round(iso[k], 3), ms_in_timed_region=round(acc[k], 3), algorithmic_bytes=alg[k],
                  achieved=alg[k] / (iso[k] * 1e-3) / 1e9, unit="GB/s", frac=alg[k] / (iso[k] * 1e-3) / 1e9 / peak,
                  traffic=tr, hbm_measured_frac=(tr / (iso[k] * 1e-3) / 1e9 / peak if tr else None))
-        if ent.get("valu_issue_cycles_per_launch"):       # 2 cycles per 32-bit, 4 per FP64 / transcendental wave instruction, over 1,024 SIMDs
+        if ent.get("valu_issue_cycles_per_launch"):       # typed instruction counts x measured issue cycles (profiles/isa_cost.py), over 1,024 SIMDs
             e["valu_issue_frac"] = ent["valu_issue_cycles_per_launch"] / 1024.0 / (iso[k] * 1e-3 * ent.get("clock_hz", 2.4e9))
         kern.append(e)
     dom = max(kern, key=lambda x: x["ms_isolated"])

@@ -696,6 +696,7 @@ struct HuKnobs {
 	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
+	int dscan1 = 0;              /* the distance-only scan with one node per lane and scalar read planes (k_seed_dscan)             */
 	int scan_pairs = 0;          /* the full (d, N) pair matrix + k_seed_topk on large trees too (default there: distance-only scan) */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
@@ -709,7 +710,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -1212,8 +1213,11 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		const dim3 grid(tiles, d.nNodesPad / 256);
 		{
 			Timer t(b, HU_T_SEED_PDIST);
-			if(dOnly && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
-			else if(dOnly) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			const dim3 grid4(tiles, (d.nNodesPad + 1023) / 1024);
+			if(dOnly && b->knob.dscan1 && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else if(dOnly && b->knob.dscan1) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
 			else if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
 			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
 			else k_seed_pdist2<uint32_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
@@ -1946,19 +1950,21 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 		 * distance matrix, that row is checked against them (saturated at the matrix's width) */
 		DBuf<uint32_t> tmp;
 		int rc;
-		if((rc = tmp.ensure((size_t) nn)) != HU_OK) return rc;
-		k_pairs_of_read<<<(nn + 255) / 256, 256, 0, b->stream>>>(b->db->dev, read_planes(b), read, tmp.p);
+		if((rc = tmp.ensure((size_t) nn * 2)) != HU_OK) return rc;
+		k_pairs_of_read<<<(nn + 255) / 256, 256, 0, b->stream>>>(b->db->dev, read_planes(b), read, tmp.p, b->scanWidth ? tmp.p + nn : nullptr);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(v.data(), tmp.p, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
-		if(b->scanWidth) {
+		if(b->scanWidth) { /* the scan leaves the read's LISTED inserts out */
 			std::vector<uint8_t> row((size_t) nn * b->scanWidth);
+			std::vector<uint32_t> want(nn);
 			HIPCHK(hipMemcpyAsync(row.data(), (const uint8_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad * b->scanWidth, row.size(), hipMemcpyDeviceToHost, b->stream));
+			HIPCHK(hipMemcpyAsync(want.data(), tmp.p + nn, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
 			HIPCHK(hipStreamSynchronize(b->stream));
 			const uint32_t sat = b->scanWidth == 1 ? 255u : 65535u;
 			for(int i = 0; i < nn; ++i) {
 				const uint32_t got = b->scanWidth == 1 ? row[i] : ((const uint16_t*) row.data())[i];
-				if(got != std::min(v[i] >> 16, sat)) { hu_set_error("hu_batch_get_pdist: the distance-only scan holds %u for read %d, node %d; the planes give %u", got, read, i, v[i] >> 16); return HU_ERR_STATE; }
+				if(got != std::min(want[i] >> 16, sat)) { hu_set_error("hu_batch_get_pdist: the distance-only scan holds %u for read %d, node %d; the planes give %u", got, read, i, want[i] >> 16); return HU_ERR_STATE; }
 			}
 		}
 	}

@@ -213,28 +213,28 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
  * cycles, 6 of them for N.  Here N is not computed at all: three operations with one scalar operand each (the floor for six
  * inputs) and one population count, 16 cycles,
  *     a = n0 ^ r0;   b = a | (n1 ^ r1);   x = b & nv & rv;   d += popc(x)
- * and the matrix holds d alone, saturated to DT.  d / N >= d / (bases of the read) bounds the distance from below, which is all
- * the selection of the blocks needs (k_seed_topk_d); the exact (d, N) of the few candidates are recomputed there from the planes.
- * `bminD`: per (read, block of 256 nodes) the minimum d over the block's nodes other than the root. */
+ * and the matrix holds d alone, saturated to DT — over the quads of the tile only: the mismatches at a read's LISTED inserts
+ * (planes_of_codes) are left out.  Any part of the mismatches over the read's bases bounds the distance from below,
+ *     d_scan <= d,   N <= L = bases of the read   =>   d / N >= d_scan / L,
+ * which is all the selection needs (k_seed_topk_d); the exact (d, N) of the few candidates are recomputed there from the planes.
+ * `bminD`: per (read, block of 256 nodes) the minimum d_scan over the block's nodes other than the root.
+ *
+ * k_seed_dscan4 is the same with FOUR nodes per lane and the reads' planes broadcast from LDS into vector registers: every
+ * operation then runs on vector registers alone (2 cycles) and a step costs 10 cycles instead of 16; the LDS serves 48 broadcast
+ * reads of 16 B per wave and quad against 2,560 cycles of arithmetic. */
 template<class DT>
 __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, DT* __restrict__ dm, const int32_t* __restrict__ slotRead,
-		uint32_t* __restrict__ bminD) {
+		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD) {
 	constexpr int T = HU_READ_TILE;
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
 	const int node = blockIdx.y * 256 + tid;
 	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
-	const int32_t* __restrict__ til = tileIns + (size_t) tile * (T * HU_MAX_INS + 1);
-	const int nq = ql[0], ne = til[0];
+	const int nq = ql[0];
 	uint32_t d[T];
 #pragma unroll
 	for(int t = 0; t < T; ++t) d[t] = 0;
-	if(ne) {
-#pragma unroll
-		for(int t = 0; t < T; ++t) acc[t][tid] = 0;
-	}
 	const size_t np = (size_t) db.nNodesPad;
 	for(int qi = 0; qi < nq; ++qi) {
 		const int q = ql[1 + qi];
@@ -248,23 +248,11 @@ __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_
 #undef HU_DSTEP
 		}
 	}
-	{ /* inserts: as in k_seed_pdist2, the mismatch bit only */
-		const size_t npw = np / 64;
-		const int nb = __builtin_amdgcn_readfirstlane(node >> 6), lane = tid & 63;
-		for(int e = 0; e < ne; ++e) {
-			const int ent = til[1 + e];
-			const int t = ent >> 24, pos = (ent >> 2) & 0x3fffff, code = ent & 3;
-			const unsigned long long* cp = db.colPlanes + ((size_t)(pos - db.QM * 128) * 3) * npw + nb;
-			const unsigned long long W0 = cp[0], W1 = cp[npw], Wv = cp[2 * npw];
-			const uint32_t valid = (uint32_t)(Wv >> lane) & 1u, nc = ((uint32_t)(W0 >> lane) & 1u) | (((uint32_t)(W1 >> lane) & 1u) << 1);
-			atomicAdd(&acc[t][tid], valid & (nc != (uint32_t) code ? 1u : 0u));
-		}
-	}
 	const uint32_t skip = node < db.nNodes && node != db.root ? 0u : 0xffffffffu;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
-		const uint32_t v = min(d[t] + (ne ? acc[t][tid] : 0u), DMAX);
+		const uint32_t v = min(d[t], DMAX);
 		if(read >= 0) dm[(size_t) read * np + node] = (DT) v;
 		acc[t][tid] = v | skip;                   /* own slot: nobody else has read or written it yet */
 	}
@@ -278,6 +266,100 @@ __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_
 	m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m); m = dpp_min_full<0x141>(m); m = dpp_min_full<0x140>(m);
 	const int read = slotRead[tile * T + t];
 	if(sg == 0 && read >= 0) bminD[(size_t) read * gridDim.y + blockIdx.y] = m;
+}
+
+template<class DT>
+__global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32_t* __restrict__ rp,
+		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD) {
+	constexpr int T = HU_READ_TILE, M = 4;
+	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
+	static_assert(T == 16, "sixteen reads x sixteen dwords per quad = one dword per thread");
+	__shared__ __attribute__((aligned(16))) uint32_t rpl[T * 16];              /* the tile's planes of one quad */
+	__shared__ __attribute__((aligned(16))) uint32_t mb[4][T][64];             /* per wave: minimum over a lane's four nodes, read by read */
+	const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int node0 = blockIdx.y * (256 * M) + tid * M;                         /* four consecutive nodes per lane: a wave = one block of 256 */
+	const bool live = node0 < db.nNodesPad;
+	const int nl = live ? node0 : 0;
+	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
+	const int nq = ql[0];
+	uint32_t d[T][M];
+#pragma unroll
+	for(int t = 0; t < T; ++t)
+#pragma unroll
+		for(int m = 0; m < M; ++m) d[t][m] = 0;
+	const size_t np = (size_t) db.nNodesPad;
+	for(int qi = 0; qi < nq; ++qi) {
+		const int q = ql[1 + qi];
+		const uint32_t mine = rp[((size_t) tile * db.WQ + q) * (T * 16) + tid];
+		uint4 n0[M], n1[M], nv[M];
+#pragma unroll
+		for(int m = 0; m < M; ++m) {
+			n0[m] = db.planes[((size_t) q * 3 + 0) * np + nl + m]; n1[m] = db.planes[((size_t) q * 3 + 1) * np + nl + m]; nv[m] = db.planes[((size_t) q * 3 + 2) * np + nl + m];
+		}
+		__syncthreads();                       /* the previous quad's planes have been read by every wave */
+		rpl[tid] = mine;
+		__syncthreads();
+		/* a read's sixteen (node, word) steps are independent until the four population counts of a node meet in its counter: issued
+		 * stage by stage (left alone the compiler chains all 64 instructions through two registers, and a dependent instruction
+		 * waits out the pipeline with only three waves per SIMD to fill it); the next read's planes are requested before the
+		 * arithmetic of this one */
+		uint4 r0 = *reinterpret_cast<const uint4*>(&rpl[0]), r1 = *reinterpret_cast<const uint4*>(&rpl[4]), rv = *reinterpret_cast<const uint4*>(&rpl[8]);
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const int tn = t + 1 < T ? t + 1 : t;
+			const uint4 p0 = *reinterpret_cast<const uint4*>(&rpl[tn * 16]), p1 = *reinterpret_cast<const uint4*>(&rpl[tn * 16 + 4]), pv = *reinterpret_cast<const uint4*>(&rpl[tn * 16 + 8]);
+			uint32_t a[M][4];
+#pragma unroll
+			for(int m = 0; m < M; ++m) { a[m][0] = n0[m].x ^ r0.x; a[m][1] = n0[m].y ^ r0.y; a[m][2] = n0[m].z ^ r0.z; a[m][3] = n0[m].w ^ r0.w; }
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for(int m = 0; m < M; ++m) {
+				a[m][0] = __builtin_amdgcn_bitop3_b32(a[m][0], n1[m].x, r1.x, 0xf6); a[m][1] = __builtin_amdgcn_bitop3_b32(a[m][1], n1[m].y, r1.y, 0xf6);
+				a[m][2] = __builtin_amdgcn_bitop3_b32(a[m][2], n1[m].z, r1.z, 0xf6); a[m][3] = __builtin_amdgcn_bitop3_b32(a[m][3], n1[m].w, r1.w, 0xf6);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for(int m = 0; m < M; ++m) {
+				a[m][0] = __builtin_amdgcn_bitop3_b32(a[m][0], nv[m].x, rv.x, 0x80); a[m][1] = __builtin_amdgcn_bitop3_b32(a[m][1], nv[m].y, rv.y, 0x80);
+				a[m][2] = __builtin_amdgcn_bitop3_b32(a[m][2], nv[m].z, rv.z, 0x80); a[m][3] = __builtin_amdgcn_bitop3_b32(a[m][3], nv[m].w, rv.w, 0x80);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for(int w = 0; w < 4; ++w) {
+#pragma unroll
+				for(int m = 0; m < M; ++m) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d[t][m]) : "v"(a[m][w]));    /* count and accumulate in one (the compiler splits it into count + add3) */
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			r0 = p0; r1 = p1; rv = pv;
+		}
+	}
+	uint32_t skip[M];
+#pragma unroll
+	for(int m = 0; m < M; ++m) skip[m] = live && node0 + m < db.nNodes && node0 + m != db.root ? 0u : 0xffffffffu;
+#pragma unroll
+	for(int t = 0; t < T; ++t) {
+		const int read = slotRead[tile * T + t];
+		uint32_t v[M];
+#pragma unroll
+		for(int m = 0; m < M; ++m) v[m] = min(d[t][m], DMAX);
+		if(read >= 0 && live) {
+			DT* dst = dm + (size_t) read * np + node0;
+			if(sizeof(DT) == 1) *reinterpret_cast<uint32_t*>(dst) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+			else *reinterpret_cast<uint2*>(dst) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+		}
+		mb[wave][t][lane] = min(min(v[0] | skip[0], v[1] | skip[1]), min(v[2] | skip[2], v[3] | skip[3]));
+	}
+	__syncthreads();
+	{ /* the wave's block: read t = lane / 4, four lanes x sixteen values, then two steps inside the quad of lanes */
+		const int t = lane >> 2, sg = lane & 3;
+		const uint4* row = reinterpret_cast<const uint4*>(&mb[wave][t][sg * 16]);
+		const uint4 a = row[0], b = row[1], c = row[2], e = row[3];
+		uint32_t m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+		m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
+		m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m);
+		const int read = slotRead[tile * T + t], blk = blockIdx.y * M + wave;
+		if(sg == 0 && read >= 0 && blk < db.nNodesPad / 256) bminD[(size_t) read * (db.nNodesPad / 256) + blk] = m;
+	}
 }
 
 /* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
@@ -517,7 +599,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restr
  * pairs the distance-only path needs (candidates of the top-k, the seeds' parents, given seeds).  The read's planes are found
  * through its slot in the scan's tiling, its quads through its quad bitmap, its listed inserts through `ins`. */
 struct HuReadPlanes { const uint32_t* rp; const uint32_t* rq; const int32_t* ins; const int32_t* readSlot; };
-__device__ inline uint32_t pair_exact(const HuDbDev& db, const HuReadPlanes& R, int r, int node) {
+__device__ inline uint32_t pair_exact(const HuDbDev& db, const HuReadPlanes& R, int r, int node, bool listed = true) {
 	const int slot = R.readSlot[r], tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
 	const int nw32 = (db.WQ + 31) / 32;
 	const size_t np = (size_t) db.nNodesPad;
@@ -536,7 +618,7 @@ __device__ inline uint32_t pair_exact(const HuDbDev& db, const HuReadPlanes& R, 
 		}
 	}
 	const int32_t* __restrict__ il = R.ins + (size_t) r * (HU_MAX_INS + 1);
-	const int cnt = il[0];
+	const int cnt = listed ? il[0] : 0;
 	for(int e = 0; e < cnt; ++e) {
 		const int ent = il[1 + e], pos = ent >> 2, code = ent & 3;
 		const int q = pos >> 7, w = (pos >> 5) & 3, bit = pos & 31;
@@ -564,9 +646,9 @@ __device__ inline uint32_t read_bases(const HuDbDev& db, const HuReadPlanes& R, 
 }
 
 /* every (d, N) of one read (hu_batch_get_pdist after the distance-only scan) */
-__global__ __launch_bounds__(256) void k_pairs_of_read(HuDbDev db, HuReadPlanes R, int read, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_pairs_of_read(HuDbDev db, HuReadPlanes R, int read, uint32_t* __restrict__ out, uint32_t* __restrict__ outScan) {
 	const int node = blockIdx.x * 256 + threadIdx.x;
-	if(node < db.nNodes) out[node] = pair_exact(db, R, read, node);
+	if(node < db.nNodes) { out[node] = pair_exact(db, R, read, node); if(outScan) outScan[node] = pair_exact(db, R, read, node, false); }
 }
 /* (d, N) of the seeds' parents from the pair matrix (the paths that keep one): estimateSeq's pDist(v.seq) */
 __global__ void k_parent_pairs(HuDbDev db, int n, const void* __restrict__ pairs, int p16, const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId,
@@ -667,28 +749,32 @@ __device__ inline void topk_exact_recompute(const HuDbDev& db, const HuReadPlane
 }
 
 /* std::sort + truncation to max_nseed after the distance-only scan: one workgroup per read.
- *   L = bases of the read >= every N, so d / N >= d / L: a node at distance x has d <= x L.
- *   1. Dsel = the max_nseed-th smallest block minimum of d (bitwise selection on one wave): at least max_nseed blocks hold a node
- *      with d <= Dsel; no other block does.
- *   2. histogram of d over those blocks -> Dk, the max_nseed-th smallest d overall; C1 = {d <= Dk} (>= max_nseed nodes).
+ *   d_scan <= d (the scan leaves the listed inserts out), L = bases of the read >= every N: a node at distance x has d_scan <= x L.
+ *   1. Dsel = the max_nseed-th smallest block minimum of d_scan (bitwise selection on one wave): at least max_nseed blocks hold a
+ *      node with d_scan <= Dsel; no other block does.
+ *   2. histogram of d_scan over those blocks -> Dk, the max_nseed-th smallest d_scan overall; C1 = {d_scan <= Dk} (>= max_nseed nodes).
  *   3. exact (d, N) of C1 from the planes; (d1, N1) = its max_nseed-th smallest key, an upper bound of the wanted distance.
- *   4. every wanted node has d <= D1 = floor(d1 L / N1); if D1 > Dk the nodes with Dk < d <= D1 join (blocks with minimum <= D1).
- *   5. the candidates ranked by counting on their exact keys (dist, node id); (d, N) of the seeds and of their parents written.
- * Comparisons on the saturated matrix are valid below the saturation value; a read that reaches it, or whose ties overflow the
- * buffers, takes topk_exact_recompute.  stat (optional): reads served here, blocks, candidates, reads passed on. */
+ *   4. every wanted node has d_scan <= D1 = floor(d1 L / N1); if D1 > Dk the nodes with Dk < d_scan <= D1 join.
+ *   5. (d, N) of the seeds and of their parents written in (dist, node id) order.
+ * Candidates are absorbed into a kept set of the max_nseed best by counting ranks on the exact keys — all at once when the
+ * histogram says they fit the buffers (the usual case: ~80 candidates), else three blocks at a time.  Comparisons on the saturated
+ * matrix are valid below the saturation value; a read that reaches it, or has fewer than max_nseed nodes with N > 0, takes
+ * topk_exact_recompute; a read without bases gets the first nodes by id with (0, 0) like k_seed_topk.
+ * stat (optional): reads served here, blocks, candidates, reads passed on. */
 template<class DT>
 __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __restrict__ dm, const uint32_t* __restrict__ bminD, HuReadPlanes R,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
 		uint32_t* __restrict__ stat) {
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	constexpr int NBITS = 8 * (int) sizeof(DT);
-	constexpr uint32_t CAP = 1024, HB = 1024;
+	constexpr uint32_t CAP = 1024, HB = 1024, NONE = 0xffffffffu;
+	static_assert(3 * 256 + HU_MAX_SEEDS <= CAP, "three blocks and the kept set fit the candidate buffers");
 	__shared__ unsigned long long keys[HU_TOPK_CAP];        /* 32 KB, carved up below */
 	__shared__ uint32_t chunk[256];
 	__shared__ uint32_t sh[8];
 	uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                                   /* [2048] block minima          0 ..  8 KB */
 	unsigned short* sel = reinterpret_cast<unsigned short*>(keys + 1024);               /* [2048] chosen blocks         8 .. 12 KB */
-	uint32_t* hist = reinterpret_cast<uint32_t*>(keys + 1536);                          /* [HB] histogram of d         12 .. 16 KB */
+	uint32_t* hist = reinterpret_cast<uint32_t*>(keys + 1536);                          /* [HB] histogram of d_scan    12 .. 16 KB */
 	unsigned long long* ck = keys + 2048;                                               /* [CAP] candidate keys        16 .. 24 KB */
 	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
 	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
@@ -701,13 +787,22 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 	uint32_t* outPar = parDN + (size_t) read * HU_MAX_SEEDS;
 	const uint32_t need = (uint32_t) maxNSeed;
 	const int per = (nBlk + 63) / 64;                                                   /* block minima per lane of wave 0: <= 32 */
-	for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bminD[(size_t) read * nBlk + i] : 0xffffffffu;
-	if(tid == 0) { sh[0] = 0xffffffffu; sh[2] = 0; sh[3] = 0; sh[4] = 0; sh[5] = read_bases(db, R, read); }
+	for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bminD[(size_t) read * nBlk + i] : NONE;
+	if(tid == 0) { sh[0] = NONE; sh[2] = 0; sh[3] = 0; sh[5] = read_bases(db, R, read); }
 	__syncthreads();
+	const uint32_t L = sh[5];
+	if(L == 0) { /* no base in the region (a read that was not aligned): every N is 0, the order is the node ids' */
+		if(tid == 0) {
+			int k = 0;
+			for(int node = 0; node < db.nNodes && k < maxNSeed; ++node) if(node != db.root) { outId[k] = node; outDN[k] = 0; outPar[k] = 0; ++k; }
+			seedCnt[read] = k;
+		}
+		return;
+	}
 	if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
 		uint32_t x[32];
 #pragma unroll
-		for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : 0xffffffffu;
+		for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : NONE;
 		uint32_t res = 0;
 		if(per <= 16) {
 			for(int bit = NBITS; bit >= 0; --bit) {
@@ -729,95 +824,111 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		if(tid == 0) sh[0] = res;
 	}
 	__syncthreads();
-	const uint32_t Dsel = sh[0], L = sh[5];
+	const uint32_t Dsel = sh[0];
 	bool served = false;
 	if(Dsel < DMAX && Dsel < HB) {
-		/* one pass over the blocks with minimum <= lim: histogram (pass 0: d <= lim) or list (pass 1: lo < d <= lim) */
-		auto sweep = [&](uint32_t lo, uint32_t lim, int pass) {
+		/* blocks with minimum <= lim -> sel; returns their number */
+		auto choose = [&](uint32_t lim) {
 			if(tid == 0) sh[2] = 0;
 			__syncthreads();
 			for(int i = tid; i < nBlk; i += 256)
 				if(bm[i] <= lim) sel[atomicAdd(&sh[2], 1u)] = (unsigned short) i;
 			__syncthreads();
-			const int nsel = (int) sh[2];
+			return (int) sh[2];
+		};
+		/* the nodes of sel[g0, g1) with lo < d_scan <= lim (lo == NONE: no lower limit): histogram (pass 0) or list at sh[3] (pass 1) */
+		auto sweep = [&](int g0, int g1, uint32_t lo, uint32_t lim, int pass) {
 #pragma unroll 1
-			for(int s0 = 0; s0 < nsel; s0 += 16) {     /* sixteen loads in flight per thread: scalar block base + one lane offset */
+			for(int s0 = g0; s0 < g1; s0 += 16) {     /* sixteen loads in flight per thread: scalar block base + one lane offset */
 				uint32_t pv[16];
 #pragma unroll
-				for(int k = 0; k < 16; ++k) pv[k] = s0 + k < nsel ? (uint32_t) (dr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : 0xffffffffu;
+				for(int k = 0; k < 16; ++k) pv[k] = s0 + k < g1 ? (uint32_t) (dr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : NONE;
 #pragma unroll
 				for(int k = 0; k < 16; ++k) {
-					if(s0 + k >= nsel) continue;
+					if(s0 + k >= g1) continue;
 					const int node = __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid;
 					if(node >= db.nNodes || node == db.root || pv[k] > lim) continue;
 					if(pass == 0) atomicAdd(&hist[pv[k]], 1u);
-					else if(pv[k] > lo || lo == 0xffffffffu) { const uint32_t slot = atomicAdd(&sh[3], 1u); if(slot < CAP) cn[slot] = (uint32_t) node; }
+					else if(lo == NONE || pv[k] > lo) { const uint32_t slot = atomicAdd(&sh[3], 1u); if(slot < CAP) cn[slot] = (uint32_t) node; }
 				}
 			}
 			__syncthreads();
-			return nsel;
+		};
+		uint32_t nb = 0;                          /* kept candidates: slots [0, nb) of ck / cp / cn, the max_nseed best so far once there are that many */
+		uint32_t seen = 0;
+		/* candidates with lo < d_scan <= lim join the kept set; `expect` = their number if known */
+		auto absorb = [&](uint32_t lo, uint32_t lim, uint32_t expect) -> bool {
+			const int nsel = choose(lim);
+			const int group = expect != NONE && nb + expect <= CAP ? (nsel > 0 ? nsel : 1) : 3;
+			for(int g0 = 0; g0 < nsel; g0 += group) {
+				if(tid == 0) sh[3] = nb;
+				__syncthreads();
+				sweep(g0, min(g0 + group, nsel), lo, lim, 1);
+				const uint32_t cnt = sh[3];
+				if(cnt > CAP) return false;
+				seen += cnt - nb;
+				for(uint32_t i = nb + tid; i < cnt; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
+				__syncthreads();
+				if(cnt >= need) { /* keep the max_nseed best, in order: rank = number of smaller keys (the keys are distinct) */
+					uint32_t rk[CAP / 256], kn[CAP / 256], kp[CAP / 256]; unsigned long long kk[CAP / 256];
+#pragma unroll
+					for(int q = 0; q < (int)(CAP / 256); ++q) {
+						const uint32_t i = q * 256 + tid;
+						rk[q] = NONE;
+						if(i < cnt) {
+							const unsigned long long mine = ck[i];
+							uint32_t rank = 0;
+							for(uint32_t j = 0; j < cnt; ++j) rank += ck[j] < mine ? 1u : 0u;
+							rk[q] = rank; kk[q] = mine; kn[q] = cn[i]; kp[q] = cp[i];
+						}
+					}
+					__syncthreads();
+#pragma unroll
+					for(int q = 0; q < (int)(CAP / 256); ++q) if(rk[q] < need) { ck[rk[q]] = kk[q]; cn[rk[q]] = kn[q]; cp[rk[q]] = kp[q]; }
+					__syncthreads();
+					nb = need;
+				}
+				else nb = cnt;
+			}
+			return true;
 		};
 		for(int i = tid; i < (int) HB; i += 256) hist[i] = 0;
-		__syncthreads();
-		const int nsel0 = sweep(0, Dsel, 0);
+		const int nsel0 = choose(Dsel);
+		sweep(0, nsel0, NONE, Dsel, 0);
 		chunk[tid] = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
 		__syncthreads();
-		if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk */
+		if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk and the number of nodes with d_scan <= Dk */
 			const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
 			uint32_t inc = c16;
 			for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
 			const unsigned long long reached = __ballot(inc >= need);
-			if(!reached) { if(tid == 0) sh[1] = 0xffffffffu; }
+			if(!reached) { if(tid == 0) sh[1] = NONE; }
 			else if(tid == __ffsll((long long) reached) - 1) {
 				uint32_t cum = inc - c16; int bb = tid * 16;
 				while(bb < tid * 16 + 15 && cum + hist[bb] < need) { cum += hist[bb]; ++bb; }
-				sh[1] = (uint32_t) bb;
+				sh[1] = (uint32_t) bb; sh[6] = cum + hist[bb];
 			}
 		}
 		__syncthreads();
-		const uint32_t Dk = sh[1];
-		if(Dk <= Dsel) {
-			sweep(0xffffffffu, Dk, 1);                             /* C1 = every node with d <= Dk */
-			uint32_t c1 = sh[3];
-			if(c1 >= need && c1 <= CAP) {
-				for(uint32_t i = tid; i < c1; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
-				__syncthreads();
-				/* (d1, N1): the key of rank max_nseed - 1 among C1 (keys are distinct) */
-				for(uint32_t i = tid; i < c1; i += 256) {
-					const unsigned long long mine = ck[i];
-					uint32_t rank = 0;
-					for(uint32_t j = 0; j < c1; ++j) rank += ck[j] < mine ? 1u : 0u;
-					if(rank == need - 1) sh[4] = cp[i];
+		const uint32_t Dk = sh[1], cnt1 = sh[6];
+		if(Dk <= Dsel && absorb(NONE, Dk, cnt1) && nb == need) {
+			const uint32_t c1p = cp[need - 1], d1 = c1p >> 16, N1 = c1p & 0xffffu;     /* the max_nseed-th smallest key of C1 */
+			if(N1 != 0) {
+				const unsigned long long D1l = (unsigned long long) d1 * L / N1;
+				const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
+				bool ok = true;
+				if(D1 > Dk) {
+					if(D1 >= DMAX) ok = false;
+					else {
+						if(tid == 0) { uint32_t e = NONE; if(D1 <= Dsel) { e = 0; for(uint32_t x = Dk + 1; x <= D1; ++x) e += hist[x]; } sh[7] = e; }
+						__syncthreads();
+						ok = absorb(Dk, D1, sh[7]);
+					}
 				}
-				__syncthreads();
-				const uint32_t c1p = sh[4], d1 = c1p >> 16, N1 = c1p & 0xffffu;
-				if(N1 != 0) {
-					const unsigned long long D1l = (unsigned long long) d1 * L / N1;
-					const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
-					bool ok = true;
-					uint32_t c2 = c1;
-					if(D1 > Dk) {
-						if(D1 >= DMAX) ok = false;
-						else {
-							sweep(Dk, D1, 1);
-							c2 = sh[3];
-							if(c2 > CAP) ok = false;
-							else {
-								for(uint32_t i = c1 + tid; i < c2; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
-								__syncthreads();
-							}
-						}
-					}
-					if(ok) {
-						for(uint32_t i = tid; i < c2; i += 256) {
-							const unsigned long long mine = ck[i];
-							uint32_t rank = 0;
-							for(uint32_t j = 0; j < c2; ++j) rank += ck[j] < mine ? 1u : 0u;
-							if(rank < need) { outId[rank] = (int32_t) cn[i]; outDN[rank] = cp[i]; outPar[rank] = pair_exact(db, R, read, db.parent[cn[i]]); }
-						}
-						if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], c2); } }
-						served = true;
-					}
+				if(ok) {
+					for(uint32_t i = tid; i < need; i += 256) { outId[i] = (int32_t) cn[i]; outDN[i] = cp[i]; outPar[i] = pair_exact(db, R, read, db.parent[cn[i]]); }
+					if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
+					served = true;
 				}
 			}
 		}

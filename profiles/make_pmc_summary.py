@@ -6,8 +6,10 @@
      profiles/<tag>_summary.md          one table
    HBM bytes: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM: gfx950 tallies the 128-B requests
    of wide coalesced reads at 64 B), WRITE_SIZE is taken as is.
-   VALU issue cycles per launch = 4 x (ADD + MUL + FMA)_F64 + 16 x TRANS_F64 + 8 x TRANS_F32 + 2 x every other VALU instruction
-   (MI355X_MICROARCH.md: 2 cycles per 32-bit wave-instruction on the SIMD-32, FP64 at half that rate, transcendentals at a quarter).
+   VALU issue cycles per launch = 4 x (ADD + MUL + FMA)_F64 + 16 x TRANS_F64 + 8 x TRANS_F32 + c x every other VALU instruction,
+   c = the mean issue cost of those instructions in the kernel's inner loops (profiles/isa_cost.py over the ISA listing with the rates
+   measured by profiles/ubench/valu_rate.hip: 2 cycles only for a handful of operations on vector registers alone, 4 for the rest and
+   for anything with a scalar operand; profiles/<tag>_isa_costs.json), 4 when the kernel is not in that file.
    Usage: python3 profiles/make_pmc_summary.py gpurun_out/<tag> <tag> '<workload json>'"""
 import collections, csv, json, os, shutil, sys
 
@@ -24,6 +26,9 @@ def agg(path):
 
 
 fe, wr, sq, va = (agg(os.path.join(d, x + "_engine.csv")) for x in ("fetch", "write", "sq", "valu"))
+isa = {}
+if os.path.exists("profiles/%s_isa_costs.json" % tag):
+    isa = json.load(open("profiles/%s_isa_costs.json" % tag))["kernels"]
 bench = json.load(open(os.path.join(d, "bench_profiled.json")))
 iso = {}
 for k in bench.get("roofline_kernels", []):
@@ -47,7 +52,9 @@ for k in sorted(set(fe) | set(sq)):
         tot = sq[k].get("SQ_INSTS_VALU", 0)
         e.update({c: x for c, x in v.items() if c != "launches"})
         e["valu_fp64_frac"] = (f64 + t64) / tot if tot else None
-        e["valu_issue_cycles_per_launch"] = 4 * f64 + 16 * t64 + 8 * t32 + 2 * max(0.0, tot - f64 - t64 - t32)
+        rest_cost = (isa.get(k) or {}).get("rest_mean_cycles") or 4.0
+        e["valu_rest_mean_cycles"] = rest_cost
+        e["valu_issue_cycles_per_launch"] = 4 * f64 + 16 * t64 + 8 * t32 + rest_cost * max(0.0, tot - f64 - t64 - t32)
     if sq.get(k, {}).get("SQ_WAVE_CYCLES"):
         e["valu_active_per_wave_cycle"] = sq[k].get("SQ_ACTIVE_INST_VALU", 0) / sq[k]["SQ_WAVE_CYCLES"]
         e["waiting_frac"] = sq[k].get("SQ_WAIT_ANY", 0) / sq[k]["SQ_WAVE_CYCLES"]
@@ -75,7 +82,7 @@ if os.path.exists(p1):
 for x in ("fetch", "write", "sq", "valu"):
     shutil.copy(os.path.join(d, x + "_engine.csv"), "profiles/%s_pmc_%s.csv" % (tag, x))
 onetime = lambda nm: nm.startswith(('k_pack', 'k_tree', 'k_model', 'k_col'))
-stage_prefix = [("k_viterbi", "viterbi"), ("k_seed_pdist", "seed_pdist"), ("k_seed_topk", "seed_topk"), ("k_estimate", "estimate"), ("k_place", "place")]
+stage_prefix = [("k_viterbi", "viterbi"), ("k_seed_dscan", "seed_pdist"), ("k_seed_pdist", "seed_pdist"), ("k_seed_topk", "seed_topk"), ("k_estimate", "estimate"), ("k_place", "place")]
 by_stage = {k["stage"]: k for k in bench.get("roofline_kernels", [])}
 def stage_entry(nm):
     for pre, st in stage_prefix:
@@ -108,6 +115,7 @@ with open("profiles/%s_summary.md" % tag, "w") as f:
             "%.0f %%" % (100 * e["valu_issue_cycles_per_launch"] / 1024 / (ms * 1e-3 * 2.4e9)) if e.get("valu_issue_cycles_per_launch") and ms else "",
             "%.2f" % e["valu_active_per_wave_cycle"] if "valu_active_per_wave_cycle" in e else "",
             "%.2f" % e["l2_hit_rate"] if e.get("l2_hit_rate") is not None else ""))
-    f.write("\nVALU issue %: 4 cycles per FP64 add/mul/fma, 16 per FP64 transcendental (v_rcp_f64), 8 per FP32 transcendental, 2 per other VALU wave-instruction, over 1,024 SIMDs at 2.4 GHz "
+    f.write("\nVALU issue %: 4 cycles per FP64 add/mul/fma, 16 per FP64 transcendental (v_rcp_f64), 8 per FP32 transcendental, and for every other VALU wave-instruction the mean issue cost "
+            "of such instructions in the kernel's inner loops (profiles/isa_cost.py, rates measured by profiles/ubench/valu_rate.hip: 2 cycles for a few operations on vector registers alone, else 4), over 1,024 SIMDs at 2.4 GHz "
             "and the kernel's isolated time (bench.py HIP events, one batch in flight); the chip holds less than 2.4 GHz under FP64-dense load, so 100 % is not reachable.\n")
 print(open("profiles/%s_summary.md" % tag).read())

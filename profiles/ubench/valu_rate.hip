@@ -19,10 +19,10 @@
 	X(29, "v_pk_add_u16 %0, %1, %0") X(30, "v_cvt_f32_u32 %0, %0") X(31, "v_cvt_f32_ubyte1 %0, %0") X(32, "v_rcp_f32 %0, %0") X(33, "v_exp_f32 %0, %0") \
 	X(34, "v_add_f32 %0, %1, %0") X(35, "v_mul_f32 %0, %1, %0") X(36, "v_fma_f32 %0, %1, %2, %0") X(37, "v_min_f32 %0, %1, %0") \
 	X(39, "v_cmp_lt_u32 vcc, %1, %0") X(40, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") X(41, "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
-	X(42, "v_xor_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") X(43, "v_sad_u32 %0, %1, %2, %0") X(44, "v_mbcnt_lo_u32_b32 %0, %1, %0") X(45, "v_readlane_b32 s6, %0, 3")
+	X(42, "v_xor_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") X(43, "v_sad_u32 %0, %1, %2, %0") X(44, "v_mbcnt_lo_u32_b32 %0, %1, %0") X(45, "v_readlane_b32 s6, %0, 3") X(46, "v_cndmask_b32_e64 %0, %1, %0, s[8:9]") X(47, "v_not_b32 %0, %0") X(48, "v_xor_b32 %0, 0x12345678, %0") X(49, "v_xor_b32 %0, 5, %0") X(50, "v_fmac_f32 %0, %1, %2") X(51, "v_max_f32 %0, %1, %0") X(52, "v_mul_f32 %0, 0x40490fdb, %0") X(53, "v_mul_f32 %0, s4, %0")
 #define OPS64(X) \
 	X(100, "v_add_f64 %0, %1, %0") X(101, "v_mul_f64 %0, %1, %0") X(102, "v_fma_f64 %0, %1, %2, %0") X(103, "v_min_f64 %0, %1, %0") X(104, "v_rcp_f64 %0, %0") \
-	X(105, "v_lshlrev_b64 %0, 1, %0") X(107, "v_cmp_lt_f64 vcc, %1, %0") X(109, "v_ldexp_f64 %0, %0, 1")
+	X(105, "v_lshlrev_b64 %0, 1, %0") X(107, "v_cmp_lt_f64 vcc, %1, %0") X(109, "v_ldexp_f64 %0, %0, 1") X(110, "v_max_f64 %0, %1, %0") X(111, "v_fma_f64 %0, %1, s[8:9], %0") X(113, "v_mul_f64 %0, 2.0, %0")
 
 static int g_clk = 0;
 template<int OP>
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, int iters, uint32_t se
 	uint32_t x = seed ^ threadIdx.x, y = seed * 3 + blockIdx.x;
 	asm volatile("s_mov_b32 s4, %0" : : "s"(seed) : "s4");
 	for(int it = 0; it < iters; ++it) {
-#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "s4", "s6", "vcc"); } }
+#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "s4", "s6", "s8", "s9", "vcc"); } }
 		OPS32(X)
 #undef X
 	}
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k64(uint32_t* out, int iters, uint32_t se
 	for(int i = 0; i < 16; ++i) a[i] = 1.0 + 1e-9 * (seed * (i + 1) + threadIdx.x);
 	double x = 1.0 + 1e-12 * (seed ^ threadIdx.x), y = 1e-13 * blockIdx.x;
 	for(int it = 0; it < iters; ++it) {
-#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "vcc"); } }
+#define X(id, txt) if(OP == id) { _Pragma("unroll") for(int h = 0; h < 2; ++h) { _Pragma("unroll") for(int i = 0; i < 16; ++i) asm volatile(txt : "+v"(a[i]) : "v"(x), "v"(y) : "vcc", "s8", "s9"); } }
 		OPS64(X)
 #undef X
 	}
