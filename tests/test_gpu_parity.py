@@ -791,6 +791,41 @@ def test_distance_only_scan_and_its_topk(mean_blen, max_nseed, read_len, wide):
     B.close(); D.close()
 
 
+def test_seed_paths_agree_on_a_large_tree():
+    """The two seed paths on a tree of 39,999 nodes with the default 50 seeds, 2,048 reads (amplicon reads, reads scattered over the
+    consensus, a few reads cut down to a handful of bases): distance-only scan + top-k from the planes against pair matrix + k_seed_topk —
+    same seed ids, order, (d, N) and the same estimates (the parents' pairs) for every read."""
+    E = _engine()
+    import torch
+    from hmmufotu_amd import synth, synth_gpu
+    db, up, down = synth_gpu.make_db_gpu(20000, 1500, "GTR", dg_k=0, seed=21, device="cuda:0", log=lambda *a: None)
+    reads = synth_gpu.simulate_reads_gpu(db, up, down, 1536, 150, seed=5, amplicon_start=200, amplicon_cols=170, device="cuda:0")
+    reads += synth_gpu.simulate_reads_gpu(db, up, down, 512, 150, seed=6, amplicon_start=0, amplicon_cols=170, uniform=True, device="cuda:0")
+    for i in range(0, 40, 5):                                  # short reads: few bases, many ties
+        r = reads[i]; reads[i] = synth.SimRead(r.seq[:12 + i], r.cols[:12 + i], r.node, r.rc, r.cs_start, r.cs_end)
+    vps = np.stack([synth.read_vpaths(db.hmm, r) for r in reads])
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+    D = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, db.anno_id, msgs_on_device=True)
+    assert D.n_nodes // 256 >= 100
+    B = E.Batch(D, len(reads))
+    opts = E.default_opts()
+    B.set_reads([r.seq for r in reads], vps); B.align(opts)
+    B.set_knob("trace", 1)
+    B.get_seed(opts); a = B.seeds(); B.estimate_seq(opts); ea = B.estimates()
+    B.set_knob("scan_pairs", 1)
+    B.get_seed(opts); b = B.seeds(); B.estimate_seq(opts); eb = B.estimates()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(ea, eb):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert (a[0] == 50).all()
+    d, N = B.pdist(3)
+    B.set_knob("scan_pairs", 0); B.get_seed(opts)
+    d2, N2 = B.pdist(3)                                            # the scan's own row checked inside
+    assert np.array_equal(d, d2) and np.array_equal(N, N2)
+    B.close(); D.close()
+
+
 def test_streaming_sep_kernels(monkeypatch):
     """the one-wave-per-unit streaming estimate / place kernels (regions beyond 3,072 columns) and the per-site
     log() estimate kernel give the same placements as the table-driven workgroup kernels"""
