@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32
 	constexpr int T = HU_READ_TILE, M = 4;
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	static_assert(T == 16, "sixteen reads x sixteen dwords per quad = one dword per thread");
-	__shared__ __attribute__((aligned(16))) uint32_t rpl[T * 16];              /* the tile's planes of one quad */
+	__shared__ __attribute__((aligned(16))) uint32_t rpl2[2][T * 16];          /* the tile's planes of one quad, two quads in rotation: one barrier per quad */
 	__shared__ __attribute__((aligned(16))) uint32_t mb[4][T][64];             /* per wave: minimum over a lane's four nodes, read by read */
 	const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int node0 = blockIdx.y * (256 * M) + tid * M;                         /* four consecutive nodes per lane: a wave = one block of 256 */
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32
 		for(int m = 0; m < M; ++m) {
 			n0[m] = db.planes[((size_t) q * 3 + 0) * np + nl + m]; n1[m] = db.planes[((size_t) q * 3 + 1) * np + nl + m]; nv[m] = db.planes[((size_t) q * 3 + 2) * np + nl + m];
 		}
-		__syncthreads();                       /* the previous quad's planes have been read by every wave */
+		uint32_t* rpl = rpl2[qi & 1];          /* written while slower waves may still read the other one; whoever passes the barrier below has finished with both older quads */
 		rpl[tid] = mine;
 		__syncthreads();
 		/* a read's sixteen (node, word) steps are independent until the four population counts of a node meet in its counter: issued
