@@ -94,6 +94,7 @@ static void usage(const char* p) {
 		"            -i|--ignore  -N INT [50]  -d|--max-diff DBL  -H|--max-height DBL  -e|--err DBL [20]\n"
 		"            -m|--method unweighted|weighted  --ML  --prior uniform|height  --fmt fasta|fastq\n"
 		"            --fix-root-loglik  rank candidates by the intended root log-likelihood (the reference returns a constant)\n"
+		"            --no-csfm        build the seed index from the .ptu even when <DB>.csfm exists\n"
 		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
@@ -112,7 +113,7 @@ struct Slot { Packed f, r; std::vector<std::string> ids, descs; };
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
 	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0;
-	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false;
+	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false, noCsfm = false;
 	std::string alnFn;
 	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
 	hu_opts o; hu_default_opts(&o);
@@ -136,6 +137,7 @@ int main(int argc, char** argv) {
 		else if(a == "-m" || a == "--method") method = val();
 		else if(a == "--ML") o.only_ml = 1;
 		else if(a == "--fix-root-loglik") o.fix_root_loglik = 1;      /* not in the reference: SURVEY.md F4 / H2 */
+		else if(a == "--no-csfm") noCsfm = true;                      /* index from the .ptu's leaf rows even when <DB>.csfm exists */
 		else if(a == "--prior") prior = val();
 		else if(a == "--fmt") fmt = val();
 		else if(a == "-C" || a == "--chimera") checkChimera = true;
@@ -201,9 +203,14 @@ int main(int argc, char** argv) {
 	CHK(hu_db_get_tree(db, parent.data(), nullptr, seq.data(), nullptr));
 	CHK(hu_db_get_profile(db, nullptr, nullptr, nullptr, p2cs.data(), nullptr, nullptr));
 	hu_seed_index* ix = nullptr;
-	CHK(hu_seed_index_create(nNodes, L, parent.data(), seq.data(), K, p2cs.data(), seedLen, &ix));
+	/* the database's own index file when it is there (<DB>.csfm, as the reference requires it): seeds in the file's suffix order,
+	 * first hit = CSFMIndex::locateFirst; else the same index from the leaf rows of the .ptu */
+	bool fromCsfm = false;
+	if(!noCsfm) { FILE* t = fopen((pos[0] + ".csfm").c_str(), "rb"); if(t) { fclose(t); fromCsfm = true; } }
+	if(fromCsfm) CHK(hu_seed_index_load_csfm((pos[0] + ".csfm").c_str(), K, p2cs.data(), seedLen, &ix));
+	else CHK(hu_seed_index_create(nNodes, L, parent.data(), seq.data(), K, p2cs.data(), seedLen, &ix));
 	{ std::vector<int8_t>().swap(seq); }
-	if(verbose) { int64_t np = 0; const int64_t by = hu_seed_index_bytes(ix, &np); std::cerr << "seed index built: " << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers at " << np << " positions, " << by / 1e6 << " MB" << std::endl; }
+	if(verbose) { int64_t np = 0; const int64_t by = hu_seed_index_bytes(ix, &np); std::cerr << (fromCsfm ? "seed index read from the .csfm: " : "seed index built: ") << hu_seed_index_size(ix) << " distinct " << seedLen << "-mers at " << np << " positions, " << by / 1e6 << " MB" << std::endl; }
 	hu_batch* gb = nullptr;
 	CHK(hu_batch_create(db, std::min(batch, std::max(nTest, 1)), &gb));       /* strand detection only */
 

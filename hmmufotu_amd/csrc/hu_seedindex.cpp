@@ -20,6 +20,8 @@
 // 1.4 x 10^8 residues of a gg_97-scale MSA (the hash table this replaces held ~5 GB).
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <cstdio>
 #include <thread>
 #include <cstring>
 #include <string>
@@ -57,6 +59,19 @@ static inline uint64_t window32(const std::vector<uint64_t>& text, uint64_t p) {
 	return s ? hi | (text[w + 1] >> (64 - s)) : hi;
 }
 static inline uint64_t keep_top(uint64_t v, int nsym) { return nsym >= 32 ? v : nsym <= 0 ? 0 : v & ~((~0ull) >> (2 * nsym)); }
+
+/* directory over the first 12 bases and the number of distinct seeds, from `sa` in its final order */
+static void finish_index(hu_seed_index* ix) {
+	ix->dir.assign(((size_t) 1 << (2 * HU_SX_DIRK)) + 1, 0);
+	uint64_t lastK = ~0ull;
+	ix->distinct = 0;
+	for(size_t i = 0; i < ix->sa.size(); ++i) {
+		const uint64_t km = keep_top(window32(ix->text, ix->sa[i]), ix->seedLen);
+		ix->dir[(size_t)(km >> (64 - 2 * HU_SX_DIRK)) + 1]++;
+		if(km != lastK || i == 0) { ix->distinct++; lastK = km; }
+	}
+	for(size_t i = 1; i < ix->dir.size(); ++i) ix->dir[i] += ix->dir[i - 1];
+}
 
 extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
 		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) {
@@ -120,19 +135,242 @@ extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32
 		for(auto& t : th) t.join();
 	}
 	ix->sa.resize(ents.size());
-	ix->dir.assign(((size_t) 1 << (2 * HU_SX_DIRK)) + 1, 0);
-	const uint64_t kmask = ~((~0ull) >> (2 * seed_len));
-	uint64_t lastK = ~0ull;
-	for(size_t i = 0; i < ents.size(); ++i) {
-		ix->sa[i] = ents[i].pos;
-		ix->dir[(size_t)(ents[i].key >> (64 - 2 * HU_SX_DIRK)) + 1]++;
-		const uint64_t km = ents[i].key & kmask;
-		if(km != lastK || i == 0) { ix->distinct++; lastK = km; }
-	}
-	for(size_t i = 1; i < ix->dir.size(); ++i) ix->dir[i] += ix->dir[i - 1];
+	for(size_t i = 0; i < ents.size(); ++i) ix->sa[i] = ents[i].pos;
+	finish_index(ix);
 	*out = ix;
 	return HU_OK;
 }
+/* ------------------------------------------------------------------------------------------
+ * Reading the reference's own index file, <DB>.csfm (CSFMIndex::save / load, src/CSFMIndex.cpp:176-230):
+ *     string alphabet name (size_t length + bytes) | char gapCh | uint16 csLen | int32 concatLen | int32 C[256] |
+ *     string csSeq | double csIdentity[csLen + 1] | uint16 concat2CS[concatLen + 1] | uint32 saSampled[concatLen / 4] |
+ *     saIdx: a libcds BitSequenceRRR | bwt: a libcds WaveletTreeNoptrs over BitSequenceRRR levels with a MapperNone
+ * libcds (vendored by the reference under src/libcds, v1.0.x) serialises
+ *     BitSequenceRRR     uint32 2 | size_t length | size_t ones | uint32 C_len, C_field_bits, O_len, O_bits_len, sample_rate |
+ *                        uint32 C[ceil(C_len * C_field_bits / 32)] | uint32 O[O_len]               (BitSequenceRRR.cpp:379-402)
+ *                        blocks of 15 bits: C = popcount of a block, O = its index among the 15-bit words of that popcount in
+ *                        the order TableOffsetRRR.cpp:101-134 generates them (positions ascending, lexicographic), in
+ *                        bits(binomial(15, c) - 1) bits
+ *     WaveletTreeNoptrs  uint32 3 | size_t n | size_t length | uint32 max_v | uint32 height | uint32 2 (MapperNone) |
+ *                        height x BitSequenceRRR | uint32 OCC[max_v + 2]                            (WaveletTreeNoptrs.cpp:244-256)
+ *                        level l holds bit (height - 1 - l) of the symbols, stably grouped by their higher bits (OCC = first
+ *                        position of every symbol's group); n >= length: one padding symbol per value that does not occur.
+ * The bit sequences are decoded to plain words once, the BWT symbols read off the wavelet tree, and every sequence is walked backwards
+ * from the suffix that starts at its separator (rows 1 .. numSeq of the suffix array: the suffixes that start with the separator) by
+ * LF steps on BASE symbols only — the LF step on the separator symbol is not a bijection in this index (separators and the
+ * terminator share the symbol 0 and the BWT writes 0 for the row of text position 0), and is never needed.  The walk passes a
+ * sampled suffix-array entry (every fourth text position) which anchors the sequence in the text; concat2CS gives the CS columns.
+ * The rows met on the way are the ranks of the sequence's suffixes in the reference's own suffix order, so the seeds are indexed in
+ * exactly that order and "the first hit" here is locateFirst's (src/CSFMIndex.cpp:92-119).
+ * Tested against files written by the real libcds + libdivsufsort (oracle/csfm_ref.cpp, tests/test_csfm.py). */
+namespace {
+struct PlainBits {
+	std::vector<uint64_t> w; std::vector<uint32_t> blk; size_t n = 0;      /* blk[b] = ones before word 8 b */
+	bool get(size_t i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+	size_t rank1(size_t i) const { /* ones in [0, i] */
+		const size_t wi = i >> 6; size_t r = blk[wi >> 3];
+		for(size_t k = wi & ~(size_t) 7; k < wi; ++k) r += (size_t) __builtin_popcountll(w[k]);
+		return r + (size_t) __builtin_popcountll(w[wi] & (~0ull >> (63 - (i & 63))));
+	}
+	void index() {
+		blk.assign(w.size() / 8 + 2, 0);
+		uint32_t run = 0;
+		for(size_t k = 0; k < w.size(); ++k) { if((k & 7) == 0) blk[k >> 3] = run; run += (uint32_t) __builtin_popcountll(w[k]); }
+		blk[(w.size() + 7) >> 3] = run;
+	}
+};
+struct Reader {
+	FILE* f; bool ok = true;
+	template<class T> T val() { T v{}; if(fread(&v, sizeof(T), 1, f) != 1) ok = false; return v; }
+	template<class T> bool arr(std::vector<T>& v, size_t n) { v.resize(n); if(n && fread(v.data(), sizeof(T), n, f) != n) ok = false; return ok; }
+	bool str(std::string& s) { const uint64_t n = val<uint64_t>(); if(!ok || n > (1u << 28)) return ok = false; s.resize((size_t) n); if(n && fread(&s[0], 1, (size_t) n, f) != n) ok = false; return ok; }
+};
+inline uint32_t bits_of(uint32_t n) { uint32_t b = 0; while(n) { ++b; n >>= 1; } return b; }
+inline uint32_t field(const std::vector<uint32_t>& A, size_t ini, uint32_t len) { /* len bits starting at bit ini (libcds get_var_field) */
+	if(len == 0) return 0;
+	const size_t i = ini >> 5; const uint32_t j = (uint32_t)(ini & 31);
+	uint64_t v = A[i]; if(j + len > 32) v |= (uint64_t) A[i + 1] << 32;
+	return (uint32_t)((v >> j) & ((1ull << len) - 1));
+}
+/* the 15-bit words of every popcount in libcds's order + the width of an offset */
+struct RrrTables {
+	std::vector<uint16_t> word[16]; uint32_t width[16];
+	RrrTables() {
+		for(int c = 0; c <= 15; ++c) { gen(c, 0, 0, 0); width[c] = bits_of((uint32_t) word[c].size() - 1); }
+	}
+	void gen(int cls, int placed, int from, uint32_t made) {
+		if(placed == cls) { word[cls].push_back((uint16_t) made); return; }
+		for(int i = from; i < 15; ++i) gen(cls, placed + 1, i + 1, made | (1u << i));
+	}
+};
+bool read_rrr(Reader& R, PlainBits& out) {
+	static const RrrTables T;
+	if(R.val<uint32_t>() != 2u) return false;                 /* RRR02_HDR */
+	const uint64_t length = R.val<uint64_t>(), ones = R.val<uint64_t>();
+	const uint32_t C_len = R.val<uint32_t>(), C_bits = R.val<uint32_t>(), O_len = R.val<uint32_t>(), O_bits_len = R.val<uint32_t>();
+	(void) R.val<uint32_t>();                                  /* sample_rate: libcds rebuilds its samples on load, we keep plain words */
+	if(!R.ok || C_bits != 4 || length > (1ull << 33) || (uint64_t) C_len != (length + 14) / 15) return false;
+	std::vector<uint32_t> C, O;
+	if(!R.arr(C, ((size_t) C_len * C_bits + 31) / 32) || !R.arr(O, O_len)) return false;
+	C.push_back(0); O.push_back(0); O.push_back(0);
+	out.n = (size_t) length; out.w.assign(out.n / 64 + 2, 0);
+	size_t pos = 0, cnt = 0;
+	for(size_t k = 0; k < C_len; ++k) {
+		const uint32_t c = field(C, k * 4, 4);
+		if(c > 15 || pos + T.width[c] > (size_t) O_bits_len) return false;
+		const uint32_t off = field(O, pos, T.width[c]); pos += T.width[c];
+		if(off >= T.word[c].size()) return false;
+		const uint64_t v = T.word[c][off]; cnt += c;
+		const size_t b = k * 15;
+		out.w[b >> 6] |= v << (b & 63);
+		if((b & 63) > 49) out.w[(b >> 6) + 1] |= v >> (64 - (b & 63));
+	}
+	if(cnt != ones) return false;
+	out.index();
+	return true;
+}
+}
+
+extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) {
+	if(!path || !p2cs || !out || seed_len < HU_SX_DIRK || seed_len > 31) { hu_set_error("hu_seed_index_load_csfm: bad argument (seed length must be in %d..31)", HU_SX_DIRK); return HU_ERR_ARG; }
+	FILE* f = fopen(path, "rb");
+	if(!f) { hu_set_error("cannot open %s", path); return HU_ERR_IO; }
+	Reader R{f};
+	auto fail = [&](const char* what) { fclose(f); hu_set_error("%s: %s", path, what); return HU_ERR_IO; };
+	std::string abc, csSeq;
+	if(!R.str(abc)) return fail("no alphabet name");
+	if(abc != "DNA") return fail("not a DNA index");
+	(void) R.val<char>();
+	const uint16_t csLen = R.val<uint16_t>();
+	const int32_t concatLen = R.val<int32_t>();
+	std::vector<int32_t> Cc; std::vector<double> ident; std::vector<uint16_t> c2cs; std::vector<uint32_t> saS;
+	if(!R.ok || concatLen < 1 || !R.arr(Cc, 256) || !R.str(csSeq) || csSeq.size() != (size_t) csLen + 1 || !R.arr(ident, (size_t) csLen + 1)
+		|| !R.arr(c2cs, (size_t) concatLen + 1) || !R.arr(saS, (size_t) concatLen / 4)) return fail("truncated header");
+	const size_t N = (size_t) concatLen + 1;
+	PlainBits saIdx;
+	if(!read_rrr(R, saIdx) || saIdx.n != N) return fail("bad sampled-suffix-array bitmap (BitSequenceRRR)");
+	if(R.val<uint32_t>() != 3u) return fail("no WaveletTreeNoptrs");
+	const uint64_t wn = R.val<uint64_t>(), wlen = R.val<uint64_t>();
+	const uint32_t maxv = R.val<uint32_t>(), height = R.val<uint32_t>();
+	if(!R.ok || wlen != N || wn < wlen || maxv > 255 || height != bits_of(maxv) || height < 1 || R.val<uint32_t>() != 2u) return fail("bad wavelet-tree header");
+	std::vector<PlainBits> lev(height);
+	for(uint32_t l = 0; l < height; ++l) if(!read_rrr(R, lev[l]) || lev[l].n != wn) return fail("bad wavelet-tree level (BitSequenceRRR)");
+	std::vector<uint32_t> OCC;
+	if(!R.arr(OCC, (size_t) maxv + 2)) return fail("truncated wavelet tree");
+	fclose(f);
+	unsigned nt = std::thread::hardware_concurrency(); if(nt > 16) nt = 16; if(nt < 1) nt = 1;
+	auto par = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) {
+		std::atomic<size_t> next{0};
+		auto work = [&] { for(;;) { const size_t a = next.fetch_add(grain); if(a >= n) break; body(a, std::min(n, a + grain)); } };
+		std::vector<std::thread> th;
+		for(unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for(auto& t : th) t.join();
+	};
+	/* the BWT symbols (WaveletTreeNoptrs::access, WaveletTreeNoptrs.cpp:301-323) */
+	std::vector<uint8_t> L(N);
+	par(N, 1 << 16, [&](size_t a, size_t e) {
+		for(size_t i = a; i < e; ++i) {
+			uint32_t ret = 0; size_t pos = i, start = 0;
+			for(uint32_t l = 0; l < height; ++l) {
+				const size_t before = start > 0 ? lev[l].rank1(start - 1) : 0;
+				const size_t r1 = lev[l].rank1(pos);
+				if(lev[l].get(pos)) { ret |= 1u << (height - l - 1); start = OCC[ret]; pos = r1 - 1 - before + start; }
+				else pos = (pos + 1 - r1) - 1 + before;
+			}
+			L[i] = (uint8_t) ret;
+		}
+	});
+	for(size_t i = 0; i < N; ++i) if(L[i] > 4) { hu_set_error("%s: symbol %d in the BWT", path, (int) L[i]); return HU_ERR_IO; }
+	/* occurrences of the four bases before every 64th row */
+	const size_t nb = N / 64 + 2;
+	std::vector<uint32_t> occ(nb * 4, 0);
+	{ uint32_t run[5] = {0, 0, 0, 0, 0}; for(size_t i = 0; i < N; ++i) { if((i & 63) == 0) for(int c = 1; c <= 4; ++c) occ[(i >> 6) * 4 + c - 1] = run[c]; run[L[i]]++; }
+	  for(size_t b = (N + 63) / 64; b < nb; ++b) for(int c = 1; c <= 4; ++c) occ[b * 4 + c - 1] = run[c]; }
+	auto rankc = [&](int c, size_t i) { /* occurrences of base c in rows [0, i] */
+		size_t r = occ[(i >> 6) * 4 + c - 1];
+		for(size_t k = i & ~(size_t) 63; k <= i; ++k) r += L[k] == c;
+		return r;
+	};
+	const size_t nSeq = (size_t) Cc[1] - 1;              /* rows 0 .. C[1]-1 start with the symbol 0: the terminator + one separator per sequence */
+	if(Cc[0] != 0 || Cc[1] < 2 || (size_t) Cc[5] != N) return fail("inconsistent symbol counts");
+	std::vector<uint32_t> rowAt(N, 0xffffffffu);          /* rank of the suffix at every text position that holds a base */
+	std::vector<int64_t> sepOf(nSeq + 1, -1);             /* text position of the separator whose suffix is row j */
+	std::atomic<int> bad{0};
+	par(nSeq, 64, [&](size_t a, size_t e) {
+		std::vector<uint32_t> rows;
+		for(size_t j = a + 1; j <= e; ++j) {
+			rows.clear();
+			size_t row = j; int64_t s = -1;
+			auto sampled = [&](size_t rw, size_t t) { if(s < 0 && saIdx.get(rw)) { const size_t q = saIdx.rank1(rw) - 1; if(q < saS.size()) s = (int64_t) saS[q] + (int64_t) t; } };
+			sampled(row, 0);
+			for(;;) {
+				const int c = L[row];
+				if(c == 0) break;
+				row = (size_t) Cc[c] + rankc(c, row) - 1;
+				rows.push_back((uint32_t) row);
+				sampled(row, rows.size());
+				if(rows.size() > N) { bad = 1; break; }
+			}
+			if(s < 0) continue;                      /* fewer than four bases and no sample: cannot hold a seed anyway */
+			const size_t len = rows.size();
+			if(s >= (int64_t) N || (int64_t) len > s || c2cs[(size_t) s] != 0 || (s - (int64_t) len > 0 && c2cs[(size_t) s - len - 1] != 0)) { bad = 1; continue; }
+			sepOf[j] = s;
+			for(size_t t = 0; t < len; ++t) { if(c2cs[(size_t) s - 1 - t] == 0) bad = 1; rowAt[(size_t) s - 1 - t] = rows[t]; }
+		}
+	});
+	if(bad) { hu_set_error("%s: the BWT, the sampled suffix array and concat2CS do not describe one text", path); return HU_ERR_IO; }
+	/* the sequences in text order */
+	hu_seed_index* ix = new hu_seed_index;
+	ix->seedLen = seed_len; ix->csLen = csLen; ix->K = K;
+	ix->cs2p.assign((size_t) csLen + 2, 0);
+	for(int k = 1; k <= K; ++k) if(p2cs[k] >= 1 && p2cs[k] <= csLen) ix->cs2p[p2cs[k]] = k;
+	for(int i = p2cs[K] + 1; i <= csLen; ++i) ix->cs2p[i] = K;
+	struct Ent { uint32_t row, pos; };
+	std::vector<Ent> ents;
+	size_t at = 0;
+	ix->text.assign((size_t)(N / 32 + 3), 0);
+	ix->cols.reserve(N);
+	for(size_t p = 0; p < N; ) {
+		if(c2cs[p] == 0) { ++p; continue; }
+		size_t e = p; while(e < N && c2cs[e] != 0) ++e;                /* [p, e) = one sequence; e = its separator */
+		const bool placed = rowAt[p] != 0xffffffffu;                   /* a sequence the walk could not anchor (< 4 bases) is left out */
+		if(placed) {
+			const size_t b0 = at;
+			for(size_t q = p; q < e; ++q) {
+				if(rowAt[q] == 0xffffffffu) { delete ix; hu_set_error("%s: a sequence is only partly covered by the BWT walk", path); return HU_ERR_IO; }
+				ix->cols.push_back((uint16_t)(c2cs[q] - 1));
+				++at;
+			}
+			for(size_t q = p; q + (size_t) seed_len <= e; ++q) ents.push_back(Ent{rowAt[q], (uint32_t)(b0 + (q - p))});
+			ix->seqEnd.push_back((uint32_t) at);
+		}
+		p = e;
+	}
+	/* the residues: the base at text position q is the BWT symbol of the row of position q + 1 (its suffix's predecessor) — for the
+	 * last base of a sequence that is the row of its separator's suffix */
+	{
+		std::vector<uint8_t> base(N, 0);
+		for(size_t j = 1; j <= nSeq; ++j) if(sepOf[j] > 0) base[(size_t) sepOf[j] - 1] = L[j];
+		for(size_t q = 0; q + 1 < N; ++q) if(rowAt[q + 1] != 0xffffffffu && c2cs[q] != 0) base[q] = L[rowAt[q + 1]];
+		size_t a2 = 0;
+		for(size_t p = 0; p < N; ++p) {
+			if(c2cs[p] == 0 || rowAt[p] == 0xffffffffu) continue;
+			if(base[p] < 1 || base[p] > 4) { delete ix; hu_set_error("%s: no base at text position %zu", path, p); return HU_ERR_IO; }
+			ix->text[a2 >> 5] |= (uint64_t)(base[p] - 1) << (62 - 2 * (int)(a2 & 31));
+			++a2;
+		}
+		if(a2 != at) { delete ix; hu_set_error("%s: internal: residue count", path); return HU_ERR_IO; }
+	}
+	ix->nRes = (int64_t) at;
+	std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.row < y.row; });
+	ix->sa.resize(ents.size());
+	for(size_t i = 0; i < ents.size(); ++i) ix->sa[i] = ents[i].pos;
+	finish_index(ix);
+	*out = ix;
+	return HU_OK;
+}
+
 extern "C" void hu_seed_index_destroy(hu_seed_index* ix) { delete ix; }
 /* number of distinct seed_len-mers indexed */
 extern "C" int64_t hu_seed_index_size(const hu_seed_index* ix) { return ix ? ix->distinct : 0; }
@@ -200,6 +438,32 @@ extern "C" int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char
 		++n;
 	}
 	return n;
+}
+
+/* CSFMIndex::locateFirst for one seed of the index's length (src/CSFMIndex.cpp:92-119): 1-based CS columns of its first and last
+ * base at the first hit (0, 0 without a hit), and the number of hits (CSFMIndex::count, :43-64).  Returns 1 on a hit. */
+extern "C" int hu_seed_index_locate_first(const hu_seed_index* ix, const char* kmer, int32_t* cs_start, int32_t* cs_end, int64_t* count) {
+	if(cs_start) *cs_start = 0;
+	if(cs_end) *cs_end = 0;
+	if(count) *count = 0;
+	if(!ix || !kmer) return 0;
+	const int k = ix->seedLen;
+	uint64_t key = 0;
+	for(int i = 0; i < k; ++i) { const int8_t c = sym_code(kmer[i]); if(c < 0) return 0; key |= (uint64_t) c << (62 - 2 * i); }
+	const size_t b = (size_t)(key >> (64 - 2 * HU_SX_DIRK));
+	int64_t n = 0; size_t first = 0;
+	for(size_t i = ix->dir[b]; i < ix->dir[b + 1]; ++i) {
+		const uint64_t km = keep_top(window32(ix->text, ix->sa[i]), k);
+		if(km < key) continue;
+		if(km > key) break;
+		if(n++ == 0) first = i;
+	}
+	if(count) *count = n;
+	if(!n) return 0;
+	const uint16_t* cols = &ix->cols[ix->sa[first]];
+	if(cs_start) *cs_start = cols[0] + 1;
+	if(cs_end) *cs_end = cols[k - 1] + 1;
+	return 1;
 }
 
 /* the two seed scans of alignSeq (src/HmmUFOtu_main.cpp:50-84) for n reads; vpaths [n][2][6] */

@@ -216,13 +216,17 @@ def write_ptu(path, parent, blen, seq, up, down, height, model: ModelDesc, names
 class SeedIndex:
     """Host k-mer index standing in for the CSFM lookup of alignSeq (hu_seed_index_*)."""
 
-    def __init__(self, parent, seq, hmm, seed_len=20):
-        self.parent = np.ascontiguousarray(parent, np.int32); self.seq = np.ascontiguousarray(seq, np.int8)
+    def __init__(self, parent, seq, hmm, seed_len=20, csfm=None):
+        """from the leaf rows of a tree (parent, seq), or — csfm=<path> — from the reference's own <DB>.csfm (hu_seed_index_load_csfm)"""
         self.p2cs = np.ascontiguousarray(hmm.p2cs, np.int32)
-        n, L = self.seq.shape
         self.h = C.c_void_p()
-        _chk(load_library().hu_seed_index_create(C.c_int32(n), C.c_int32(L), _p(self.parent, C.c_int32), _p(self.seq, C.c_int8),
-                                                 C.c_int32(int(hmm.K)), _p(self.p2cs, C.c_int32), C.c_int32(seed_len), C.byref(self.h)))
+        if csfm is not None:
+            _chk(load_library().hu_seed_index_load_csfm(str(csfm).encode(), C.c_int32(int(hmm.K)), _p(self.p2cs, C.c_int32), C.c_int32(seed_len), C.byref(self.h)))
+        else:
+            self.parent = np.ascontiguousarray(parent, np.int32); self.seq = np.ascontiguousarray(seq, np.int8)
+            n, L = self.seq.shape
+            _chk(load_library().hu_seed_index_create(C.c_int32(n), C.c_int32(L), _p(self.parent, C.c_int32), _p(self.seq, C.c_int8),
+                                                     C.c_int32(int(hmm.K)), _p(self.p2cs, C.c_int32), C.c_int32(seed_len), C.byref(self.h)))
         lib = load_library(); lib.hu_seed_index_size.restype = C.c_int64; lib.hu_seed_index_bytes.restype = C.c_int64
         lib.hu_seed_index_occurrences.restype = C.c_int64
         self.size = int(lib.hu_seed_index_size(self.h))
@@ -236,6 +240,12 @@ class SeedIndex:
         n = int(load_library().hu_seed_index_occurrences(self.h, kmer.encode(), _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32), C.c_int64(cap)))
         m = min(n, cap)
         return n, a[:m], b[:m], c[:m]
+
+    def locate_first(self, kmer: str):
+        """CSFMIndex::locateFirst + count: (csStart, csEnd) 1-based of the first hit (0, 0 = none), number of hits"""
+        a = C.c_int32(0); b = C.c_int32(0); n = C.c_int64(0)
+        load_library().hu_seed_index_locate_first(self.h, kmer.encode(), C.byref(a), C.byref(b), C.byref(n))
+        return int(a.value), int(b.value), int(n.value)
 
     def lookup(self, reads, seed_region=50, align_mode=0):
         n = len(reads)

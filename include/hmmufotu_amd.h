@@ -207,11 +207,18 @@ int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* c
 typedef struct hu_seed_index hu_seed_index;
 int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
 		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out);
+/* The same index from the reference's own <DB>.csfm (CSFMIndex::load, src/CSFMIndex.cpp:200-230: libcds BitSequenceRRR +
+ * WaveletTreeNoptrs): the sequences are recovered from the BWT, the sampled suffix array and concat2CS, and the seeds are kept in
+ * the file's own suffix order, so the first hit of a seed is CSFMIndex::locateFirst's (src/CSFMIndex.cpp:92-119).
+ * p2cs / K: the profile's map (hu_db_info / the .hmm), as for hu_seed_index_create. */
+int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out);
 void hu_seed_index_destroy(hu_seed_index* ix);
 int64_t hu_seed_index_size(const hu_seed_index* ix);          /* distinct seed_len-mers */
 int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions /* indexed k-mer starts; may be NULL */);   /* resident bytes */
 /* every occurrence of one seed in index (suffix) order — the range locateOne draws from: sequence number (leaves in node-id
  * order), residue offset inside it, 0-based CS column of its first base.  Returns the count; at most cap entries are written */
+/* CSFMIndex::locateFirst + count for one seed of the index's length: 1-based CS columns of the first hit's first and last base */
+int hu_seed_index_locate_first(const hu_seed_index* ix, const char* kmer, int32_t* cs_start, int32_t* cs_end, int64_t* count);
 int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap);
 /* the 5' and (GLOBAL mode) 3' seed scans for n reads -> vpaths [n][2][6] for hu_batch_set_reads */
 int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
