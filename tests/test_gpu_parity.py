@@ -626,6 +626,21 @@ def test_cli_end_to_end(tmp_path):
     assert outm.returncode == 0 and "2 device(s) x 2 batches in flight" in outm.stderr, outm.stderr
     assert [l for l in outm.stdout.split("\n") if l and not l.startswith("#")][1:] == want
     assert subprocess.run([cli, pre, fa, "--gpus", "9"], capture_output=True).returncode != 0          # more devices than the box has
+    # with the database's own <DB>.csfm beside it (written here by the reference's libcds + libdivsufsort, oracle/_ref/csfm_ref, from the
+    # leaf rows): the CLI reads it instead of rebuilding the index; these reads come from single leaves, so the assignments are the same
+    ref_writer = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "csfm_ref")
+    if os.path.exists(ref_writer):
+        msa = str(tmp_path / "msa.fasta")
+        with open(msa, "w") as f:
+            for u in leaves:
+                f.write(">n%d\n%s\n" % (u, "".join("ACGT"[x] if x >= 0 else "-" for x in db.seq[u])))
+        assert subprocess.run([ref_writer, msa, pre + ".csfm"], capture_output=True).returncode == 0
+        outc = subprocess.run([cli, pre, fa, "-s", "1", "-v"], capture_output=True, text=True, timeout=300)
+        assert outc.returncode == 0 and "seed index read from the .csfm" in outc.stderr, outc.stderr
+        assert [l for l in outc.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+        outn = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--no-csfm"], capture_output=True, text=True, timeout=300)
+        assert outn.returncode == 0 and "seed index built" in outn.stderr
+        os.remove(pre + ".csfm")
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
     import gzip
     fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")
