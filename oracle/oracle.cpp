@@ -1,5 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C ABI over the CPU restatement (ctypes-friendly).
-// See oracle_models.h for the scope note.  PARITY UNPINNED.
+// See oracle_models.h for the scope note.  PARITY UNPINNED for everything floating-point; the integer rows a8
+// (DigitalSeq encoding) and a9 (SeqUtils::pDist) are checked against the reference's own code where it compiles without Eigen3 /
+// Boost (oracle/_ref/libref_seq.so, tests/test_ref_seq.py), row f2's file format against its vendored libcds (oracle/csfm_ref.cpp).
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
