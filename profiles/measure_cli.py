@@ -39,7 +39,7 @@ flights = os.environ.get("HU_CLI_INFLIGHT", "6").split(",")          # several v
 runs = [("shm_file", ["-o", os.path.join(tmp, "out.tsv")], flights[0])] + [("devnull" if f == flights[0] else "devnull_inflight%s" % f, ["-o", "/dev/null"], f) for f in flights]
 for name, extra, fl in runs:
     t1 = time.time()
-    p = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--inflight", fl] + extra, capture_output=True, text=True)
+    p = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--inflight", fl] + extra + os.environ.get("HU_CLI_EXTRA", "").split(), capture_output=True, text=True)
     wall = time.time() - t1
     line = [l for l in p.stderr.splitlines() if l.startswith("read loop:")]
     log(name, "rc", p.returncode, "wall %.1fs" % wall, line)
