@@ -363,9 +363,13 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 		if(a2 != at) { delete ix; hu_set_error("%s: internal: residue count", path); return HU_ERR_IO; }
 	}
 	ix->nRes = (int64_t) at;
-	std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.row < y.row; });
-	ix->sa.resize(ents.size());
-	for(size_t i = 0; i < ents.size(); ++i) ix->sa[i] = ents[i].pos;
+	{ /* the rows are distinct ranks in [0, N): order by them with one scatter and one sweep */
+		std::vector<uint32_t> byRow(N, 0xffffffffu);
+		for(const Ent& e : ents) byRow[e.row] = e.pos;
+		ix->sa.clear(); ix->sa.reserve(ents.size());
+		for(size_t r = 0; r < N; ++r) if(byRow[r] != 0xffffffffu) ix->sa.push_back(byRow[r]);
+		if(ix->sa.size() != ents.size()) { delete ix; hu_set_error("%s: two suffixes share a rank", path); return HU_ERR_IO; }
+	}
 	finish_index(ix);
 	*out = ix;
 	return HU_OK;
