@@ -42,6 +42,10 @@ struct HuDbDev {
 	 * position is three 8-byte words (in `planes` it is 3 KB: a whole quad's lines for one bit per node) */
 	const unsigned long long* colPlanes;
 	int32_t QM, pad0;
+	/* per node: first and last scan position that holds a base, in the profile block [0, QM * 128) and in the non-profile block
+	 * (x = first1 | last1 << 16, y = first2 | last2 << 16; first > last: none there).  A node whose two intervals miss a read's two
+	 * (HuReadPlanes::rspan) shares no valid position with it: N = 0 exactly — reference sequences that do not cover the amplicon. */
+	const uint2* nodeCover;
 	const int32_t* parent;
 	const double* blen;
 	const double* height;

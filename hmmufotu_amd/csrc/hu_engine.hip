@@ -272,6 +272,14 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 			if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("transposing the non-profile planes failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
 			d.colPlanes = cp;
 		}
+		{
+			uint2* cv = nullptr;
+			if((rc = dev_alloc(db, &cv, np)) != HU_OK) return fail(rc);
+			k_node_cover<<<(unsigned)(np / 256), 256>>>(d, cv);
+			hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+			if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("node coverage intervals failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
+			d.nodeCover = cv;
+		}
 	}
 	{
 		int32_t* p; double* q;
@@ -756,7 +764,7 @@ struct hu_batch {
 	DBuf<int32_t> dStart, dEnd, dSeedCnt, dSeedId, dGiven, dPermCnt;
 	DBuf<uint16_t> dPerm;
 	PinnedVec<int32_t> hPermCnt;
-	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin;
+	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin, dRSpan, dTileSpan;     /* dRSpan / dTileSpan: uint2 per read / tile */
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<int32_t> dIns, dTileIns;
@@ -966,6 +974,8 @@ static int ensure_read_buffers(hu_batch* b) {
 	if((rc = b->dRq.ensure(std::max<size_t>(n, 1) * ((d.WQ + 31) / 32))) != HU_OK) return rc;
 	if((rc = b->dIns.ensure(std::max<size_t>(n, 1) * (HU_MAX_INS + 1))) != HU_OK) return rc;
 	if((rc = b->dTileIns.ensure(std::max<size_t>(tiles, 1) * (HU_READ_TILE * HU_MAX_INS + 1))) != HU_OK) return rc;
+	if((rc = b->dRSpan.ensure(std::max<size_t>(n, 1) * 2)) != HU_OK) return rc;
+	if((rc = b->dTileSpan.ensure(std::max<size_t>(tiles, 1) * 2)) != HU_OK) return rc;
 	return HU_OK;
 }
 
@@ -1023,8 +1033,8 @@ static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKi
 		const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
 		HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
 		if((rc = tile_reads(b, nullptr)) != HU_OK) return rc;
-		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p);
-		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p);
+		k_planes_from_codes<<<n, 64, 0, b->stream>>>(d, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p, (uint2*) b->dRSpan.p);
+		k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p, (const uint2*) b->dRSpan.p, (uint2*) b->dTileSpan.p);
 		HIPCHK(hipGetLastError());
 	}
 	b->state = ST_ALIGNED;
@@ -1160,8 +1170,8 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			const int tiles = (b->n + HU_READ_TILE - 1) / HU_READ_TILE;
 			HIPCHK(hipMemsetAsync(b->dRp.p, 0, (size_t) tiles * d.WQ * HU_READ_TILE * 16 * 4, b->stream));
 			if((rc = tile_reads(b, b->dAlns.p)) != HU_OK) return rc;
-			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p);
-			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p);
+			k_encode_rows<<<b->n, 64, 0, b->stream>>>(d, b->dRows.p, b->dAlns.p, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p, (uint2*) b->dRSpan.p);
+			k_tile_lists<<<tiles, 64, 0, b->stream>>>(d, b->n, b->dRq.p, b->dIns.p, b->dTileQ.p, b->dTileIns.p, b->dSlotRead.p, (const uint2*) b->dRSpan.p, (uint2*) b->dTileSpan.p);
 		}
 		HIPCHK(hipGetLastError());
 		b->hAlns.resize(b->nSeq);
@@ -1177,7 +1187,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	return HU_OK;
 }
 
-static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p}; }
+static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p, (const uint2*) b->dRSpan.p}; }
 
 extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	if(!b || !o) return HU_ERR_ARG;
@@ -1214,10 +1224,10 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		{
 			Timer t(b, HU_T_SEED_PDIST);
 			const dim3 grid4(tiles, (d.nNodesPad + 1023) / 1024);
-			if(dOnly && b->knob.dscan1 && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
-			else if(dOnly && b->knob.dscan1) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
-			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin);
-			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin);
+			if(dOnly && b->knob.dscan1 && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			else if(dOnly && b->knob.dscan1) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
 			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
 			else k_seed_pdist2<uint32_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
@@ -1234,10 +1244,11 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		}
 		HIPCHK(hipGetLastError());
 		if(stat) {
-			uint32_t h[4];
-			HIPCHK(hipMemcpyAsync(h, stat, 16, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
-			fprintf(stderr, "[hu] top-k after the distance-only scan: %u of %zu reads on the block path (%.1f blocks, %.1f candidates per read), %u by the exact recomputation\n",
-				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3]);
+			uint32_t h[16];
+			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
+			fprintf(stderr, "[hu] top-k after the distance-only scan: %u of %zu reads on the block path (%.1f blocks, %.1f candidates per read), %u by the exact recomputation; "
+				"ticks per read: start %.0f, selection + histogram %.0f, candidates %.0f, output %.0f\n",
+				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3], 16.0 * h[4] / n, 16.0 * h[5] / n, 16.0 * h[6] / n, 16.0 * h[7] / n);
 		}
 	}
 	b->seedCap = o->max_nseed;

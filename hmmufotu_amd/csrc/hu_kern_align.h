@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(HuDbDev db, int n, int ignor
  * sixteen reads of a tile cover the same few quads whatever order the reads came in (with uniform read starts a tile in read order
  * is the union of sixteen unrelated windows: 10.4 ms against 3.6 ms for the scan); quad bitmap and insert list stay indexed by read */
 __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restrict__ cd, int start, int end, int r, int slot, int lane,
-		uint32_t* __restrict__ rp, uint32_t* __restrict__ rq, int32_t* __restrict__ ins) {
+		uint32_t* __restrict__ rp, uint32_t* __restrict__ rq, int32_t* __restrict__ ins, uint2* __restrict__ rspan) {
 	const int tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
 	const int nw32 = (db.WQ + 31) / 32;
 	uint32_t* qbits = rq + (size_t) r * nw32;
@@ -1166,6 +1166,7 @@ __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restri
 	const bool dense = nIns > HU_MAX_INS;
 	uint32_t acc = 0;
 	int li = 0;
+	uint32_t f1 = 0xffffu, l1 = 0, f2 = 0xffffu, l2 = 0; bool any1 = false, any2 = false;   /* first / last position with a base: profile block, non-profile block */
 	for(int base = 0; base < db.WQ * 128; base += 64) {
 		const int c = db.posCol[base + lane];
 		const int8_t code = c >= 0 ? cd[c] : (int8_t) -2;
@@ -1173,6 +1174,11 @@ __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restri
 		const int q = base / 128, w = (base % 128) / 32;
 		const bool asList = q >= QM && !dense;
 		unsigned long long b0 = __ballot(in && (code & 1)), b1 = __ballot(in && (code & 2)), bv = __ballot(in);
+		if(lane == 0 && bv) {
+			const uint32_t lo = (uint32_t) base + (uint32_t)(__ffsll((long long) bv) - 1), hi = (uint32_t) base + 63u - (uint32_t) __clzll((long long) bv);
+			if(q < QM) { if(!any1) { f1 = lo; any1 = true; } l1 = hi; }
+			else { if(!any2) { f2 = lo; any2 = true; } l2 = hi; }
+		}
 		if(lane == 0) {
 			if(asList) {
 				unsigned long long m = bv;
@@ -1187,12 +1193,15 @@ __device__ inline void planes_of_codes(const HuDbDev& db, const int8_t* __restri
 			if((q & 31) == 31 && w == 2) { qbits[q >> 5] = acc; acc = 0; }
 		}
 	}
-	if(lane == 0) { if(db.WQ & 31) qbits[(db.WQ - 1) >> 5] = acc; il[0] = li; }
+	if(lane == 0) {
+		if(db.WQ & 31) qbits[(db.WQ - 1) >> 5] = acc; il[0] = li;
+		rspan[r] = make_uint2((any1 ? f1 : 0xffffu) | ((any1 ? l1 : 0u) << 16), (any2 ? f2 : 0xffffu) | ((any2 ? l2 : 0u) << 16));
+	}
 }
 
 __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __restrict__ rows, HuAlnDev* __restrict__ alns,
 		int8_t* __restrict__ codes, int32_t* __restrict__ rstart, int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
-		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot) {
+		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot, uint2* __restrict__ rspan) {
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const HuAlnDev a = alns[r];
 	const char* row = rows + (size_t) r * db.csLen;
@@ -1214,15 +1223,15 @@ __global__ __launch_bounds__(64) void k_encode_rows(HuDbDev db, const char* __re
 		cd[c] = c_sym_map[(int) ch & 127];
 	}
 	__syncthreads();
-	planes_of_codes(db, cd, start, end, r, readSlot[r], lane, rp, rq, ins);
+	planes_of_codes(db, cd, start, end, r, readSlot[r], lane, rp, rq, ins, rspan);
 }
 
 /* same, when the caller supplies DigitalSeq codes directly (hu_batch_set_aligned) */
 __global__ __launch_bounds__(64) void k_planes_from_codes(HuDbDev db, const int8_t* __restrict__ codes,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, uint32_t* __restrict__ rp, uint32_t* __restrict__ rq,
-		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot) {
+		int32_t* __restrict__ ins, const int32_t* __restrict__ readSlot, uint2* __restrict__ rspan) {
 	const int r = blockIdx.x, lane = threadIdx.x;
-	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, readSlot[r], lane, rp, rq, ins);
+	planes_of_codes(db, codes + (size_t) r * db.csLen, rstart[r], rend[r], r, readSlot[r], lane, rp, rq, ins, rspan);
 }
 
 /* sort keys of the tiling: first column of the region, reads without one last; vals = read index */
@@ -1246,7 +1255,7 @@ __global__ void k_tile_slots(int n, int nSlots, const uint32_t* __restrict__ sor
 /* per scan tile: the quads in which any of its reads has a base -> tileQ[tile][0] = count, [1..] = quads; and the
  * reads' insert lists as one list, tileIns[tile][0] = count, [1..] = read t << 24 | (scan position << 2 | base) */
 __global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint32_t* __restrict__ rq, const int32_t* __restrict__ ins,
-		int32_t* __restrict__ tileQ, int32_t* __restrict__ tileIns, const int32_t* __restrict__ slotRead) {
+		int32_t* __restrict__ tileQ, int32_t* __restrict__ tileIns, const int32_t* __restrict__ slotRead, const uint2* __restrict__ rspan, uint2* __restrict__ tileSpan) {
 	const int tile = blockIdx.x, lane = threadIdx.x;
 	const int nw32 = (db.WQ + 31) / 32;
 	int32_t* out = tileQ + (size_t) tile * (db.WQ + 1);
@@ -1268,5 +1277,15 @@ __global__ __launch_bounds__(64) void k_tile_lists(HuDbDev db, int n, const uint
 			for(int e = 0; e < il[0]; ++e) til[1 + ne++] = (t << 24) | il[1 + e];
 		}
 		til[0] = ne;
+		/* the union of the reads' position intervals, block by block */
+		uint32_t f1 = 0xffffu, l1 = 0, f2 = 0xffffu, l2 = 0; bool a1 = false, a2 = false;
+		for(int t = 0; t < HU_READ_TILE; ++t) {
+			const int r = slotRead[tile * HU_READ_TILE + t];
+			if(r < 0) continue;
+			const uint2 s2 = rspan[r];
+			if((s2.x & 0xffffu) <= (s2.x >> 16)) { f1 = a1 ? min(f1, s2.x & 0xffffu) : (s2.x & 0xffffu); l1 = a1 ? max(l1, s2.x >> 16) : (s2.x >> 16); a1 = true; }
+			if((s2.y & 0xffffu) <= (s2.y >> 16)) { f2 = a2 ? min(f2, s2.y & 0xffffu) : (s2.y & 0xffffu); l2 = a2 ? max(l2, s2.y >> 16) : (s2.y >> 16); a2 = true; }
+		}
+		tileSpan[tile] = make_uint2((a1 ? f1 : 0xffffu) | ((a1 ? l1 : 0u) << 16), (a2 ? f2 : 0xffffu) | ((a2 ? l2 : 0u) << 16));
 	}
 }

@@ -144,6 +144,29 @@ __global__ __launch_bounds__(64) void k_col_planes(HuDbDev db, unsigned long lon
 	}
 }
 
+/* one-time: HuDbDev::nodeCover from the validity plane */
+__global__ __launch_bounds__(256) void k_node_cover(HuDbDev db, uint2* __restrict__ cover) {
+	const int node = blockIdx.x * 256 + threadIdx.x;
+	if(node >= db.nNodesPad) return;
+	uint32_t f1 = 0xffffu, l1 = 0, f2 = 0xffffu, l2 = 0; bool any1 = false, any2 = false;
+	for(int q = 0; q < db.WQ; ++q) {
+		const uint4 v = db.planes[((size_t) q * 3 + 2) * db.nNodesPad + node];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		for(int k = 0; k < 4; ++k) {
+			if(!w[k]) continue;
+			const uint32_t lo = (uint32_t) q * 128 + k * 32 + (__ffs(w[k]) - 1), hi = (uint32_t) q * 128 + k * 32 + 31 - __clz(w[k]);
+			if(q < db.QM) { if(!any1) { f1 = lo; any1 = true; } l1 = hi; }
+			else { if(!any2) { f2 = lo; any2 = true; } l2 = hi; }
+		}
+	}
+	cover[node] = make_uint2((any1 ? f1 : 0xffffu) | ((any1 ? l1 : 0u) << 16), (any2 ? f2 : 0xffffu) | ((any2 ? l2 : 0u) << 16));
+}
+/* do two (first | last << 16) intervals share a position? (first > last: empty) */
+__device__ inline bool hu_span_meets(uint32_t a, uint32_t b) {
+	return (a & 0xffffu) <= (b >> 16) && (b & 0xffffu) <= (a >> 16) && (a & 0xffffu) <= (a >> 16) && (b & 0xffffu) <= (b >> 16);
+}
+__device__ inline bool hu_cover_meets(uint2 node, uint2 read) { return hu_span_meets(node.x, read.x) || hu_span_meets(node.y, read.y); }
+
 /* Measured and not kept (round 2): requesting the reads' planes one or two reads ahead with explicit s_load_dwordx8/x4 asm and
  * two / four SGPR sets in rotation (left to the compiler every request is followed at once by s_waitcnt lgkmcnt(0)): 4.89 ms against
  * 3.68 ms.  Scalar loads return out of order, so a wait is always "all of them" and a request is covered by one vector block only;
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
  * reads of 16 B per wave and quad against 2,560 cycles of arithmetic. */
 template<class DT>
 __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD) {
+		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD, const uint2* __restrict__ tileSpan) {
 	constexpr int T = HU_READ_TILE;
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
@@ -248,7 +271,8 @@ __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_
 #undef HU_DSTEP
 		}
 	}
-	const uint32_t skip = node < db.nNodes && node != db.root ? 0u : 0xffffffffu;
+	/* a node that shares no position with ANY read of the tile (N = 0 for all of them: d_scan = 0 without being near) stays out of the minima */
+	const uint32_t skip = node < db.nNodes && node != db.root && hu_cover_meets(db.nodeCover[node], tileSpan[tile]) ? 0u : 0xffffffffu;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_
 
 template<class DT>
 __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD) {
+		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD, const uint2* __restrict__ tileSpan) {
 	constexpr int T = HU_READ_TILE, M = 4;
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	static_assert(T == 16, "sixteen reads x sixteen dwords per quad = one dword per thread");
@@ -333,9 +357,11 @@ __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32
 			r0 = p0; r1 = p1; rv = pv;
 		}
 	}
+	/* a node that shares no position with ANY read of the tile (N = 0 for all of them: d_scan = 0 without being near) stays out of the minima */
 	uint32_t skip[M];
+	const uint2 tsp = tileSpan[tile];
 #pragma unroll
-	for(int m = 0; m < M; ++m) skip[m] = live && node0 + m < db.nNodes && node0 + m != db.root ? 0u : 0xffffffffu;
+	for(int m = 0; m < M; ++m) skip[m] = live && node0 + m < db.nNodes && node0 + m != db.root && hu_cover_meets(db.nodeCover[nl + m], tsp) ? 0u : 0xffffffffu;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
@@ -598,7 +624,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(HuDbDev db, const PT* __restr
  * The exact (d, N) of one (read, node) from the bit-planes: what k_seed_pdist2 writes for every pair, here on demand for the few
  * pairs the distance-only path needs (candidates of the top-k, the seeds' parents, given seeds).  The read's planes are found
  * through its slot in the scan's tiling, its quads through its quad bitmap, its listed inserts through `ins`. */
-struct HuReadPlanes { const uint32_t* rp; const uint32_t* rq; const int32_t* ins; const int32_t* readSlot; };
+struct HuReadPlanes { const uint32_t* rp; const uint32_t* rq; const int32_t* ins; const int32_t* readSlot; const uint2* rspan; /* per read: its two position intervals, as HuDbDev::nodeCover */ };
 __device__ inline uint32_t pair_exact(const HuDbDev& db, const HuReadPlanes& R, int r, int node, bool listed = true) {
 	const int slot = R.readSlot[r], tile = slot / HU_READ_TILE, t = slot % HU_READ_TILE;
 	const int nw32 = (db.WQ + 31) / 32;
@@ -771,7 +797,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 	static_assert(3 * 256 + HU_MAX_SEEDS <= CAP, "three blocks and the kept set fit the candidate buffers");
 	__shared__ unsigned long long keys[HU_TOPK_CAP];        /* 32 KB, carved up below */
 	__shared__ uint32_t chunk[256];
-	__shared__ uint32_t sh[8];
+	__shared__ uint32_t sh[10];
 	uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                                   /* [2048] block minima          0 ..  8 KB */
 	unsigned short* sel = reinterpret_cast<unsigned short*>(keys + 1024);               /* [2048] chosen blocks         8 .. 12 KB */
 	uint32_t* hist = reinterpret_cast<uint32_t*>(keys + 1536);                          /* [HB] histogram of d_scan    12 .. 16 KB */
@@ -788,9 +814,10 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 	const uint32_t need = (uint32_t) maxNSeed;
 	const int per = (nBlk + 63) / 64;                                                   /* block minima per lane of wave 0: <= 32 */
 	for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bminD[(size_t) read * nBlk + i] : NONE;
-	if(tid == 0) { sh[0] = NONE; sh[2] = 0; sh[3] = 0; sh[5] = read_bases(db, R, read); }
+	if(tid == 0) { sh[0] = NONE; sh[2] = 0; sh[3] = 0; sh[9] = 0; sh[5] = read_bases(db, R, read); }
 	__syncthreads();
 	const uint32_t L = sh[5];
+	const uint2 rsp = R.rspan[read];
 	if(L == 0) { /* no base in the region (a read that was not aligned): every N is 0, the order is the node ids' */
 		if(tid == 0) {
 			int k = 0;
@@ -799,36 +826,43 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		}
 		return;
 	}
-	if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
-		uint32_t x[32];
+	/* the want-th smallest block minimum, bit by bit from the top on one wave: the largest r with #{x < r} < want */
+	auto select_rank = [&](int want) __attribute__((always_inline)) {
+		__syncthreads();
+		if(tid < 64) {
+			uint32_t x[32];
 #pragma unroll
-		for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : NONE;
-		uint32_t res = 0;
-		if(per <= 16) {
-			for(int bit = NBITS; bit >= 0; --bit) {
-				const uint32_t trial = res | (1u << bit);
-				int cnt = 0;
+			for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : NONE;
+			uint32_t res = 0;
+			if(per <= 16) {
+				for(int bit = NBITS; bit >= 0; --bit) {
+					const uint32_t trial = res | (1u << bit);
+					int cnt = 0;
 #pragma unroll
-				for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
-				if(cnt < maxNSeed) res = trial;
+					for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
+					if(cnt < want) res = trial;
+				}
+			} else {
+				for(int bit = NBITS; bit >= 0; --bit) {
+					const uint32_t trial = res | (1u << bit);
+					int cnt = 0;
+#pragma unroll
+					for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
+					if(cnt < want) res = trial;
+				}
 			}
-		} else {
-			for(int bit = NBITS; bit >= 0; --bit) {
-				const uint32_t trial = res | (1u << bit);
-				int cnt = 0;
-#pragma unroll
-				for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
-				if(cnt < maxNSeed) res = trial;
-			}
+			if(tid == 0) sh[0] = res;
 		}
-		if(tid == 0) sh[0] = res;
-	}
-	__syncthreads();
-	const uint32_t Dsel = sh[0];
+		__syncthreads();
+		return sh[0];
+	};
 	bool served = false;
-	if(Dsel < DMAX && Dsel < HB) {
+	long long tstamp = stat ? (long long) __builtin_readcyclecounter() : 0;
+#define STAMP(i) do { if(stat && tid == 0) { const long long t_ = (long long) __builtin_readcyclecounter(); atomicAdd(&stat[4 + i], (uint32_t)((t_ - tstamp) >> 4)); tstamp = t_; } } while(0)
+	STAMP(0);
+	{
 		/* blocks with minimum <= lim -> sel; returns their number */
-		auto choose = [&](uint32_t lim) {
+		auto choose = [&](uint32_t lim) __attribute__((always_inline)) {
 			if(tid == 0) sh[2] = 0;
 			__syncthreads();
 			for(int i = tid; i < nBlk; i += 256)
@@ -837,7 +871,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 			return (int) sh[2];
 		};
 		/* the nodes of sel[g0, g1) with lo < d_scan <= lim (lo == NONE: no lower limit): histogram (pass 0) or list at sh[3] (pass 1) */
-		auto sweep = [&](int g0, int g1, uint32_t lo, uint32_t lim, int pass) {
+		auto sweep = [&](int g0, int g1, uint32_t lo, uint32_t lim, int pass) __attribute__((always_inline)) {
 #pragma unroll 1
 			for(int s0 = g0; s0 < g1; s0 += 16) {     /* sixteen loads in flight per thread: scalar block base + one lane offset */
 				uint32_t pv[16];
@@ -847,7 +881,9 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 				for(int k = 0; k < 16; ++k) {
 					if(s0 + k >= g1) continue;
 					const int node = __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid;
-					if(node >= db.nNodes || node == db.root || pv[k] > lim) continue;
+					bool take = node < db.nNodes && node != db.root && pv[k] <= lim;
+					if(take && pv[k] == 0) take = hu_cover_meets(db.nodeCover[node], rsp);        /* no shared position: N = 0 exactly, never a candidate (sorts last) */
+					if(!take) continue;
 					if(pass == 0) atomicAdd(&hist[pv[k]], 1u);
 					else if(lo == NONE || pv[k] > lo) { const uint32_t slot = atomicAdd(&sh[3], 1u); if(slot < CAP) cn[slot] = (uint32_t) node; }
 				}
@@ -857,7 +893,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		uint32_t nb = 0;                          /* kept candidates: slots [0, nb) of ck / cp / cn, the max_nseed best so far once there are that many */
 		uint32_t seen = 0;
 		/* candidates with lo < d_scan <= lim join the kept set; `expect` = their number if known */
-		auto absorb = [&](uint32_t lo, uint32_t lim, uint32_t expect) -> bool {
+		auto absorb = [&](uint32_t lo, uint32_t lim, uint32_t expect) __attribute__((always_inline)) -> bool {
 			const int nsel = choose(lim);
 			const int group = expect != NONE && nb + expect <= CAP ? (nsel > 0 ? nsel : 1) : 3;
 			for(int g0 = 0; g0 < nsel; g0 += group) {
@@ -867,7 +903,10 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 				const uint32_t cnt = sh[3];
 				if(cnt > CAP) return false;
 				seen += cnt - nb;
-				for(uint32_t i = nb + tid; i < cnt; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
+				for(uint32_t i = nb + tid; i < cnt; i += 256) {
+					const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]);
+					if((c & 0xffffu) == 0) atomicAdd(&sh[9], 1u);
+				}
 				__syncthreads();
 				if(cnt >= need) { /* keep the max_nseed best, in order: rank = number of smaller keys (the keys are distinct) */
 					uint32_t rk[CAP / 256], kn[CAP / 256], kp[CAP / 256]; unsigned long long kk[CAP / 256];
@@ -892,45 +931,89 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 			}
 			return true;
 		};
-		for(int i = tid; i < (int) HB; i += 256) hist[i] = 0;
-		const int nsel0 = choose(Dsel);
-		sweep(0, nsel0, NONE, Dsel, 0);
-		chunk[tid] = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+		/* Dsel: a d_scan that at least max_nseed nodes of the read reach.  The block minima leave out the nodes that meet no read of
+		 * the TILE; a node can still miss THIS read, so when the blocks up to the max_nseed-th smallest minimum do not hold max_nseed
+		 * nodes that meet it, four times as many blocks are taken, up to all of them. */
+#pragma unroll 1
+		for(int attempt = 0; attempt < 2 && !served; ++attempt) {      /* a second time over ALL blocks when the first choice of blocks proved too narrow */
+		nb = 0;
 		__syncthreads();
-		if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk and the number of nodes with d_scan <= Dk */
-			const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
-			uint32_t inc = c16;
-			for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
-			const unsigned long long reached = __ballot(inc >= need);
-			if(!reached) { if(tid == 0) sh[1] = NONE; }
-			else if(tid == __ffsll((long long) reached) - 1) {
-				uint32_t cum = inc - c16; int bb = tid * 16;
-				while(bb < tid * 16 + 15 && cum + hist[bb] < need) { cum += hist[bb]; ++bb; }
-				sh[1] = (uint32_t) bb; sh[6] = cum + hist[bb];
+		if(tid == 0) { sh[3] = 0; sh[9] = 0; }
+		uint32_t Dsel = NONE; int nsel0 = 0; bool have = false, usedAll = false;
+#pragma unroll 1
+		for(uint32_t want = attempt ? (uint32_t) nBlk : need; ; want *= 4) {
+			const bool all = want >= (uint32_t) nBlk;
+			usedAll = all;
+			Dsel = all ? min(DMAX, HB) - 1 : select_rank((int) want);
+			if(!(Dsel < DMAX && Dsel < HB)) { if(all) break; continue; }
+			__syncthreads();
+			for(int i = tid; i < (int) HB; i += 256) hist[i] = 0;
+			nsel0 = choose(Dsel);
+			sweep(0, nsel0, NONE, Dsel, 0);
+			chunk[tid] = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+			__syncthreads();
+			if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk and the number of nodes with d_scan <= Dk */
+				const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
+				uint32_t inc = c16;
+				for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
+				const unsigned long long reached = __ballot(inc >= need);
+				if(!reached) { if(tid == 0) sh[1] = NONE; }
+				else if(tid == __ffsll((long long) reached) - 1) {
+					uint32_t cum = inc - c16; int bb = tid * 16;
+					while(bb < tid * 16 + 15 && cum + hist[bb] < need) { cum += hist[bb]; ++bb; }
+					sh[1] = (uint32_t) bb; sh[6] = cum + hist[bb];
+				}
 			}
+			__syncthreads();
+			if(sh[1] != NONE) { have = true; break; }
+			if(all) break;
 		}
-		__syncthreads();
+		STAMP(1);
 		const uint32_t Dk = sh[1], cnt1 = sh[6];
-		if(Dk <= Dsel && absorb(NONE, Dk, cnt1) && nb == need) {
-			const uint32_t c1p = cp[need - 1], d1 = c1p >> 16, N1 = c1p & 0xffffu;     /* the max_nseed-th smallest key of C1 */
-			if(N1 != 0) {
-				const unsigned long long D1l = (unsigned long long) d1 * L / N1;
-				const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
-				bool ok = true;
-				if(D1 > Dk) {
-					if(D1 >= DMAX) ok = false;
-					else {
-						if(tid == 0) { uint32_t e = NONE; if(D1 <= Dsel) { e = 0; for(uint32_t x = Dk + 1; x <= D1; ++x) e += hist[x]; } sh[7] = e; }
-						__syncthreads();
-						ok = absorb(Dk, D1, sh[7]);
-					}
+		/* ONE call site of absorb (it is a large piece of code), driven by: C1 = {d_scan <= Dk}; then, while the max_nseed-th kept key is
+		 * a candidate that shares no valid position with the read (N = 0: such nodes all have d_scan = 0 and pass the interval test only
+		 * when their bases lie on both sides of the read; they sort last), the limit moves up to the d_scan that brings as many more
+		 * nodes as there were such candidates; last, the nodes up to D1 = floor(d1 L / N1). */
+		bool ok = have && Dk <= Dsel, done = false;
+		uint32_t lo = NONE, lim = Dk, expect = cnt1, Dcur = Dk, cumCur = cnt1;
+		int rounds = 0; bool last = false;
+#pragma unroll 1
+		while(ok && !done) {
+			ok = absorb(lo, lim, expect) && nb == need;
+			STAMP(2);
+			if(!ok) break;
+			Dcur = lim;
+			if(last) { done = true; break; }
+			const uint32_t c1p = cp[need - 1], d1 = c1p >> 16, N1 = c1p & 0xffffu;     /* the max_nseed-th smallest key so far */
+			__syncthreads();
+			if(N1 == 0) {
+				if(++rounds > 4) { ok = false; break; }
+				if(tid == 0) {
+					const uint32_t target = need + sh[9];        /* sh[9]: candidates with N = 0 met so far */
+					uint32_t cum = cumCur, x = Dcur;
+					while(x < Dsel && cum < target) { ++x; cum += hist[x]; }
+					sh[7] = cum >= target ? x : NONE; sh[8] = cum;
 				}
-				if(ok) {
-					for(uint32_t i = tid; i < need; i += 256) { outId[i] = (int32_t) cn[i]; outDN[i] = cp[i]; outPar[i] = pair_exact(db, R, read, db.parent[cn[i]]); }
-					if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
-					served = true;
-				}
+				__syncthreads();
+				if(sh[7] == NONE) { ok = false; break; }
+				lo = Dcur; lim = sh[7]; expect = sh[8] - cumCur; cumCur = sh[8];
+				continue;
 			}
+			const unsigned long long D1l = (unsigned long long) d1 * L / N1;
+			const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
+			if(D1 <= Dcur) { done = true; break; }
+			if(D1 >= DMAX) { ok = false; break; }
+			if(tid == 0) { uint32_t e = NONE; if(D1 <= Dsel) { e = 0; for(uint32_t x = Dcur + 1; x <= D1; ++x) e += hist[x]; } sh[7] = e; }
+			__syncthreads();
+			lo = Dcur; lim = D1; expect = sh[7]; last = true;
+		}
+		if(ok && done) {
+			for(uint32_t i = tid; i < need; i += 256) { outId[i] = (int32_t) cn[i]; outDN[i] = cp[i]; outPar[i] = pair_exact(db, R, read, db.parent[cn[i]]); }
+			STAMP(3);
+			if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
+			served = true;
+		}
+		if(usedAll) break;
 		}
 	}
 	if(served) return;

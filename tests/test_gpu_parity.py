@@ -806,6 +806,57 @@ def test_distance_only_scan_and_its_topk(mean_blen, max_nseed, read_len, wide):
     B.close(); D.close()
 
 
+@pytest.mark.parametrize("kind", ["ends", "holes"])
+def test_seed_stage_with_partial_sequences(kind, capfd):
+    """Reference sequences that cover only part of the alignment.  "ends": half of the nodes lack a prefix or a suffix, as partial 16S
+    sequences do — for many of them a read shares no position at all (N = 0, d = 0): the scan keeps such nodes out of its block minima
+    and the top-k out of its candidates by their position intervals (HuDbDev::nodeCover), and every read stays on the block path.
+    "holes": the stretch is cut out of the middle, which the intervals cannot see: the top-k meets candidates with N = 0, raises its
+    limit past them, and takes the exact recomputation only when that is not enough.  Either way N differs widely between nodes, so the
+    bound D1 = floor(d1 L / N1) opens far beyond the first candidate set.  Seeds, order and (d, N) against the oracle and against the
+    pair-matrix path."""
+    import copy, re
+    E = _engine()
+    from oracle import oracle_py as O
+    db0 = get_db(2600, 300, "JC69", dg_k=0, seed=11, n_match=200)
+    db = copy.copy(db0)
+    rng = np.random.default_rng(17)
+    seq = db0.seq.copy()
+    for i in rng.choice(db.n_nodes, size=int(db.n_nodes * 0.5), replace=False):
+        if kind == "ends":
+            cut = int(rng.integers(40, db.cs_len - 40))
+            if rng.random() < 0.5: seq[i, :cut] = -2
+            else: seq[i, cut:] = -2
+        else:
+            a = int(rng.integers(0, db.cs_len - 40)); b = int(rng.integers(a + 20, db.cs_len))
+            seq[i, a:b] = -2
+    db.seq = seq
+    _, H, T = oracle_objects(db)
+    reads, vps = sim_reads(db0, 24, 100)
+    opts = E.default_opts(max_nseed=10)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.set_knob("trace", 1)
+    capfd.readouterr()
+    B.get_seed(opts)
+    err = capfd.readouterr().err
+    m = re.search(r"(\d+) of (\d+) reads on the block path .* (\d+) by the exact recomputation", err)
+    assert m and int(m.group(2)) == len(reads), err
+    if kind == "ends":
+        assert int(m.group(3)) == 0, err
+    cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
+    for i in range(len(reads)):
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=10)
+        assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
+    B.estimate_seq(opts); e1 = B.estimates()
+    B.set_knob("scan_pairs", 1); B.get_seed(opts); B.estimate_seq(opts)
+    c2, i2, d2, n2 = B.seeds(); e2 = B.estimates()
+    assert np.array_equal(i2[:, :10], ids[:, :10]) and np.array_equal(d2[:, :10], sd[:, :10]) and np.array_equal(n2[:, :10], sN[:, :10])
+    for a, b in zip(e1, e2):
+        assert np.array_equal(a[:, :10], b[:, :10], equal_nan=True)
+    print("partial sequences (%s):" % kind, m.group(0))
+    B.close(); D.close()
+
+
 def test_seed_paths_agree_on_a_large_tree():
     """The two seed paths on a tree of 39,999 nodes with the default 50 seeds, 2,048 reads (amplicon reads, reads scattered over the
     consensus, a few reads cut down to a handful of bases): distance-only scan + top-k from the planes against pair matrix + k_seed_topk —
