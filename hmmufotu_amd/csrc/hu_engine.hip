@@ -767,7 +767,7 @@ struct hu_batch {
 	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin, dRSpan, dTileSpan;     /* dRSpan / dTileSpan: uint2 per read / tile */
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
-	DBuf<int32_t> dIns, dTileIns;
+	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
 	DBuf<uint32_t> dSortK, dSortV;
 	DBuf<uint8_t> dSortTmp;
 	DBuf<HuEstOut> dEst;
@@ -1213,6 +1213,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	uint32_t* bmin = nullptr;
 	if(dOnly) {
 		if((rc = b->dBmin.ensure(std::max<size_t>(n, 1) * nBlk + 16)) != HU_OK) return rc;
+		if((rc = b->dRetry.ensure(n + 1)) != HU_OK) return rc;
 		bmin = b->dBmin.p;
 	}
 	uint32_t* stat = bmin && b->knob.trace ? bmin + n * nBlk : nullptr;      /* block path: reads served, blocks read, candidates, reads passed on */
@@ -1234,8 +1235,14 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 		}
 		{
 			Timer t(b, HU_T_SEED_TOPK);
-			if(dOnly && narrow) k_seed_topk_d<uint8_t><<<b->n, 256, 0, b->stream>>>(d, (const uint8_t*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat);
-			else if(dOnly) k_seed_topk_d<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat);
+			if(dOnly) { /* the straight path for every read, then the general one for the reads the first launch listed (usually none) */
+				int32_t* retry = b->dRetry.p;
+				HIPCHK(hipMemsetAsync(retry, 0, 4, b->stream));
+				#define TOPK_ARGS(T) d, (const T*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat, retry
+				if(narrow) { k_seed_topk_d<uint8_t, false><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); k_seed_topk_d<uint8_t, true><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); }
+				else { k_seed_topk_d<uint16_t, false><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); k_seed_topk_d<uint16_t, true><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
+				#undef TOPK_ARGS
+			}
 			else {
 				if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
 				else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
@@ -1247,8 +1254,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 			uint32_t h[16];
 			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
 			fprintf(stderr, "[hu] top-k after the distance-only scan: %u of %zu reads on the block path (%.1f blocks, %.1f candidates per read), %u by the exact recomputation; "
-				"ticks per read: start %.0f, selection + histogram %.0f, candidates %.0f, output %.0f\n",
-				h[0], n, h[0] ? (double) h[1] / h[0] : 0.0, h[0] ? (double) h[2] / h[0] : 0.0, h[3], 16.0 * h[4] / n, 16.0 * h[5] / n, 16.0 * h[6] / n, 16.0 * h[7] / n);
+				"%u of them through the general launch\n",
+				h[0] + h[8], n, h[0] + h[8] ? (double) h[1] / (h[0] + h[8]) : 0.0, h[0] + h[8] ? (double) h[2] / (h[0] + h[8]) : 0.0, h[3], h[8]);
 		}
 	}
 	b->seedCap = o->max_nseed;

@@ -787,10 +787,14 @@ __device__ inline void topk_exact_recompute(const HuDbDev& db, const HuReadPlane
  * matrix are valid below the saturation value; a read that reaches it, or has fewer than max_nseed nodes with N > 0, takes
  * topk_exact_recompute; a read without bases gets the first nodes by id with (0, 0) like k_seed_topk.
  * stat (optional): reads served here, blocks, candidates, reads passed on. */
-template<class DT>
+/* GENERAL = false: the straight path only (one choice of blocks, no candidate with N = 0 among the max_nseed best); a read it cannot
+ * serve is appended to `retry` ([0] = count) and left to a second launch with GENERAL = true (one workgroup per listed read), which
+ * widens, retries and finally recomputes: a read that needs the rare paths does not hold up the tail of the launch that serves the rest,
+ * and the rare reads of a batch run side by side. */
+template<class DT, bool GENERAL>
 __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __restrict__ dm, const uint32_t* __restrict__ bminD, HuReadPlanes R,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
-		uint32_t* __restrict__ stat) {
+		uint32_t* __restrict__ stat, int32_t* __restrict__ retry) {
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	constexpr int NBITS = 8 * (int) sizeof(DT);
 	constexpr uint32_t CAP = 1024, HB = 1024, NONE = 0xffffffffu;
@@ -804,7 +808,8 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 	unsigned long long* ck = keys + 2048;                                               /* [CAP] candidate keys        16 .. 24 KB */
 	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
 	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
-	const int read = blockIdx.x, tid = threadIdx.x;
+	if(GENERAL && (int) blockIdx.x >= retry[0]) return;
+	const int read = GENERAL ? retry[1 + blockIdx.x] : (int) blockIdx.x, tid = threadIdx.x;
 	const size_t np = (size_t) db.nNodesPad;
 	const DT* __restrict__ dr = dm + (size_t) read * np;
 	const int nBlk = db.nNodesPad / 256;
@@ -857,9 +862,6 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		return sh[0];
 	};
 	bool served = false;
-	long long tstamp = stat ? (long long) __builtin_readcyclecounter() : 0;
-#define STAMP(i) do { if(stat && tid == 0) { const long long t_ = (long long) __builtin_readcyclecounter(); atomicAdd(&stat[4 + i], (uint32_t)((t_ - tstamp) >> 4)); tstamp = t_; } } while(0)
-	STAMP(0);
 	{
 		/* blocks with minimum <= lim -> sel; returns their number */
 		auto choose = [&](uint32_t lim) __attribute__((always_inline)) {
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		 * the TILE; a node can still miss THIS read, so when the blocks up to the max_nseed-th smallest minimum do not hold max_nseed
 		 * nodes that meet it, four times as many blocks are taken, up to all of them. */
 #pragma unroll 1
-		for(int attempt = 0; attempt < 2 && !served; ++attempt) {      /* a second time over ALL blocks when the first choice of blocks proved too narrow */
+		for(int attempt = 0; attempt < (GENERAL ? 2 : 1) && !served; ++attempt) {      /* a second time over ALL blocks when the first choice of blocks proved too narrow */
 		nb = 0;
 		__syncthreads();
 		if(tid == 0) { sh[3] = 0; sh[9] = 0; }
@@ -966,9 +968,8 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 			}
 			__syncthreads();
 			if(sh[1] != NONE) { have = true; break; }
-			if(all) break;
+			if(all || !GENERAL) break;
 		}
-		STAMP(1);
 		const uint32_t Dk = sh[1], cnt1 = sh[6];
 		/* ONE call site of absorb (it is a large piece of code), driven by: C1 = {d_scan <= Dk}; then, while the max_nseed-th kept key is
 		 * a candidate that shares no valid position with the read (N = 0: such nodes all have d_scan = 0 and pass the interval test only
@@ -980,14 +981,13 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 #pragma unroll 1
 		while(ok && !done) {
 			ok = absorb(lo, lim, expect) && nb == need;
-			STAMP(2);
 			if(!ok) break;
 			Dcur = lim;
 			if(last) { done = true; break; }
 			const uint32_t c1p = cp[need - 1], d1 = c1p >> 16, N1 = c1p & 0xffffu;     /* the max_nseed-th smallest key so far */
 			__syncthreads();
 			if(N1 == 0) {
-				if(++rounds > 4) { ok = false; break; }
+				if(!GENERAL || ++rounds > 4) { ok = false; break; }
 				if(tid == 0) {
 					const uint32_t target = need + sh[9];        /* sh[9]: candidates with N = 0 met so far */
 					uint32_t cum = cumCur, x = Dcur;
@@ -1009,14 +1009,14 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		}
 		if(ok && done) {
 			for(uint32_t i = tid; i < need; i += 256) { outId[i] = (int32_t) cn[i]; outDN[i] = cp[i]; outPar[i] = pair_exact(db, R, read, db.parent[cn[i]]); }
-			STAMP(3);
-			if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
+			if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[GENERAL ? 8 : 0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
 			served = true;
 		}
 		if(usedAll) break;
 		}
 	}
 	if(served) return;
+	if(!GENERAL) { if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read; return; }
 	if(tid == 0 && stat) atomicAdd(&stat[3], 1u);
 	topk_exact_recompute(db, R, read, maxNSeed, keys, chunk, sh, outId, outDN, outPar, seedCnt);
 }
