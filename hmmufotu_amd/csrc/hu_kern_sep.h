@@ -808,8 +808,10 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 	unsigned long long* ck = keys + 2048;                                               /* [CAP] candidate keys        16 .. 24 KB */
 	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
 	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
-	if(GENERAL && (int) blockIdx.x >= retry[0]) return;
-	const int read = GENERAL ? retry[1 + blockIdx.x] : (int) blockIdx.x, tid = threadIdx.x;
+	/* GENERAL: a fixed grid walks the list (an empty list costs a thousand workgroups that leave at once, not one per read) */
+	for(int item = (int) blockIdx.x; item < (GENERAL ? retry[0] : (int) gridDim.x); item += (int) gridDim.x) {
+	if(GENERAL) __syncthreads();           /* the previous read's use of the shared arrays is over */
+	const int read = GENERAL ? retry[1 + item] : item, tid = threadIdx.x;
 	const size_t np = (size_t) db.nNodesPad;
 	const DT* __restrict__ dr = dm + (size_t) read * np;
 	const int nBlk = db.nNodesPad / 256;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 			for(int node = 0; node < db.nNodes && k < maxNSeed; ++node) if(node != db.root) { outId[k] = node; outDN[k] = 0; outPar[k] = 0; ++k; }
 			seedCnt[read] = k;
 		}
-		return;
+		continue;
 	}
 	/* the want-th smallest block minimum, bit by bit from the top on one wave: the largest r with #{x < r} < want */
 	auto select_rank = [&](int want) __attribute__((always_inline)) {
@@ -1015,10 +1017,11 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_d(HuDbDev db, const DT* __
 		if(usedAll) break;
 		}
 	}
-	if(served) return;
-	if(!GENERAL) { if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read; return; }
+	if(served) continue;
+	if(!GENERAL) { if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read; continue; }
 	if(tid == 0 && stat) atomicAdd(&stat[3], 1u);
 	topk_exact_recompute(db, R, read, maxNSeed, keys, chunk, sh, outId, outDN, outPar, seedCnt);
+	}
 }
 
 /* ------------------------------------------------------------------------------------------ */
