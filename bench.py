@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--paired", action="store_true", help="paired-end: two mates of --read-len from the ends of the amplicon")
     ap.add_argument("--amplicon-cols", type=int, default=0, help="CS columns of the simulated amplicon (0: from the read length)")
     ap.add_argument("--uniform-starts", action="store_true", help="read starts uniform over the resident window (SURVEY §8d second run)")
+    ap.add_argument("--partial-frac", type=float, default=0.0, help="fraction of the leaves that lose a prefix or suffix (partial reference sequences)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 15 s worth)")
     ap.add_argument("--rehearse", action="store_true",
                     help="control-flow rehearsal WITHOUT the engine (CPU, gloo): launch, rendezvous, barrier, gather, max-over-ranks, one JSON line; value is null")
@@ -161,7 +162,7 @@ def main():
     if args.win > 0:
         win = (max(0, amp_start - 200), min(args.cs_len, args.win))
     t0 = time.time()
-    db, up, down = synth_gpu.make_db_gpu(args.leaves, args.cs_len, "GTR", dg_k=args.dg_k, seed=97, win=win, device=dev, log=log)
+    db, up, down = synth_gpu.make_db_gpu(args.leaves, args.cs_len, "GTR", dg_k=args.dg_k, seed=97, win=win, device=dev, log=log, partial_frac=args.partial_frac)
     # reads are drawn from the log-space messages BEFORE the engine adopts (and repacks) them
     nb = args.inflight                                  # batches in flight per GPU (one host thread + one HIP stream each)
     all_reads, all_vps, all_mates, all_mvps = [], [], [], []
@@ -288,6 +289,8 @@ def main():
                       seed_topk=("k_seed_topk_d", "k_seed_topk"), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
     workload_key = dict(leaves=args.leaves, cs_len=args.cs_len, read_len=args.read_len, batch=args.batch, dg_k=args.dg_k, paired=bool(args.paired),
                         uniform_starts=bool(args.uniform_starts), win=args.win)
+    if args.partial_frac:
+        workload_key["partial_frac"] = args.partial_frac
     pmc, pmc_src = {}, None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted((x for x in os.listdir(pdir) if x.endswith("_pmc_summary.json")), reverse=True):

@@ -132,6 +132,7 @@ template<class X> struct DBuf {
 struct hu_db {
 	int device = 0;
 	HuDbDev dev;
+	double partialFrac = 0;      /* nodes whose bases cover less than 90 % of the profile block's positions (partial reference sequences) */
 	HuModelDev mdl;
 	hu_model_desc mdesc;
 	HuProfileHost prof;
@@ -279,6 +280,14 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 			hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
 			if(e1 != hipSuccess || e2 != hipSuccess) { hu_set_error("node coverage intervals failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return fail(HU_ERR_DEVICE); }
 			d.nodeCover = cv;
+			/* how many sequences are partial: with many of them the distance of a read to a barely overlapping node (d / N over a handful
+			 * of columns) ranks among the best, d_scan orders the candidates badly, and the seed stage takes the pair-matrix path */
+			std::vector<uint2> hc((size_t) d.nNodes);
+			if(hipMemcpy(hc.data(), cv, hc.size() * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) { hu_set_error("node coverage intervals: copy failed"); return fail(HU_ERR_DEVICE); }
+			const uint32_t span = (uint32_t) std::min<int64_t>((int64_t) d.QM * 128, (int64_t) prof->K);
+			size_t partial = 0;
+			for(const uint2& c : hc) { const uint32_t f = c.x & 0xffffu, l = c.x >> 16; if(f > l || (l - f + 1) * 10u < span * 9u) ++partial; }
+			db->partialFrac = d.nNodes ? (double) partial / d.nNodes : 0.0;
 		}
 	}
 	{
@@ -705,7 +714,7 @@ struct HuKnobs {
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
 	int dscan1 = 0;              /* the distance-only scan with one node per lane and scalar read planes (k_seed_dscan)             */
-	int scan_pairs = 0;          /* the full (d, N) pair matrix + k_seed_topk on large trees too (default there: distance-only scan) */
+	int scan_pairs = 0;          /* 1: the full (d, N) pair matrix + k_seed_topk on large trees too; -1: the distance-only scan even with many partial sequences */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
 	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
@@ -1200,7 +1209,11 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	/* Large trees without a height filter: the distance-only scan + the top-k that recomputes the (d, N) of its few candidates
 	 * (k_seed_dscan, k_seed_topk_d).  Otherwise the full (d, N) pair matrix and k_seed_topk. */
 	const int nBlk = d.nNodesPad / 256;
-	const bool dOnly = !b->knob.scan_pairs && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
+	/* scan_pairs: 1 = the pair matrix always, -1 = the distance-only scan whenever it applies, 0 (default) = the distance-only scan unless
+	 * more than 2 % of the reference sequences are partial (measured at gg_97 scale with 40 % of the leaves cut: 264 k reads/s on the
+	 * distance-only path, whose top-k then wades through thousands of barely overlapping candidates per read, 378 k on the pair matrix) */
+	const bool manyPartial = b->db->partialFrac > 0.02 && b->knob.scan_pairs != -1;
+	const bool dOnly = b->knob.scan_pairs != 1 && !manyPartial && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
 	const bool narrow = !b->knob.pairs32 && b->maxBases <= 255;      /* 8-bit distances / 16-bit pairs */
 	b->pair16 = !dOnly && narrow && !b->knob.pdist_v1;
 	b->pairsKind = dOnly ? 0 : (b->pair16 ? 16 : 32);

@@ -45,9 +45,10 @@ def _row_mean_exp(X):
 
 
 def make_db_gpu(n_leaves: int, cs_len: int, model_name="GTR", dg_k=0, dg_alpha=0.5, seed=97, mean_blen=0.05,
-                n_match=None, match_gap=0.02, sparse_gap=0.999, win=None, device="cuda:0", chunk=2048, log=print):
+                n_match=None, match_gap=0.02, sparse_gap=0.999, win=None, device="cuda:0", chunk=2048, log=print, partial_frac=0.0):
     """Returns (SynthDB-like object with host arrays, up_dev, down_dev).  `win` = (start, len) keeps
-    messages for a column window only (None = all columns)."""
+    messages for a column window only (None = all columns).  partial_frac: that fraction of the leaves lose a prefix or a suffix
+    of random length (partial reference sequences: all gaps there)."""
     t0 = time.time()
     rng = np.random.default_rng(seed)
     gen = torch.Generator(device=device); gen.manual_seed(seed)
@@ -91,6 +92,14 @@ def make_db_gpu(n_leaves: int, cs_len: int, model_name="GTR", dg_k=0, dg_alpha=0
         li = leaf_d[a:a + chunk * 4]
         g = torch.rand((len(li), cs_len), device=device, generator=gen) < gap_p[None, :]
         s = seq[li]; s[g] = -2; seq[li] = s
+    if partial_frac > 0:
+        part = leaf_idx[rng.random(len(leaf_idx)) < partial_frac]
+        cut = rng.integers(cs_len // 8, cs_len - cs_len // 8, size=len(part)); head = rng.random(len(part)) < 0.5
+        col = torch.arange(cs_len, device=device)[None, :]
+        for a in range(0, len(part), chunk * 4):
+            pi_ = torch.tensor(part[a:a + chunk * 4], device=device)
+            c = torch.tensor(cut[a:a + chunk * 4], device=device)[:, None]; h = torch.tensor(head[a:a + chunk * 4], device=device)[:, None]
+            s = seq[pi_]; s[torch.where(h, col < c, col >= c)] = -2; seq[pi_] = s
     # ---- messages
     w0, wl = (0, cs_len) if win is None else (int(win[0]), int(win[1]))
     up = torch.empty((n, wl, 4), dtype=torch.float64, device=device)

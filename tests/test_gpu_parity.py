@@ -836,6 +836,7 @@ def test_seed_stage_with_partial_sequences(kind, capfd):
     opts = E.default_opts(max_nseed=10)
     D, B = _run_stages(E, db, reads, vps, opts)
     B.set_knob("trace", 1)
+    B.set_knob("scan_pairs", -1)        # with so many partial sequences the engine would choose the pair matrix by itself: force the distance-only path
     capfd.readouterr()
     B.get_seed(opts)
     err = capfd.readouterr().err
@@ -848,7 +849,9 @@ def test_seed_stage_with_partial_sequences(kind, capfd):
         oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=10)
         assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
     B.estimate_seq(opts); e1 = B.estimates()
-    B.set_knob("scan_pairs", 1); B.get_seed(opts); B.estimate_seq(opts)
+    B.set_knob("scan_pairs", 0)                                   # the engine's own choice: the pair matrix when many sequences lack an end
+    capfd.readouterr(); B.get_seed(opts); B.estimate_seq(opts)        # (a hole in the middle does not show in a node's intervals)
+    assert ("block path" in capfd.readouterr().err) == (kind == "holes")
     c2, i2, d2, n2 = B.seeds(); e2 = B.estimates()
     assert np.array_equal(i2[:, :10], ids[:, :10]) and np.array_equal(d2[:, :10], sd[:, :10]) and np.array_equal(n2[:, :10], sN[:, :10])
     for a, b in zip(e1, e2):
