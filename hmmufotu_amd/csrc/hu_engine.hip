@@ -1252,8 +1252,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 				int32_t* retry = b->dRetry.p;
 				HIPCHK(hipMemsetAsync(retry, 0, 4, b->stream));
 				#define TOPK_ARGS(T) d, (const T*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat, retry
-				if(narrow) { k_seed_topk_d<uint8_t, false><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); k_seed_topk_d<uint8_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); }
-				else { k_seed_topk_d<uint16_t, false><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
+				if(narrow) { k_seed_topk_straight<uint8_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); k_seed_topk_d<uint8_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); }
+				else { k_seed_topk_straight<uint16_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
 				#undef TOPK_ARGS
 			}
 			else {

@@ -787,6 +787,188 @@ __device__ inline void topk_exact_recompute(const HuDbDev& db, const HuReadPlane
  * matrix are valid below the saturation value; a read that reaches it, or has fewer than max_nseed nodes with N > 0, takes
  * topk_exact_recompute; a read without bases gets the first nodes by id with (0, 0) like k_seed_topk.
  * stat (optional): reads served here, blocks, candidates, reads passed on. */
+/* The straight path of the top-k after the distance-only scan, as its own small kernel (with the rare paths in the same kernel the
+ * common path's code ran 40 % slower, 0.47 against 0.33 ms per 8,192 reads: a matter of code generation that was not pinned down): Dsel by bitwise selection, one histogram pass, C1, the bound D1, a second absorb when needed.  Anything else — fewer
+ * than max_nseed nodes within the chosen blocks, a candidate with N = 0 among the kept, buffers too small, saturation — and the read
+ * is appended to `retry` for k_seed_topk_d<DT, true>, the general launch below, which also documents the algorithm. */
+template<class DT>
+__global__ __launch_bounds__(256, 4) void k_seed_topk_straight(HuDbDev db, const DT* __restrict__ dm, const uint32_t* __restrict__ bminD, HuReadPlanes R,
+		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
+		uint32_t* __restrict__ stat, int32_t* __restrict__ retry) {
+	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
+	constexpr int NBITS = 8 * (int) sizeof(DT);
+	constexpr uint32_t CAP = 1024, HB = 1024, NONE = 0xffffffffu;
+	static_assert(3 * 256 + HU_MAX_SEEDS <= CAP, "three blocks and the kept set fit the candidate buffers");
+	__shared__ unsigned long long keys[HU_TOPK_CAP];        /* 32 KB, carved up below */
+	__shared__ uint32_t chunk[256];
+	__shared__ uint32_t sh[8];
+	uint32_t* bm = reinterpret_cast<uint32_t*>(keys);                                   /* [2048] block minima          0 ..  8 KB */
+	unsigned short* sel = reinterpret_cast<unsigned short*>(keys + 1024);               /* [2048] chosen blocks         8 .. 12 KB */
+	uint32_t* hist = reinterpret_cast<uint32_t*>(keys + 1536);                          /* [HB] histogram of d_scan    12 .. 16 KB */
+	unsigned long long* ck = keys + 2048;                                               /* [CAP] candidate keys        16 .. 24 KB */
+	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
+	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
+	const int read = blockIdx.x, tid = threadIdx.x;
+	const size_t np = (size_t) db.nNodesPad;
+	const DT* __restrict__ dr = dm + (size_t) read * np;
+	const int nBlk = db.nNodesPad / 256;
+	int32_t* outId = seedId + (size_t) read * HU_MAX_SEEDS;
+	uint32_t* outDN = seedDN + (size_t) read * HU_MAX_SEEDS;
+	uint32_t* outPar = parDN + (size_t) read * HU_MAX_SEEDS;
+	const uint32_t need = (uint32_t) maxNSeed;
+	const int per = (nBlk + 63) / 64;                                                   /* block minima per lane of wave 0: <= 32 */
+	for(int i = tid; i < per * 64; i += 256) bm[i] = i < nBlk ? bminD[(size_t) read * nBlk + i] : NONE;
+	if(tid == 0) { sh[0] = NONE; sh[2] = 0; sh[3] = 0; sh[5] = read_bases(db, R, read); }
+	__syncthreads();
+	const uint32_t L = sh[5];
+	const uint2 rsp = R.rspan[read];
+	if(L == 0) { /* no base in the region (a read that was not aligned): every N is 0, the order is the node ids' */
+		if(tid == 0) {
+			int k = 0;
+			for(int node = 0; node < db.nNodes && k < maxNSeed; ++node) if(node != db.root) { outId[k] = node; outDN[k] = 0; outPar[k] = 0; ++k; }
+			seedCnt[read] = k;
+		}
+		return;
+	}
+	if(tid < 64) { /* the max_nseed-th smallest, bit by bit from the top: the largest r with #{x < r} < max_nseed */
+		uint32_t x[32];
+#pragma unroll
+		for(int k = 0; k < 32; ++k) x[k] = k < per ? bm[k * 64 + tid] : NONE;
+		uint32_t res = 0;
+		if(per <= 16) {
+			for(int bit = NBITS; bit >= 0; --bit) {
+				const uint32_t trial = res | (1u << bit);
+				int cnt = 0;
+#pragma unroll
+				for(int k = 0; k < 16; ++k) cnt += __popcll(__ballot(x[k] < trial));
+				if(cnt < maxNSeed) res = trial;
+			}
+		} else {
+			for(int bit = NBITS; bit >= 0; --bit) {
+				const uint32_t trial = res | (1u << bit);
+				int cnt = 0;
+#pragma unroll
+				for(int k = 0; k < 32; ++k) cnt += __popcll(__ballot(x[k] < trial));
+				if(cnt < maxNSeed) res = trial;
+			}
+		}
+		if(tid == 0) sh[0] = res;
+	}
+	__syncthreads();
+	const uint32_t Dsel = sh[0];
+	bool served = false;
+	if(Dsel < DMAX && Dsel < HB) {
+		/* blocks with minimum <= lim -> sel; returns their number */
+		auto choose = [&](uint32_t lim) __attribute__((always_inline)) {
+			if(tid == 0) sh[2] = 0;
+			__syncthreads();
+			for(int i = tid; i < nBlk; i += 256)
+				if(bm[i] <= lim) sel[atomicAdd(&sh[2], 1u)] = (unsigned short) i;
+			__syncthreads();
+			return (int) sh[2];
+		};
+		/* the nodes of sel[g0, g1) with lo < d_scan <= lim (lo == NONE: no lower limit): histogram (pass 0) or list at sh[3] (pass 1) */
+		auto sweep = [&](int g0, int g1, uint32_t lo, uint32_t lim, int pass) __attribute__((always_inline)) {
+#pragma unroll 1
+			for(int s0 = g0; s0 < g1; s0 += 16) {     /* sixteen loads in flight per thread: scalar block base + one lane offset */
+				uint32_t pv[16];
+#pragma unroll
+				for(int k = 0; k < 16; ++k) pv[k] = s0 + k < g1 ? (uint32_t) (dr + (size_t) __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256)[tid] : NONE;
+#pragma unroll
+				for(int k = 0; k < 16; ++k) {
+					if(s0 + k >= g1) continue;
+					const int node = __builtin_amdgcn_readfirstlane((int) sel[s0 + k]) * 256 + tid;
+					if(node >= db.nNodes || node == db.root || pv[k] > lim) continue;
+					if(pv[k] == 0 && !hu_cover_meets(db.nodeCover[node], rsp)) continue;        /* no shared position: N = 0 exactly, never a candidate */
+					if(pass == 0) atomicAdd(&hist[pv[k]], 1u);
+					else if(lo == NONE || pv[k] > lo) { const uint32_t slot = atomicAdd(&sh[3], 1u); if(slot < CAP) cn[slot] = (uint32_t) node; }
+				}
+			}
+			__syncthreads();
+		};
+		uint32_t nb = 0;                          /* kept candidates: slots [0, nb) of ck / cp / cn, the max_nseed best so far once there are that many */
+		uint32_t seen = 0;
+		/* candidates with lo < d_scan <= lim join the kept set; `expect` = their number if known */
+		auto absorb = [&](uint32_t lo, uint32_t lim, uint32_t expect) __attribute__((always_inline)) -> bool {
+			const int nsel = choose(lim);
+			const int group = expect != NONE && nb + expect <= CAP ? (nsel > 0 ? nsel : 1) : 3;
+			for(int g0 = 0; g0 < nsel; g0 += group) {
+				if(tid == 0) sh[3] = nb;
+				__syncthreads();
+				sweep(g0, min(g0 + group, nsel), lo, lim, 1);
+				const uint32_t cnt = sh[3];
+				if(cnt > CAP) return false;
+				seen += cnt - nb;
+				for(uint32_t i = nb + tid; i < cnt; i += 256) { const uint32_t c = pair_exact(db, R, read, (int) cn[i]); cp[i] = c; ck[i] = seed_key(c >> 16, c & 0xffffu, cn[i]); }
+				__syncthreads();
+				if(cnt >= need) { /* keep the max_nseed best, in order: rank = number of smaller keys (the keys are distinct) */
+					uint32_t rk[CAP / 256], kn[CAP / 256], kp[CAP / 256]; unsigned long long kk[CAP / 256];
+#pragma unroll
+					for(int q = 0; q < (int)(CAP / 256); ++q) {
+						const uint32_t i = q * 256 + tid;
+						rk[q] = NONE;
+						if(i < cnt) {
+							const unsigned long long mine = ck[i];
+							uint32_t rank = 0;
+							for(uint32_t j = 0; j < cnt; ++j) rank += ck[j] < mine ? 1u : 0u;
+							rk[q] = rank; kk[q] = mine; kn[q] = cn[i]; kp[q] = cp[i];
+						}
+					}
+					__syncthreads();
+#pragma unroll
+					for(int q = 0; q < (int)(CAP / 256); ++q) if(rk[q] < need) { ck[rk[q]] = kk[q]; cn[rk[q]] = kn[q]; cp[rk[q]] = kp[q]; }
+					__syncthreads();
+					nb = need;
+				}
+				else nb = cnt;
+			}
+			return true;
+		};
+		for(int i = tid; i < (int) HB; i += 256) hist[i] = 0;
+		const int nsel0 = choose(Dsel);
+		sweep(0, nsel0, NONE, Dsel, 0);
+		chunk[tid] = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+		__syncthreads();
+		if(tid < 64) { /* prefix over the 64 x 16 bins on one wave -> Dk and the number of nodes with d_scan <= Dk */
+			const uint32_t c16 = chunk[tid * 4] + chunk[tid * 4 + 1] + chunk[tid * 4 + 2] + chunk[tid * 4 + 3];
+			uint32_t inc = c16;
+			for(int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if(tid >= off) inc += o; }
+			const unsigned long long reached = __ballot(inc >= need);
+			if(!reached) { if(tid == 0) sh[1] = NONE; }
+			else if(tid == __ffsll((long long) reached) - 1) {
+				uint32_t cum = inc - c16; int bb = tid * 16;
+				while(bb < tid * 16 + 15 && cum + hist[bb] < need) { cum += hist[bb]; ++bb; }
+				sh[1] = (uint32_t) bb; sh[6] = cum + hist[bb];
+			}
+		}
+		__syncthreads();
+		const uint32_t Dk = sh[1], cnt1 = sh[6];
+		if(Dk <= Dsel && absorb(NONE, Dk, cnt1) && nb == need) {
+			const uint32_t c1p = cp[need - 1], d1 = c1p >> 16, N1 = c1p & 0xffffu;     /* the max_nseed-th smallest key of C1 */
+			if(N1 != 0) {
+				const unsigned long long D1l = (unsigned long long) d1 * L / N1;
+				const uint32_t D1 = D1l > 0xfffffffeull ? 0xfffffffeu : (uint32_t) D1l;
+				bool ok = true;
+				if(D1 > Dk) {
+					if(D1 >= DMAX) ok = false;
+					else {
+						if(tid == 0) { uint32_t e = NONE; if(D1 <= Dsel) { e = 0; for(uint32_t x = Dk + 1; x <= D1; ++x) e += hist[x]; } sh[7] = e; }
+						__syncthreads();
+						ok = absorb(Dk, D1, sh[7]);
+					}
+				}
+				if(ok) {
+					for(uint32_t i = tid; i < need; i += 256) { outId[i] = (int32_t) cn[i]; outDN[i] = cp[i]; outPar[i] = pair_exact(db, R, read, db.parent[cn[i]]); }
+					if(tid == 0) { seedCnt[read] = (int32_t) need; if(stat) { atomicAdd(&stat[0], 1u); atomicAdd(&stat[1], (uint32_t) nsel0); atomicAdd(&stat[2], seen); } }
+					served = true;
+				}
+			}
+		}
+	}
+	if(served) return;
+	if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read;        /* left to the general launch */
+}
+
 /* GENERAL = false: the straight path only (one choice of blocks, no candidate with N = 0 among the max_nseed best); a read it cannot
  * serve is appended to `retry` ([0] = count) and left to a second launch with GENERAL = true (one workgroup per listed read), which
  * widens, retries and finally recomputes: a read that needs the rare paths does not hold up the tail of the launch that serves the rest,
