@@ -286,7 +286,7 @@ def main():
     # (rocprofv3 --pmc passes of this same command, profiles/make_pmc_summary.py); tagged with its source, null otherwise
     stages = ("viterbi", "seed_pdist", "seed_topk", "estimate", "place")
     pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_dscan4", "k_seed_dscan", "k_seed_pdist2", "k_seed_pdist"),
-                      seed_topk=("k_seed_topk_d", "k_seed_topk"), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
+                      seed_topk=("k_seed_topk_straight", "k_seed_topk_d", "k_seed_topk"), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
     workload_key = dict(leaves=args.leaves, cs_len=args.cs_len, read_len=args.read_len, batch=args.batch, dg_k=args.dg_k, paired=bool(args.paired),
                         uniform_starts=bool(args.uniform_starts), win=args.win)
     if args.partial_frac:

@@ -969,8 +969,9 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_straight(HuDbDev db, const
 	if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read;        /* left to the general launch */
 }
 
-/* GENERAL = false: the straight path only (one choice of blocks, no candidate with N = 0 among the max_nseed best); a read it cannot
- * serve is appended to `retry` ([0] = count) and left to a second launch with GENERAL = true (one workgroup per listed read), which
+/* GENERAL = false (no longer launched: k_seed_topk_straight above took its place): the straight path only (one choice of blocks, no
+ * candidate with N = 0 among the max_nseed best); a read it cannot serve is appended to `retry` ([0] = count) and left to a second launch
+ * with GENERAL = true (one workgroup per listed read), which
  * widens, retries and finally recomputes: a read that needs the rare paths does not hold up the tail of the launch that serves the rest,
  * and the rare reads of a batch run side by side. */
 template<class DT, bool GENERAL>
