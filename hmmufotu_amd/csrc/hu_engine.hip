@@ -713,6 +713,7 @@ struct HuKnobs {
 	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
+	int topk_general = 0;        /* every read through the general top-k launch (k_seed_topk_d<DT, true>) instead of the straight kernel */
 	int dscan1 = 0;              /* the distance-only scan with one node per lane and scalar read planes (k_seed_dscan)             */
 	int scan_pairs = 0;          /* 1: the full (d, N) pair matrix + k_seed_topk on large trees too; -1: the distance-only scan even with many partial sequences */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
@@ -727,7 +728,7 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
 	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
@@ -1252,8 +1253,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 				int32_t* retry = b->dRetry.p;
 				HIPCHK(hipMemsetAsync(retry, 0, 4, b->stream));
 				#define TOPK_ARGS(T) d, (const T*) b->dPairs.p, bmin, read_planes(b), o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, stat, retry
-				if(narrow) { k_seed_topk_straight<uint8_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); k_seed_topk_d<uint8_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); }
-				else { k_seed_topk_straight<uint16_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
+				if(narrow) { k_seed_topk_straight<uint8_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint8_t), b->knob.topk_general); k_seed_topk_d<uint8_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint8_t)); }
+				else { k_seed_topk_straight<uint16_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t), b->knob.topk_general); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
 				#undef TOPK_ARGS
 			}
 			else {

@@ -794,7 +794,7 @@ __device__ inline void topk_exact_recompute(const HuDbDev& db, const HuReadPlane
 template<class DT>
 __global__ __launch_bounds__(256, 4) void k_seed_topk_straight(HuDbDev db, const DT* __restrict__ dm, const uint32_t* __restrict__ bminD, HuReadPlanes R,
 		int maxNSeed, int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
-		uint32_t* __restrict__ stat, int32_t* __restrict__ retry) {
+		uint32_t* __restrict__ stat, int32_t* __restrict__ retry, int leaveAll) {
 	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
 	constexpr int NBITS = 8 * (int) sizeof(DT);
 	constexpr uint32_t CAP = 1024, HB = 1024, NONE = 0xffffffffu;
@@ -809,6 +809,7 @@ __global__ __launch_bounds__(256, 4) void k_seed_topk_straight(HuDbDev db, const
 	uint32_t* cp = reinterpret_cast<uint32_t*>(keys + 3072);                            /* [CAP] candidate (d, N)      24 .. 28 KB */
 	uint32_t* cn = reinterpret_cast<uint32_t*>(keys + 3584);                            /* [CAP] candidate nodes       28 .. 32 KB */
 	const int read = blockIdx.x, tid = threadIdx.x;
+	if(leaveAll) { if(tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = read; return; }      /* test knob: every read through the general launch */
 	const size_t np = (size_t) db.nNodesPad;
 	const DT* __restrict__ dr = dm + (size_t) read * np;
 	const int nBlk = db.nNodesPad / 256;

@@ -889,7 +889,13 @@ def test_seed_paths_agree_on_a_large_tree():
         assert np.array_equal(x, y, equal_nan=True)
     assert (a[0] == 50).all()
     d, N = B.pdist(3)
-    B.set_knob("scan_pairs", 0); B.get_seed(opts)
+    B.set_knob("scan_pairs", 0); B.set_knob("topk_general", 1)    # all 2,048 reads through the general launch: its 1,024 workgroups take two each
+    B.get_seed(opts); g = B.seeds(); B.estimate_seq(opts); eg = B.estimates()
+    for x, y in zip(a, g):
+        assert np.array_equal(x, y)
+    for x, y in zip(ea, eg):
+        assert np.array_equal(x, y, equal_nan=True)
+    B.set_knob("topk_general", 0); B.get_seed(opts)
     d2, N2 = B.pdist(3)                                            # the scan's own row checked inside
     assert np.array_equal(d, d2) and np.array_equal(N, N2)
     B.close(); D.close()
