@@ -37,3 +37,38 @@ with tempfile.TemporaryDirectory() as t:
     with open(os.path.join(t, "x.csfm"), "rb") as f, gzip.GzipFile(os.path.join(G, "70_otus.csfm.gz"), "wb", mtime=0) as g:
         g.write(f.read())
 print("wrote", os.path.getsize(os.path.join(G, "70_otus.csfm.gz")), "bytes;", len(pats), "patterns")
+
+# ---- a small alignment of awkward rows: empty rows, rows of one to three bases, IUPAC symbols, lower case, '.' gaps
+random.seed(11)
+rows2 = []
+for i in range(48):
+    r = []
+    kind = i % 8
+    for j in range(240):
+        if kind == 0:
+            r.append("-")                                                    # no base at all
+        elif kind == 1:
+            r.append(random.choice("ACGT") if j in (5 + i, 100, 200)[:1 + i % 3] else ".")   # one to three bases
+        else:
+            r.append(random.choice("ACGTacgtNRYK") if random.random() < 0.75 else random.choice("-."))
+    rows2.append("".join(r))
+pats2 = []
+for i in range(200):
+    r = rows2[random.randrange(len(rows2))]
+    g = "".join(c for c in r if c not in "-.").upper()
+    if len(g) < 14:
+        continue
+    p = random.randrange(0, len(g) - 12)
+    pats2.append(g[p:p + 12])
+with tempfile.TemporaryDirectory() as t:
+    fa = os.path.join(t, "msa.fasta")
+    with open(fa, "w") as f:
+        for i, r in enumerate(rows2):
+            f.write(">s%d\n%s\n" % (i, r))
+    open(os.path.join(t, "pats.txt"), "w").write("\n".join(pats2) + "\n")
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "csfm_ref"), fa, os.path.join(t, "x.csfm"), os.path.join(t, "pats.txt"), os.path.join(G, "csfm_awkward_hits.tsv")])
+    with open(os.path.join(t, "x.csfm"), "rb") as f, gzip.GzipFile(os.path.join(G, "csfm_awkward.csfm.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    with gzip.GzipFile(os.path.join(G, "csfm_awkward.fasta.gz"), "wb", mtime=0) as g:
+        g.write(open(fa, "rb").read())
+print("awkward alignment:", len(pats2), "patterns")

@@ -138,3 +138,31 @@ def test_a_damaged_file_is_refused(csfm_path, tmp_path):
         del ix
     except Exception:
         pass
+
+
+def test_awkward_rows(tmp_path):
+    """rows without a base, rows of one to three bases (no sampled suffix-array entry: they cannot hold a seed and are left out), IUPAC
+    symbols, lower case, both gap characters — written by the reference's libcds (tests/golden/csfm_awkward.*)"""
+    from hmmufotu_amd import engine as E
+    p = tmp_path / "awk.csfm"
+    p.write_bytes(gzip.open(os.path.join(G, "csfm_awkward.csfm.gz"), "rb").read())
+    rows = []
+    for l in gzip.open(os.path.join(G, "csfm_awkward.fasta.gz"), "rt"):
+        l = l.strip()
+        if l.startswith(">"):
+            rows.append("")
+        elif rows:
+            rows[-1] += l
+    ix = E.SeedIndex(None, None, _Hmm(len(rows[0])), 12, csfm=p)
+    gapfree = [r.replace("-", "").replace(".", "") for r in rows]
+    assert ix.positions == sum(max(0, len(g) - 11) for g in gapfree)
+    checked = 0
+    for l in open(os.path.join(G, "csfm_awkward_hits.tsv")):
+        pat, s, e, n = l.rstrip("\n").split("\t")
+        got = ix.locate_first(pat)
+        assert got[2] == int(n), pat
+        if got[:2] != (int(s), int(e)):
+            nocc, sq, off, col = ix.occurrences(pat)
+            assert off[0] < 4 and col[0] + 1 == got[0], (pat, got, (s, e))      # the reference's accessSA walk left its sequence (see above)
+        checked += 1
+    assert checked >= 100
