@@ -293,10 +293,12 @@ namespace {
 struct Rd {
 	std::ifstream in;
 	bool ok = true;
+	uint64_t size = 0;          /* of the file: no length field read from it may ask for more memory than that */
+	void measure() { in.seekg(0, std::ios::end); const std::streamoff e = in.tellg(); size = e > 0 ? (uint64_t) e : 0; in.seekg(0, std::ios::beg); }
 	template<class X> X get() { X v{}; in.read((char*) &v, sizeof(X)); if(!in) ok = false; return v; }
 	std::string str() {
 		uint64_t n = get<uint64_t>();
-		if(!ok || n > (1ull << 32)) { ok = false; return std::string(); }
+		if(!ok || n > size) { ok = false; return std::string(); }
 		std::string s(n, '\0');
 		if(n) in.read(&s[0], n);
 		if(!in) ok = false;
@@ -352,6 +354,7 @@ int hu_read_ptu_sink(const char* path, HuTreeHost& t, const std::function<int(bo
 	Rd r;
 	r.in.open(path, std::ios::binary);
 	if(!r.in) { hu_set_error("cannot open PTU file '%s'", path); return HU_ERR_IO; }
+	r.measure();
 	char magic[8];
 	r.in.read(magic, 8);
 	if(!r.in || memcmp(magic, "HmmUFOtu", 8) != 0) { hu_set_error("'%s' is not a HmmUFOtu database file", path); return HU_ERR_IO; }
@@ -359,6 +362,8 @@ int hu_read_ptu_sink(const char* path, HuTreeHost& t, const std::function<int(bo
 	uint64_t n = r.get<uint64_t>();
 	int32_t csLen = r.get<int32_t>();
 	if(!r.ok || n == 0 || n > (1u << 24) || csLen < 1 || csLen > 65535) { hu_set_error("ptu: bad header"); return HU_ERR_IO; }
+	/* the file carries 2 (n - 1) messages of 4 x csLen doubles: a header that promises more than the file holds is refused before anything is sized by it */
+	if((n - 1) * 2 * 32 * (uint64_t) csLen > r.size) { hu_set_error("ptu: the header names %llu nodes x %d columns, the file has %llu bytes", (unsigned long long) n, (int) csLen, (unsigned long long) r.size); return HU_ERR_IO; }
 	t.n = (int32_t) n; t.csLen = csLen;
 	t.parent.assign(n, -1); t.blen.assign(n, 0.0); t.height.assign(n, 0.0); t.annoDist.assign(n, 0.0);
 	t.seq.assign((size_t) n * csLen, (int8_t) -2);

@@ -179,11 +179,16 @@ struct PlainBits {
 		blk[(w.size() + 7) >> 3] = run;
 	}
 };
-struct Reader {
-	FILE* f; bool ok = true;
-	template<class T> T val() { T v{}; if(fread(&v, sizeof(T), 1, f) != 1) ok = false; return v; }
-	template<class T> bool arr(std::vector<T>& v, size_t n) { v.resize(n); if(n && fread(v.data(), sizeof(T), n, f) != n) ok = false; return ok; }
-	bool str(std::string& s) { const uint64_t n = val<uint64_t>(); if(!ok || n > (1u << 28)) return ok = false; s.resize((size_t) n); if(n && fread(&s[0], 1, (size_t) n, f) != n) ok = false; return ok; }
+struct Reader {      /* every array is checked against what is left of the file BEFORE it is allocated: a damaged length cannot ask for memory */
+	FILE* f; bool ok = true; uint64_t left = 0;
+	explicit Reader(FILE* fp) : f(fp) { if(fseek(f, 0, SEEK_END) == 0) { const long e = ftell(f); if(e > 0) left = (uint64_t) e; } rewind(f); }
+	template<class T> T val() { T v{}; if(left < sizeof(T) || fread(&v, sizeof(T), 1, f) != 1) ok = false; else left -= sizeof(T); return v; }
+	template<class T> bool arr(std::vector<T>& v, uint64_t n) {
+		if(!ok || n > left / sizeof(T)) return ok = false;
+		v.resize((size_t) n); if(n && fread(v.data(), sizeof(T), (size_t) n, f) != n) return ok = false;
+		left -= n * sizeof(T); return true;
+	}
+	bool str(std::string& s) { const uint64_t n = val<uint64_t>(); if(!ok || n > left) return ok = false; s.resize((size_t) n); if(n && fread(&s[0], 1, (size_t) n, f) != n) return ok = false; left -= n; return true; }
 };
 inline uint32_t bits_of(uint32_t n) { uint32_t b = 0; while(n) { ++b; n >>= 1; } return b; }
 inline uint32_t field(const std::vector<uint32_t>& A, size_t ini, uint32_t len) { /* len bits starting at bit ini (libcds get_var_field) */
@@ -209,9 +214,9 @@ bool read_rrr(Reader& R, PlainBits& out) {
 	const uint64_t length = R.val<uint64_t>(), ones = R.val<uint64_t>();
 	const uint32_t C_len = R.val<uint32_t>(), C_bits = R.val<uint32_t>(), O_len = R.val<uint32_t>(), O_bits_len = R.val<uint32_t>();
 	(void) R.val<uint32_t>();                                  /* sample_rate: libcds rebuilds its samples on load, we keep plain words */
-	if(!R.ok || C_bits != 4 || length > (1ull << 33) || (uint64_t) C_len != (length + 14) / 15) return false;
+	if(!R.ok || C_bits != 4 || length > (1ull << 33) || (uint64_t) C_len != (length + 14) / 15 || (uint64_t) O_bits_len > (uint64_t) O_len * 32) return false;
 	std::vector<uint32_t> C, O;
-	if(!R.arr(C, ((size_t) C_len * C_bits + 31) / 32) || !R.arr(O, O_len)) return false;
+	if(!R.arr(C, ((uint64_t) C_len * C_bits + 31) / 32) || !R.arr(O, O_len)) return false;
 	C.push_back(0); O.push_back(0); O.push_back(0);
 	out.n = (size_t) length; out.w.assign(out.n / 64 + 2, 0);
 	size_t pos = 0, cnt = 0;
@@ -235,7 +240,7 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 	if(!path || !p2cs || !out || seed_len < HU_SX_DIRK || seed_len > 31) { hu_set_error("hu_seed_index_load_csfm: bad argument (seed length must be in %d..31)", HU_SX_DIRK); return HU_ERR_ARG; }
 	FILE* f = fopen(path, "rb");
 	if(!f) { hu_set_error("cannot open %s", path); return HU_ERR_IO; }
-	Reader R{f};
+	Reader R(f);
 	auto fail = [&](const char* what) { fclose(f); hu_set_error("%s: %s", path, what); return HU_ERR_IO; };
 	std::string abc, csSeq;
 	if(!R.str(abc)) return fail("no alphabet name");
@@ -269,19 +274,29 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 	};
 	/* the BWT symbols (WaveletTreeNoptrs::access, WaveletTreeNoptrs.cpp:301-323) */
 	std::vector<uint8_t> L(N);
+	std::atomic<int> bad{0};
 	par(N, 1 << 16, [&](size_t a, size_t e) {
 		for(size_t i = a; i < e; ++i) {
 			uint32_t ret = 0; size_t pos = i, start = 0;
 			for(uint32_t l = 0; l < height; ++l) {
+				if(pos >= wn || start > wn) { bad = 1; ret = 255; break; }      /* a damaged level or OCC table sends the walk out of the level */
 				const size_t before = start > 0 ? lev[l].rank1(start - 1) : 0;
 				const size_t r1 = lev[l].rank1(pos);
-				if(lev[l].get(pos)) { ret |= 1u << (height - l - 1); start = OCC[ret]; pos = r1 - 1 - before + start; }
-				else pos = (pos + 1 - r1) - 1 + before;
+				if(lev[l].get(pos)) { ret |= 1u << (height - l - 1); if(ret >= OCC.size() || r1 < 1 + before) { bad = 1; ret = 255; break; } start = OCC[ret]; pos = r1 - 1 - before + start; }
+				else { if(pos + 1 < r1) { bad = 1; ret = 255; break; } pos = (pos + 1 - r1) - 1 + before; }
 			}
 			L[i] = (uint8_t) ret;
 		}
 	});
+	if(bad) { hu_set_error("%s: the wavelet tree's levels and its OCC table do not fit together", path); return HU_ERR_IO; }
 	for(size_t i = 0; i < N; ++i) if(L[i] > 4) { hu_set_error("%s: symbol %d in the BWT", path, (int) L[i]); return HU_ERR_IO; }
+	{ /* C[] must be the running totals of the BWT's own symbol counts: then every LF step below lands inside [0, N) */
+		uint64_t cnt[5] = {0, 0, 0, 0, 0}, run = 0;
+		for(size_t i = 0; i < N; ++i) cnt[L[i]]++;
+		for(int c = 0; c <= 4; ++c) { if(Cc[c] < 0 || (uint64_t) Cc[c] != run) { hu_set_error("%s: the symbol counts C[] do not match the BWT", path); return HU_ERR_IO; } run += cnt[c]; }
+		if(Cc[5] < 0 || (uint64_t) Cc[5] != N || Cc[1] < 2) { hu_set_error("%s: the symbol counts C[] do not match the BWT", path); return HU_ERR_IO; }
+	}
+	for(size_t p = 0; p < N; ++p) if(c2cs[p] > csLen) { hu_set_error("%s: concat2CS names column %d of %d", path, (int) c2cs[p], (int) csLen); return HU_ERR_IO; }
 	/* occurrences of the four bases before every 64th row */
 	const size_t nb = N / 64 + 2;
 	std::vector<uint32_t> occ(nb * 4, 0);
@@ -293,10 +308,8 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 		return r;
 	};
 	const size_t nSeq = (size_t) Cc[1] - 1;              /* rows 0 .. C[1]-1 start with the symbol 0: the terminator + one separator per sequence */
-	if(Cc[0] != 0 || Cc[1] < 2 || (size_t) Cc[5] != N) return fail("inconsistent symbol counts");
 	std::vector<uint32_t> rowAt(N, 0xffffffffu);          /* rank of the suffix at every text position that holds a base */
 	std::vector<int64_t> sepOf(nSeq + 1, -1);             /* text position of the separator whose suffix is row j */
-	std::atomic<int> bad{0};
 	par(nSeq, 64, [&](size_t a, size_t e) {
 		std::vector<uint32_t> rows;
 		for(size_t j = a + 1; j <= e; ++j) {
@@ -325,7 +338,7 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 	ix->seedLen = seed_len; ix->csLen = csLen; ix->K = K;
 	ix->cs2p.assign((size_t) csLen + 2, 0);
 	for(int k = 1; k <= K; ++k) if(p2cs[k] >= 1 && p2cs[k] <= csLen) ix->cs2p[p2cs[k]] = k;
-	for(int i = p2cs[K] + 1; i <= csLen; ++i) ix->cs2p[i] = K;
+	for(int i = std::max(1, K >= 0 ? p2cs[K] + 1 : 1); i <= csLen; ++i) ix->cs2p[i] = K;
 	struct Ent { uint32_t row, pos; };
 	std::vector<Ent> ents;
 	size_t at = 0;
