@@ -396,9 +396,14 @@ def build_hmm(leaf_seq: np.ndarray, symfrac: float = 0.5, name: str = "synth") -
 
 def make_db(n_leaves: int, cs_len: int, model_name: str = "GTR", dg_k: int = 0, dg_alpha: float = 0.5,
             n_match: int | None = None, seed: int = 97, mean_blen: float = 0.05,
-            match_gap: float = 0.02, sparse_gap: float = 0.999, n_taxa: int = 8) -> SynthDB:
+            match_gap: float = 0.02, sparse_gap: float = 0.999, n_taxa: int = 8, pi=None) -> SynthDB:
+    """pi: base frequencies in place of the model file's (TN93 / HKY85 / F81 only) — e.g. two equal pairs, which makes the A and G
+    components of every all-gap column tie in exact arithmetic; such a database is for in-memory tests (its model text is not rewritten)."""
     rng = np.random.default_rng(seed)
     model = load_model(model_name)
+    if pi is not None:
+        assert model_name in ("TN93", "HKY85", "F81") and abs(sum(pi) - 1.0) < 1e-12
+        model = SubModel(model.name, np.asarray(pi, np.float64), model.par, "")
     parent, blen, is_leaf = make_tree(n_leaves, rng, mean_blen)
     n = len(parent)
     if dg_k > 0:
@@ -620,6 +625,7 @@ def write_ptu(db: SynthDB, path: str):
         f.write(struct.pack("<I", len(leaves)))
         for k, i in enumerate(leaves):
             f.write(struct.pack("<Iq", k, int(i)))
+        assert db.model.text, "a database made with pi= has no model text to write"
         f.write((db.model.name + "\n").encode()); f.write(db.model.text.encode())
         if not db.model.text.endswith("\n"):
             f.write(b"\n")

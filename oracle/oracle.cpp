@@ -129,10 +129,10 @@ int orc_place(void* tr, const int8_t* seq, int start, int end, int cNode, double
 	return p.iters;
 }
 
-struct OrcOpts { double maxDiff, maxHeight, maxError; int maxNSeed, weighted, onlyML, prior, tieMode, fixRootLoglik; };
+struct OrcOpts { double maxDiff, maxHeight, maxError; int maxNSeed, weighted, onlyML, prior, tieMode, fixRootLoglik; double tieTol; };
 static AssignOpts to_opts(const OrcOpts* o) {
 	AssignOpts a; a.maxDiff = o->maxDiff; a.maxHeight = o->maxHeight; a.maxError = o->maxError; a.maxNSeed = o->maxNSeed;
-	a.weighted = o->weighted; a.onlyML = o->onlyML; a.prior = o->prior; a.tieMode = o->tieMode; a.fixRootLoglik = o->fixRootLoglik; return a;
+	a.weighted = o->weighted; a.onlyML = o->onlyML; a.prior = o->prior; a.tieMode = o->tieMode; a.fixRootLoglik = o->fixRootLoglik; a.tieTol = o->tieTol; return a;
 }
 static void export_place(const Placement& p, int* ni, double* nd) {
 	ni[0] = p.cNode; ni[1] = p.pNode; ni[2] = p.aNode; ni[3] = p.iters;
@@ -243,7 +243,7 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			auto t2 = std::chrono::steady_clock::now();
 			loc[1] += std::chrono::duration<double>(t2 - t1).count();
 			std::vector<Placement> places;
-			for(const PTLoc& l : seeds) places.push_back(estimateSeq(*t, dseq.data(), l, opts.weighted != 0));
+			for(const PTLoc& l : seeds) places.push_back(estimateSeq(*t, dseq.data(), l, opts.weighted != 0, opts.tieTol));
 			filterPlacements(places, opts.maxError);
 			if(candNode) for(size_t k = 0; k < places.size() && k < 64; ++k) {
 				candNode[64 * (size_t) r + k] = places[k].cNode;

@@ -40,6 +40,16 @@ inline int argmax4(const double* v) { /* Eigen maxCoeff(&idx): first strict maxi
 	for(int i = 1; i < 4; ++i) if(v[i] > v[b]) b = i;
 	return b;
 }
+/* NOT the reference: the product's documented rule for components that tie in exact arithmetic — the first index
+ * whose value is within a relative `tol` (in linear space) of the maximum.  The reference takes the first STRICT maximum of values whose
+ * last bits depend on Eigen's summation order; where two components are mathematically equal (equal base frequencies) that order, not the
+ * data, picks the winner.  tests/ use this variant (AssignOpts::tieTol > 0) to tell such sites from real disagreements. */
+inline int argmax4_tol(const double* v, double tol) {
+	if(!(tol > 0)) return argmax4(v);
+	const double thr = max4(v) + std::log1p(-tol);
+	for(int i = 0; i < 3; ++i) if(v[i] >= thr) return i;
+	return 3;
+}
 inline double scale_of(double maxV) { return (maxV != NEG_INF && maxV < MIN_LOGLIK_EXP) ? MIN_LOGLIK_EXP - maxV : 0; }
 
 /* dot_product_scaled(Matrix4d, Vector4d) (src/PhyloTreeUnrooted.h:1495-1503) */
@@ -172,7 +182,7 @@ inline void inferWeight(const double* ll, double* w) {
 }
 
 /* PTUnrooted::estimateSeq (src/PhyloTreeUnrooted.cpp:849-877) */
-inline Placement estimateSeq(const Tree& t, const int8_t* seq, const PTLoc& loc, bool weighted) {
+inline Placement estimateSeq(const Tree& t, const int8_t* seq, const PTLoc& loc, bool weighted, double tieTol = 0) {
 	const int u = (int) loc.id, v = t.parent[u];
 	double cDist = loc.dist;
 	double pDist = pdist(t.S(v), seq, loc.start, loc.end);
@@ -190,7 +200,7 @@ inline Placement estimateSeq(const Tree& t, const int8_t* seq, const PTLoc& loc,
 		V4& r = R[j - loc.start];
 		for(int i = 0; i < 4; ++i) r.v[i] = a.v[i] + b.v[i];
 		V4 nl = leafLoglik(t, seq, j);
-		int b1 = argmax4(r.v), b2 = argmax4(nl.v);
+		int b1 = argmax4_tol(r.v, tieTol), b2 = argmax4(nl.v);
 		if(!weighted) { if(b1 != b2) d++; }
 		else {
 			double w1[4], w2[4]; inferWeight(r.v, w1); inferWeight(nl.v, w2);
@@ -390,6 +400,7 @@ struct AssignOpts {
 	int prior = 0;
 	int tieMode = TIE_STABLE;
 	int fixRootLoglik = 0;
+	double tieTol = 0;     /* > 0: argmax4_tol in estimateSeq (test aid, see there); 0 = the reference's rule */
 };
 
 /* the SEP part of the per-read task (src/hmmufotu.cpp:641-647,720-733); seq = DigitalSeq of
@@ -399,7 +410,7 @@ inline std::vector<Placement> assignSeq(const Tree& t, const int8_t* seq, int st
 	std::vector<PTLoc> seeds = getSeed(t, seq, start, end, o.maxDiff, o.maxHeight, o.tieMode, (size_t) o.maxNSeed);
 	if(seedsOut) *seedsOut = seeds;
 	std::vector<Placement> places;
-	for(const PTLoc& l : seeds) places.push_back(estimateSeq(t, seq, l, o.weighted != 0));
+	for(const PTLoc& l : seeds) places.push_back(estimateSeq(t, seq, l, o.weighted != 0, o.tieTol));
 	if(estOut) *estOut = places;
 	filterPlacements(places, o.maxError);
 	if(filtOut) { filtOut->clear(); for(const Placement& p : places) filtOut->push_back(p.cNode); }
@@ -435,7 +446,7 @@ inline ChimeraResult chimeraCheck(const Tree& t, const int8_t* seq, int start, i
 			PTLoc l; l.start = s0; l.end = e0; l.id = s.id;
 			pdist_counts(seq, t.S((int) s.id), s0, e0, l.d, l.N);
 			l.dist = static_cast<double>(l.d) / l.N;
-			segPlaces.push_back(estimateSeq(t, seq, l, o.weighted != 0));
+			segPlaces.push_back(estimateSeq(t, seq, l, o.weighted != 0, o.tieTol));
 		}
 		filterPlacements(segPlaces, maxChimeraError);
 		for(Placement& p : segPlaces) placeSeq(t, seq, p, o.maxHeight, o.fixRootLoglik != 0);
@@ -448,11 +459,11 @@ inline ChimeraResult chimeraCheck(const Tree& t, const int8_t* seq, int start, i
 	res.seg5 = seg5[0]; res.seg3 = seg3[0];
 	PTLoc a5; a5.start = res.seg5.start; a5.end = res.seg5.end; a5.id = res.seg3.cNode; /* seg3's branch, distance to seg5's own node */
 	pdist_counts(seq, t.S(res.seg5.cNode), a5.start, a5.end, a5.d, a5.N); a5.dist = static_cast<double>(a5.d) / a5.N;
-	res.alt5 = estimateSeq(t, seq, a5, o.weighted != 0);
+	res.alt5 = estimateSeq(t, seq, a5, o.weighted != 0, o.tieTol);
 	placeSeq(t, seq, res.alt5, o.maxHeight, o.fixRootLoglik != 0);
 	PTLoc a3; a3.start = res.seg3.start; a3.end = res.seg3.end; a3.id = res.seg5.cNode;
 	pdist_counts(seq, t.S(res.seg3.cNode), a3.start, a3.end, a3.d, a3.N); a3.dist = static_cast<double>(a3.d) / a3.N;
-	res.alt3 = estimateSeq(t, seq, a3, o.weighted != 0);
+	res.alt3 = estimateSeq(t, seq, a3, o.weighted != 0, o.tieTol);
 	placeSeq(t, seq, res.alt3, o.maxHeight, o.fixRootLoglik != 0);
 	res.lod = res.seg5.loglik - res.alt5.loglik + res.seg3.loglik - res.alt3.loglik;
 	res.isChimera = res.seg5.aNode != res.seg3.aNode && res.lod > minChimeraLod; /* getTaxonId() = aNode id (src/PhyloTreeUnrooted.h:430-435) */

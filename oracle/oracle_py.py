@@ -38,11 +38,11 @@ def _p(a, t):
 class OrcOpts(C.Structure):
     _fields_ = [("maxDiff", C.c_double), ("maxHeight", C.c_double), ("maxError", C.c_double),
                 ("maxNSeed", C.c_int), ("weighted", C.c_int), ("onlyML", C.c_int), ("prior", C.c_int), ("tieMode", C.c_int),
-                ("fixRootLoglik", C.c_int)]
+                ("fixRootLoglik", C.c_int), ("tieTol", C.c_double)]
 
 
 def default_opts(**kw):
-    o = OrcOpts(float("inf"), float("inf"), 20.0, 50, 0, 0, 0, 0, 0)
+    o = OrcOpts(float("inf"), float("inf"), 20.0, 50, 0, 0, 0, 0, 0, 0.0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
