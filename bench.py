@@ -38,8 +38,8 @@ def log(*a):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--leaves", type=int, default=int(os.environ.get("HU_BENCH_LEAVES", 99322)))
     ap.add_argument("--cs-len", type=int, default=7682)
     ap.add_argument("--read-len", type=int, default=250)
