@@ -5,6 +5,8 @@ oracle/_ref/libref_seq.so (`make -C oracle ref`) is the reference's alphabet, Di
   * DigitalSeq(abc, name, str)    == oracle digitize, character by character over the whole IUPAC / gap / junk range
   * SeqUtils::pDist             (SURVEY §8 a9: the inner function of getSeed) == the oracle's (d, N) counts for every node of a tree
   * PrimarySeq::revcom          == the read-side reverse complement used by the data tooling
+  * the head of a `.ptu` (SURVEY §8 a16: saveProgInfo / loadProgInfo, StringUtils::saveString / loadString, DigitalSeq::save / load) in
+    both directions against the product's writer and reader
 The library is built in the container that has /root/reference and travels with the tree (git-ignored, not gpurun-ignored)."""
 import ctypes as C
 import os
@@ -97,3 +99,78 @@ def test_engine_pairs_against_the_reference_pdist():
             ref = L.ref_pdist(q.ctypes.data_as(p8), row.ctypes.data_as(p8), db.cs_len, int(st[i]), int(en[i]))
             assert (np.isnan(ref) and N[node] == 0) or ref == d[node] / N[node]
     B.close(); D.close()
+
+
+def _ptu_head_api(L):
+    L.ref_ptu_head_write.restype = C.c_long
+    L.ref_ptu_head_write.argtypes = [C.c_long, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_long]
+    L.ref_ptu_head_read.restype = C.c_long
+    L.ref_ptu_head_read.argtypes = [C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                    C.c_void_p, C.c_void_p]
+    return L
+
+
+def _small_db():
+    from hmmufotu_amd import synth
+    db = synth.make_db(24, 160, "GTR", dg_k=4, seed=5)
+    db.names[3] = ""; db.annos[5] = ""; db.names[7] = "a name with spaces\tand a tab"       # empty and awkward strings
+    db.anno_dist = np.linspace(0.0, 0.3, db.n_nodes)
+    return db
+
+
+def test_ptu_head_written_by_the_product_is_read_by_the_reference_code(tmp_path):
+    """SURVEY §8 a16.  The head of a `.ptu` — program name + version, node count, csLen and every node record (id, name, DigitalSeq,
+    annotation, annotation distance) — written by the PRODUCT (hu_ptu_write) and read back by the reference's own loadProgInfo /
+    StringUtils::loadString / DigitalSeq::load (compiled from /root/reference, oracle/ref_seq_shim.cpp): every field equal, and the
+    reference code stops reading exactly where the edge block starts."""
+    from hmmufotu_amd import engine as E
+    L = _ptu_head_api(_ref())
+    db = _small_db()
+    n, cs = db.n_nodes, db.cs_len
+    p = str(tmp_path / "product.ptu")
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+    E.write_ptu(p, db.parent, db.blen, db.seq, db.up, db.down, db.height, md, model_text=db.model.text, names=db.names, annos=db.annos,
+                anno_dist=db.anno_dist, dg_alpha=db.dg_alpha, dg_breaks=db.dg_b)
+    nn, cl = C.c_long(0), C.c_int(0)
+    codes = np.full((n, cs), 99, np.int8); ad = np.zeros(n); sl = np.zeros(n, np.int64)
+    names = C.create_string_buffer(1 << 16); annos = C.create_string_buffer(1 << 16)
+    off = L.ref_ptu_head_read(p.encode(), C.byref(nn), C.byref(cl), codes.ctypes.data, codes.size, names, len(names), annos, len(annos),
+                              ad.ctypes.data, sl.ctypes.data)
+    assert off > 0, off                                                  # loadProgInfo accepted name and version
+    assert (nn.value, cl.value) == (n, cs) and (sl == cs).all()
+    assert np.array_equal(codes, db.seq) and np.array_equal(ad, db.anno_dist)
+    assert names.value.decode().split("\n")[:-1] == list(db.names) and annos.value.decode().split("\n")[:-1] == list(db.annos)
+    raw = open(p, "rb").read()
+    assert int.from_bytes(raw[off:off + 8], "little") == 2 * (n - 1)      # the edge count follows the last node record
+
+
+def test_ptu_head_written_by_the_reference_code_is_read_by_the_product(tmp_path):
+    """The other direction: saveProgInfo + StringUtils::saveString + DigitalSeq::save (the reference's code) write the head, the tail
+    (edges, root, heights, index, models: raw longs / doubles and the model text, whose format the reference's own data/*.sm files pin)
+    is taken from the Python writer; the product's reader (hu_db parse path, host only) must return every field.  The bytes of the two
+    heads are also compared: the Python writer, the native writer and the reference code agree byte for byte."""
+    from hmmufotu_amd import engine as E, synth
+    L = _ptu_head_api(_ref())
+    db = _small_db()
+    n, cs = db.n_nodes, db.cs_len
+    py = str(tmp_path / "py.ptu"); synth.write_ptu(db, py)
+    raw = open(py, "rb").read()
+    buf = C.create_string_buffer(len(raw))
+    names = (C.c_char_p * n)(*[s.encode() for s in db.names]); annos = (C.c_char_p * n)(*[s.encode() for s in db.annos])
+    seq = np.ascontiguousarray(db.seq, np.int8); ad = np.ascontiguousarray(db.anno_dist, np.float64)
+    k = L.ref_ptu_head_write(n, cs, seq.ctypes.data, names, annos, ad.ctypes.data, buf, len(raw))
+    assert k > 0
+    head = buf.raw[:k]
+    assert raw[:k] == head                                                # byte for byte
+    assert int.from_bytes(raw[k:k + 8], "little") == 2 * (n - 1)
+    mixed = str(tmp_path / "mixed.ptu")
+    open(mixed, "wb").write(head + raw[k:])
+    got = E.parse_files(None, mixed)
+    assert np.array_equal(got["seq"], db.seq) and np.array_equal(got["parent"], db.parent) and np.array_equal(got["up"], db.up)
+    # a node without a sequence (DigitalSeq of length 0): the record shrinks, the product reads the rest unharmed
+    seq2 = seq.copy(); seq2[4, :] = -128
+    k2 = L.ref_ptu_head_write(n, cs, seq2.ctypes.data, names, annos, ad.ctypes.data, buf, len(raw))
+    assert k2 == k - cs
+    open(mixed, "wb").write(buf.raw[:k2] + raw[k:])
+    got = E.parse_files(None, mixed)
+    assert np.array_equal(np.delete(got["seq"], 4, 0), np.delete(db.seq, 4, 0)) and np.array_equal(got["up"], db.up)
