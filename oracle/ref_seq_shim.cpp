@@ -103,4 +103,22 @@ long ref_ptu_head_read(const char* path, long* nNodes, int* csLen, int8_t* codes
 	memcpy(names, allNames.c_str(), allNames.size() + 1); memcpy(annos, allAnnos.c_str(), allAnnos.size() + 1);
 	return (long) in.tellg();
 }
+/* readProgInfo (src/util/ProgEnv.cpp:106-134) on the first line of an assignment file: 1 = accepted, 0 = refused;
+ * writeProgInfo (:101-104) into out */
+int ref_read_prog_info(const char* text) {
+	std::istringstream in(text);
+	std::streambuf* keep = std::cerr.rdbuf(nullptr);      /* the reference prints its refusal to stderr */
+	int rc;
+	try { EGriceLab::readProgInfo(in); rc = in.bad() ? 0 : 1; } catch(...) { rc = -1; }      /* VersionSequence may throw on a malformed version */
+	std::cerr.rdbuf(keep);
+	return rc;
+}
+int ref_write_prog_info(const char* info, char* out, int cap) {
+	std::ostringstream o;
+	EGriceLab::writeProgInfo(o, info);
+	const std::string b = o.str();
+	if((int) b.size() >= cap) return -1;
+	memcpy(out, b.c_str(), b.size() + 1);
+	return (int) b.size();
+}
 }

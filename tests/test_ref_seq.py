@@ -174,3 +174,39 @@ def test_ptu_head_written_by_the_reference_code_is_read_by_the_product(tmp_path)
     open(mixed, "wb").write(buf.raw[:k2] + raw[k:])
     got = E.parse_files(None, mixed)
     assert np.array_equal(np.delete(got["seq"], 4, 0), np.delete(db.seq, 4, 0)) and np.array_equal(got["up"], db.up)
+
+
+def test_assignment_file_header_against_the_reference_readproginfo():
+    """SURVEY §8 f4.  The first line of the CLI's TSV (committed sample written by hmmufotu-amd on the GPU box) and the Python restatement
+    of the consumers' header check (tests/tsv_consumers.py) against the reference's own readProgInfo / writeProgInfo (src/util/ProgEnv.cpp)."""
+    import tsv_consumers as T
+    L = _ref()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    first = open(os.path.join(gold, "cli_sampleA.tsv")).readline()
+    assert L.ref_read_prog_info(first.encode()) == 1                                   # hmmufotu-sum / -jplace would read on
+    buf = C.create_string_buffer(4096)
+    k = L.ref_write_prog_info(b" taxonomy assignment generated by ", buf, len(buf))     # hmmufotu.cpp:590 + argv[0]
+    assert k > 0 and first.startswith(buf.value.decode().rstrip("\n"))
+    for line in ("# HmmUFOtu v1.5.1 taxonomy assignment generated by hmmufotu", "# HmmUFOtu v1.4.0 x", "# HmmUFOtu v1.5.0", "# HmmUFOtu v1.5.2 x",
+                 "# hmmufotu_amd v0.1.0 x", "# HmmUFOtu v1.6.0 x", "# HmmUFOtu v2.0.0 x", "id\tdescription", "# HmmUFOtu", "#HmmUFOtu v1.5.1",
+                 "# HmmUFOtu v1.5 x", "# HmmUFOtu 1.5.1 x", "# HmmUFOtu v0.0.0 x", ""):
+        try:
+            T.read_prog_info(line); mine = 1
+        except ValueError:
+            mine = 0
+        try:
+            ref = L.ref_read_prog_info(line.encode())
+        except Exception:
+            ref = -1
+        assert mine == ref, (line, mine, ref)
+    rng = np.random.default_rng(4)
+    for _ in range(400):                                       # random program names, separators and version strings
+        name = rng.choice(["HmmUFOtu", "HmmUFOtu", "hmmufotu", "HmmUFOtu2", "X"])
+        ver = rng.choice(["v%d.%d.%d", "v%d.%d.%d", "V%d.%d.%d", "%d.%d.%d", "v%d.%d", "v%d.%d.%d-rc1", "v%d.%d.%d.7"])
+        ver = ver % tuple(int(x) for x in rng.integers(0, 12, size=ver.count("%d")))
+        line = "#" + str(rng.choice(["", " ", "  ", "\t"])) + name + str(rng.choice([" ", "  ", "\t"])) + ver + str(rng.choice(["", " tail", "\ttail"]))
+        try:
+            T.read_prog_info(line); mine = 1
+        except ValueError:
+            mine = 0
+        assert mine == L.ref_read_prog_info(line.encode()), line

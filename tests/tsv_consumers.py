@@ -26,13 +26,27 @@ def c_atof(s):
 
 def read_prog_info(line):
     """sscanf(header, "# %s %s", pname, ver); progName == pname; progVer >= VersionSequence(ver) ("v%d.%d.%d")"""
-    m = re.match(r"# (\S+) (\S+)", line)
+    m = re.match(r"#\s*(\S+)\s+(\S+)", line)          # a blank in a scanf format matches any run of white space, an empty one included
     if not m:
         raise ValueError("Unrecognized input file for " + PROG_NAME)
     if m.group(1) != PROG_NAME:
         raise ValueError("Not an valid input file of " + PROG_NAME)
-    v = re.match(r"v(\d+)\.(\d+)\.(\d+)", m.group(2))
-    ver = tuple(int(x) for x in v.groups()) if v else (0, 0, 0)
+    # VersionSequence::parseString (src/util/VersionSequence.cpp:56-58): sscanf(str, "v%d.%d.%d") into a (0, 0, 0) object — the
+    # numbers converted before the first mismatch stay ("v10.2" is 10.2.0, "1.5.1" is 0.0.0); %d takes a sign
+    ver = [0, 0, 0]
+    rest = m.group(2)
+    if rest[:1] == "v":
+        rest = rest[1:]
+        for k in range(3):
+            d = re.match(r"[+-]?\d+", rest)
+            if not d:
+                break
+            ver[k] = int(d.group(0)); rest = rest[d.end():]
+            if k < 2:
+                if rest[:1] != ".":
+                    break
+                rest = rest[1:]
+    ver = tuple(ver)
     if not PROG_VER >= ver:
         raise ValueError("file written by a newer version")
     return ver
