@@ -108,22 +108,35 @@ def _run_stages(E, db, reads, vps, opts, mode=0, mates=None, mvps=None):
     return D, B
 
 
+LONG_DB = dict(n_leaves=60, cs_len=1800, db_kw=dict(n_match=1400))      # leaves of ~1,370 bases: full-length 16S reads
+
+
 @pytest.mark.parametrize("cfg", [dict(model="GTR", dg_k=4, read_len=150), dict(model="JC69", dg_k=0, read_len=100),
-                                 dict(model="TN93", dg_k=4, read_len=250)])
+                                 dict(model="TN93", dg_k=4, read_len=250),
+                                 # reads longer than the 512 rows the wave kernels hold: 600 bp, and (nearly) the whole gene
+                                 dict(model="GTR", dg_k=4, read_len=600, n_reads=16, **LONG_DB),
+                                 dict(model="GTR", dg_k=4, read_len=1300, n_reads=8, **LONG_DB)])
 def test_align_parity(cfg):
     E = _engine()
-    db = get_db(120, 700 if cfg["read_len"] < 200 else 1400, cfg["model"], dg_k=cfg["dg_k"])
+    if "db_kw" in cfg:
+        db = get_db(cfg["n_leaves"], cfg["cs_len"], cfg["model"], dg_k=cfg["dg_k"], **cfg["db_kw"])
+    else:
+        db = get_db(120, 700 if cfg["read_len"] < 200 else 1400, cfg["model"], dg_k=cfg["dg_k"])
     _, H, _ = oracle_objects(db)
-    reads, vps = sim_reads(db, 48, cfg["read_len"])
+    reads, vps = sim_reads(db, cfg.get("n_reads", 48), cfg["read_len"])
     # exercise: no seed at all (full DP), one seed only, both seeds
     vps = vps.copy(); vps[0] = 0; vps[1, 1] = 0; vps[2, 0] = vps[2, 1]; vps[2, 1] = 0
-    opts = E.default_opts()
-    D, B = _run_stages(E, db, reads, vps, opts)
-    out = B.alignments(want_align=True, want_trace=True, trace_stride=db.hmm.K + 400)
-    cd, st, en = B.codes()
+    _check_alignments(E, db, H, [r.seq for r in reads], vps)
+
+
+def _check_alignments(E, db, H, seqs, vps):
     from oracle import oracle_py as O
-    for i, r in enumerate(reads):
-        a = H.align(r.seq, vps[i])
+    opts = E.default_opts()
+    D, B = _run_stages(E, db, seqs, vps, opts)
+    out = B.alignments(want_align=True, want_trace=True, trace_stride=db.hmm.K + max(len(s) for s in seqs) + 400)
+    cd, st, en = B.codes()
+    for i, seq in enumerate(seqs):
+        a = H.align(seq, vps[i])
         rec = out["recs"][i]
         assert a["ok"] and rec["status"] == 1, i
         assert (rec["seq_start"], rec["seq_end"], rec["hmm_start"], rec["hmm_end"], rec["cs_start"], rec["cs_end"]) == \
@@ -136,6 +149,31 @@ def test_align_parity(cfg):
         assert (cd[i] == ds).all(), i
         assert st[i] == a["csStart"] - 1 and en[i] == a["csEnd"] - 1
     B.close(); D.close()
+
+
+def test_reads_longer_than_the_profile():
+    """A read with more bases than the profile has match states (K = 1,400): 1,300 bases of a leaf followed by 700 random ones (an
+    unclipped adapter / chimeric tail), with its 5' seed only, with none (full DP over 2,000 x 1,400 cells), and a short real read in
+    front of a long tail; and a batch that mixes such reads with ordinary 150-base ones (ragged lengths in one launch)."""
+    E = _engine()
+    db = get_db(LONG_DB["n_leaves"], LONG_DB["cs_len"], "GTR", dg_k=4, **LONG_DB["db_kw"])
+    _, H, _ = oracle_objects(db)
+    rng = np.random.default_rng(17)
+    long_reads, lvps = sim_reads(db, 4, 1300)
+    short_reads, svps = sim_reads(db, 6, 150)
+    tail = lambda n: "".join(rng.choice(list("ACGT"), size=n))
+    seqs, vps = [], []
+    for k, r in enumerate(long_reads):
+        seqs.append(r.seq + tail(700)); v = lvps[k].copy(); v[1] = 0      # the 3' seed would sit in the random tail: not found
+        if k == 3:
+            v[:] = 0                                                      # no seed at all
+        vps.append(v)
+    for k, r in enumerate(short_reads):
+        seqs.append(r.seq if k % 2 else r.seq + tail(900)); v = svps[k].copy()
+        if k % 2 == 0:
+            v[1] = 0
+        vps.append(v)
+    _check_alignments(E, db, H, seqs, np.stack(vps))
 
 
 def test_hbm_staged_viterbi_kernel(monkeypatch):
@@ -277,7 +315,10 @@ def test_pe_merge_parity():
                                  dict(model="TN93", dg_k=3, n_leaves=100, cs_len=700, read_len=100, db_kw=dict(pi=(0.35, 0.15, 0.35, 0.15))),
                                  # 5,199 nodes = 21 blocks of 256 >= 2 x max_nseed: the distance-only scan and its top-k (the gg_97-scale path)
                                  dict(model="GTR", dg_k=4, n_leaves=2600, cs_len=300, read_len=100, max_nseed=10, n_reads=24, db_kw=dict(n_match=200)),
-                                 dict(model="HKY85", dg_k=0, n_leaves=2600, cs_len=700, read_len=300, max_nseed=8, n_reads=12, db_kw=dict(n_match=450))])
+                                 dict(model="HKY85", dg_k=0, n_leaves=2600, cs_len=700, read_len=300, max_nseed=8, n_reads=12, db_kw=dict(n_match=450)),
+                                 # full-length reads: > 256 base sites and > 1,536 region columns per read (the kernels without split slots)
+                                 dict(model="GTR", dg_k=4, read_len=600, n_reads=12, **LONG_DB),
+                                 dict(model="GTR", dg_k=4, read_len=1300, n_reads=8, **LONG_DB)])
 def test_sep_parity(cfg):
     """seed scan, top-k, estimate, filter, place, q-values vs the oracle, stage by stage."""
     E = _engine()
