@@ -98,7 +98,8 @@ static void usage(const char* p) {
 		"            -C|--chimera  --num-segment INT [2]  --chimera-err DBL [-e / --num-segment]  --chimera-lod DBL [0]\n"
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
-		"            --inflight INT [3] batches in flight per device  -v  -h|--help\n";
+		"            --inflight INT [3] batches in flight per device  -v  --version  -h|--help\n"
+		"            -S|--seed INT and -p|--process INT are accepted and have no effect (seed hits are deterministic; host threads follow the batches in flight)\n";
 }
 #define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
 
@@ -123,6 +124,7 @@ int main(int argc, char** argv) {
 		std::string a = argv[i];
 		auto val = [&]() -> const char* { if(i + 1 >= argc) { std::cerr << "Error: option " << a << " needs a value\n"; exit(EXIT_FAILURE); } return argv[++i]; };
 		if(a == "-h" || a == "--help") { usage(argv[0]); return EXIT_SUCCESS; }
+		else if(a == "--version") { std::cerr << argv[0] << ": v1.5.1\nPackage: HmmUFOtu v1.5.1 (file formats and assignment semantics; hmmufotu_amd engine for gfx950)" << std::endl; return EXIT_SUCCESS; }   /* printVersion, src/util/ProgEnv.cpp:19-22 */
 		else if(a == "-o") outFn = val();
 		else if(a == "-L" || a == "--seed-len") seedLen = atoi(val());
 		else if(a == "-R") seedRegion = atoi(val());
