@@ -23,27 +23,8 @@
 #include <thread>
 #include <zlib.h>
 #include "../../include/hmmufotu_amd.h"
+#include "hu_reads_io.h"
 
-struct Read { std::string id, desc, seq; };
-
-/* line reader over zlib: plain and gzip-compressed inputs alike (the reference reads .gz / .bz2 through boost::iostreams) */
-struct LineIn {
-	gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
-	bool open(const std::string& fn) { f = gzopen(fn.c_str(), "rb"); if(f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr; }
-	~LineIn() { if(f) gzclose(f); }
-	bool fill() { if(eof) return false; const int k = gzread(f, buf.data(), (unsigned) buf.size()); pos = 0; len = k > 0 ? (size_t) k : 0; if(k <= 0) eof = true; return k > 0; }
-	int peek() { if(pos >= len && !fill()) return EOF; return (unsigned char) buf[pos]; }
-	bool getline(std::string& s) {
-		s.clear();
-		if(pos >= len && !fill()) return false;
-		for(;;) {
-			const char* b = buf.data() + pos; const char* e = (const char*) memchr(b, '\n', len - pos);
-			if(e) { s.append(b, e - b); pos += (size_t)(e - b) + 1; return true; }
-			s.append(b, len - pos); pos = len;
-			if(!fill()) return true;
-		}
-	}
-};
 /* writer: gzip when the file name ends in .gz */
 struct LineOut {
 	gzFile z = nullptr; std::ofstream f; bool on = false;
@@ -57,29 +38,6 @@ struct LineOut {
 	~LineOut() { if(z) gzclose(z); }
 };
 
-static bool next_read(LineIn& in, bool fastq, Read& r) {
-	std::string line;
-	r = Read();
-	bool got = false;
-	if(fastq) {
-		while((got = in.getline(line))) if(!line.empty() && line[0] == '@') break;
-		if(!got || line.empty() || line[0] != '@') return false;
-		std::string q, plus;
-		if(!in.getline(r.seq) || !in.getline(plus) || !in.getline(q)) return false;
-	}
-	else {
-		while((got = in.getline(line))) if(!line.empty() && line[0] == '>') break;
-		if(!got || line.empty() || line[0] != '>') return false;
-		while(in.peek() != EOF && in.peek() != '>') { std::string s; in.getline(s); while(!s.empty() && (s.back() == '\r' || s.back() == ' ')) s.pop_back(); r.seq += s; }
-	}
-	while(!line.empty() && line.back() == '\r') line.pop_back();
-	const size_t sp = line.find_first_of(" \t");
-	r.id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-	if(sp != std::string::npos) r.desc = line.substr(sp + 1);
-	while(!r.seq.empty() && (r.seq.back() == '\r' || r.seq.back() == '\n')) r.seq.pop_back();
-	for(char& c : r.seq) c = (char) toupper((unsigned char) c);
-	return true;
-}
 static std::string revcom(const std::string& s) { /* IUPACNucl complements (src/IUPACNucl.cpp:52-71) */
 	std::string r(s.rbegin(), s.rend());
 	for(char& c : r) switch(c) {

@@ -1,0 +1,62 @@
+// Reading FASTA / FASTQ read files (plain or gzip) for the hmmufotu-amd CLI: the counterpart of the reference's SeqIO
+// (src/SeqIO.cpp:75-119: nextFastaSeq / nextFastqSeq) over zlib.  Header-only so that tests/test_ref_seq.py can drive it on the CPU
+// (tests/san/reads_driver.cpp) beside the reference's own SeqIO compiled from /root/reference.
+//   id   = the first word after the tag, desc = the rest of the header line without the blanks between them (SeqIO.cpp:83-87)
+//   FASTA sequence = the following lines up to the next line that starts with '>', joined; FASTQ = exactly four lines per record
+// Deliberate differences: a trailing '\r' (and trailing blanks of a FASTA line) are dropped — the reference's PrimarySeq constructor throws
+// on them and the program ends; blank lines BEFORE a record are skipped (the reference stops reading there); bases are upper-cased here
+// (the reference keeps the case and upper-cases when it encodes, src/DigitalSeq.cpp:41-48).
+#pragma once
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+struct Read { std::string id, desc, seq; };
+
+/* line reader over zlib: plain and gzip-compressed inputs alike (the reference reads .gz / .bz2 through boost::iostreams) */
+struct LineIn {
+	gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+	bool open(const std::string& fn) { f = gzopen(fn.c_str(), "rb"); if(f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr; }
+	~LineIn() { if(f) gzclose(f); }
+	bool fill() { if(eof) return false; const int k = gzread(f, buf.data(), (unsigned) buf.size()); pos = 0; len = k > 0 ? (size_t) k : 0; if(k <= 0) eof = true; return k > 0; }
+	int peek() { if(pos >= len && !fill()) return EOF; return (unsigned char) buf[pos]; }
+	bool getline(std::string& s) {
+		s.clear();
+		if(pos >= len && !fill()) return false;
+		for(;;) {
+			const char* b = buf.data() + pos; const char* e = (const char*) memchr(b, '\n', len - pos);
+			if(e) { s.append(b, e - b); pos += (size_t)(e - b) + 1; return true; }
+			s.append(b, len - pos); pos = len;
+			if(!fill()) return true;
+		}
+	}
+};
+static bool next_read(LineIn& in, bool fastq, Read& r) {
+	std::string line;
+	r = Read();
+	bool got = false;
+	if(fastq) {
+		while((got = in.getline(line))) if(!line.empty() && line[0] == '@') break;
+		if(!got || line.empty() || line[0] != '@') return false;
+		std::string q, plus;
+		if(!in.getline(r.seq) || !in.getline(plus) || !in.getline(q)) return false;
+	}
+	else {
+		while((got = in.getline(line))) if(!line.empty() && line[0] == '>') break;
+		if(!got || line.empty() || line[0] != '>') return false;
+		while(in.peek() != EOF && in.peek() != '>') { std::string s; in.getline(s); while(!s.empty() && (s.back() == '\r' || s.back() == ' ')) s.pop_back(); r.seq += s; }
+	}
+	while(!line.empty() && line.back() == '\r') line.pop_back();
+	/* id = the first word after the tag (operator>> skips blanks before it), desc = the rest of the line after the blanks that follow the id */
+	auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f' || c == '\r'; };
+	size_t a = 1; while(a < line.size() && blank(line[a])) ++a;
+	size_t e = a; while(e < line.size() && !blank(line[e])) ++e;
+	r.id = line.substr(a, e - a);
+	while(e < line.size() && blank(line[e])) ++e;
+	r.desc = line.substr(e);
+	while(!r.seq.empty() && (r.seq.back() == '\r' || r.seq.back() == '\n')) r.seq.pop_back();
+	for(char& c : r.seq) c = (char) toupper((unsigned char) c);
+	return true;
+}

@@ -13,6 +13,7 @@
 #include "DigitalSeq.h"
 #include "PrimarySeq.h"
 #include "SeqUtils.h"
+#include "SeqIO.h"
 using namespace EGriceLab::HmmUFOtu;
 
 extern "C" {
@@ -120,5 +121,23 @@ int ref_write_prog_info(const char* info, char* out, int cap) {
 	if((int) b.size() >= cap) return -1;
 	memcpy(out, b.c_str(), b.size() + 1);
 	return (int) b.size();
+}
+/* SeqIO (src/SeqIO.cpp:75-119) over a file: records as id \x1f desc \x1f seq \n into out; returns the number of records, -1 when
+ * the reference throws (PrimarySeq refuses a character), -2 when out is too small */
+long ref_seqio_read(const char* path, const char* fmt, char* out, long cap) {
+	std::ifstream in(path);
+	if(!in) return -3;
+	std::string all; long n = 0;
+	try {
+		SeqIO io(&in, AlphabetFactory::nuclAbc, fmt);
+		while(io.hasNext()) {
+			const PrimarySeq s = io.nextSeq();
+			all += s.getId(); all += '\x1f'; all += s.getDesc(); all += '\x1f'; all += s.getSeq(); all += '\n';
+			++n;
+		}
+	} catch(...) { return -1; }
+	if((long) all.size() >= cap) return -2;
+	memcpy(out, all.c_str(), all.size() + 1);
+	return n;
 }
 }

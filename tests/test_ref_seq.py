@@ -210,3 +210,81 @@ def test_assignment_file_header_against_the_reference_readproginfo():
         except ValueError:
             mine = 0
         assert mine == L.ref_read_prog_info(line.encode()), line
+
+
+@pytest.fixture(scope="module")
+def reads_driver(tmp_path_factory):
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("rd") / "reads_driver")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I" + os.path.join(root, "hmmufotu_amd", "csrc"), "-o", exe, os.path.join(root, "tests", "san", "reads_driver.cpp"), "-lz"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def _product_reads(exe, fmt, path):
+    import subprocess
+    r = subprocess.run([exe, fmt, str(path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [tuple(l.split("\x1f")) for l in r.stdout.split("\n")[:-1]]
+
+
+def _reference_reads(L, fmt, path):
+    L.ref_seqio_read.restype = C.c_long
+    buf = C.create_string_buffer(1 << 20)
+    n = L.ref_seqio_read(str(path).encode(), fmt.encode(), buf, len(buf))
+    if n < 0:
+        return n
+    recs = [tuple(l.split("\x1f")) for l in buf.value.decode().split("\n")[:-1]]
+    assert len(recs) == n
+    return recs
+
+
+def test_read_files_against_the_reference_seqio(tmp_path, reads_driver):
+    """The CLI's FASTA / FASTQ reader (hu_reads_io.h, under the sanitizers) and the reference's SeqIO on the same files: ids, descriptions
+    and sequences equal (the product upper-cases; the reference upper-cases later, when it encodes).  Then the documented differences:
+    where the reference ends the program (a '\\r' or a blank inside a sequence: PrimarySeq throws) or stops reading (a blank line between
+    records), the product reads on."""
+    L = _ref()
+    rng = np.random.default_rng(3)
+    seq = lambda n: "".join(rng.choice(list("ACGTacgtNRYKMSWBDHVU"), size=n))
+    fa = tmp_path / "a.fasta"
+    recs = [("r1", "", seq(70)), ("r2", "a description  with   blanks", seq(150)), ("r3|x:1", "tab\tin desc", seq(1)), ("r4", "", seq(300)), ("r5", "d", "")]
+    with open(fa, "w") as f:
+        f.write(">r1\n%s\n" % recs[0][2])
+        f.write(">r2 a description  with   blanks\n" + "".join(recs[1][2][i:i + 60] + "\n" for i in range(0, 150, 60)))     # wrapped at 60
+        f.write(">r3|x:1\t tab\tin desc\n%s\n" % recs[2][2])                                                               # tab + blank after the id
+        f.write(">r4   \n" + "".join(recs[3][2][i:i + 7] + "\n" for i in range(0, 300, 7)))                                 # blanks after the id, no description
+        f.write(">r5 d\n")                                                                                                 # a record without a sequence, last line
+    ref = _reference_reads(L, "fasta", fa)
+    assert ref == [(i, d, s) for i, d, s in recs]
+    assert _product_reads(reads_driver, "fasta", fa) == [(i, d, s.upper()) for i, d, s in ref]
+    fq = tmp_path / "a.fastq"
+    qrecs = [("q1", "1:N:0:1", seq(100)), ("q2", "", seq(33)), ("@odd", "x", seq(5))]
+    with open(fq, "w") as f:
+        for i, d, s in qrecs:
+            f.write("@%s%s\n%s\n+%s\n%s\n" % (i, " " + d if d else "", s, i if i == "q1" else "", "I" * len(s)))
+    ref = _reference_reads(L, "fastq", fq)
+    assert ref == qrecs
+    assert _product_reads(reads_driver, "fastq", fq) == [(i, d, s.upper()) for i, d, s in ref]
+    # no newline at the end of the file
+    nf = tmp_path / "nonl.fasta"; nf.write_text(">x y\nACGT\nAC")
+    assert _reference_reads(L, "fasta", nf) == [("x", "y", "ACGTAC")] == _product_reads(reads_driver, "fasta", nf)
+    # ---- documented differences ----
+    cr = tmp_path / "crlf.fasta"; cr.write_bytes(b">w1 dos file\r\nACGT\r\nAC\r\n>w2\r\nGG\r\n")
+    assert _reference_reads(L, "fasta", cr) == -1                                    # PrimarySeq throws on '\r': the reference program ends
+    assert _product_reads(reads_driver, "fasta", cr) == [("w1", "dos file", "ACGTAC"), ("w2", "", "GG")]
+    bl = tmp_path / "blank.fasta"; bl.write_text(">b1\nACGT\n\n>b2\nGG\n")
+    assert _reference_reads(L, "fasta", bl) == [("b1", "", "ACGT"), ("b2", "", "GG")]  # a blank line INSIDE a record is an empty line of sequence
+    assert _product_reads(reads_driver, "fasta", bl) == [("b1", "", "ACGT"), ("b2", "", "GG")]
+    lead = tmp_path / "lead.fasta"; lead.write_text("\n>c1\nAC\n")
+    assert _reference_reads(L, "fasta", lead) == []                                  # hasNext() sees '\n', not '>': nothing is read
+    assert _product_reads(reads_driver, "fasta", lead) == [("c1", "", "AC")]
+    gz = tmp_path / "a.fasta.gz"
+    import gzip
+    gz.write_bytes(gzip.compress(fa.read_bytes()))
+    assert _product_reads(reads_driver, "fasta", gz) == _product_reads(reads_driver, "fasta", fa)
