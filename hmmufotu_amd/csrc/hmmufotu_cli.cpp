@@ -38,14 +38,6 @@ struct LineOut {
 	~LineOut() { if(z) gzclose(z); }
 };
 
-static std::string revcom(const std::string& s) { /* IUPACNucl complements (src/IUPACNucl.cpp:52-71) */
-	std::string r(s.rbegin(), s.rend());
-	for(char& c : r) switch(c) {
-		case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'U': c = 'A'; break;
-		case 'Y': c = 'R'; break; case 'R': c = 'Y'; break; case 'K': c = 'M'; break; case 'M': c = 'K'; break;
-		case 'B': c = 'V'; break; case 'V': c = 'B'; break; case 'D': c = 'H'; break; case 'H': c = 'D'; break; default: break; }
-	return r;
-}
 static void usage(const char* p) {
 	std::cerr << "Usage:    " << p << "  <HmmUFOtu-DB> <READ-FILE1> [READ-FILE2] [options]\n"
 		"Options:    -o FILE  -L|--seed-len INT [20]  -R INT [50]  --single  -s|--strand INT [0]  -t|--test INT [100]\n"

@@ -60,3 +60,11 @@ static bool next_read(LineIn& in, bool fastq, Read& r) {
 	for(char& c : r.seq) c = (char) toupper((unsigned char) c);
 	return true;
 }
+static std::string revcom(const std::string& s) { /* IUPACNucl complements (src/IUPACNucl.cpp:52-71) */
+	std::string r(s.rbegin(), s.rend());
+	for(char& c : r) switch(c) {
+		case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'U': c = 'A'; break;
+		case 'Y': c = 'R'; break; case 'R': c = 'Y'; break; case 'K': c = 'M'; break; case 'M': c = 'K'; break;
+		case 'B': c = 'V'; break; case 'V': c = 'B'; break; case 'D': c = 'H'; break; case 'H': c = 'D'; break; default: break; }
+	return r;
+}

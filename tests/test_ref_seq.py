@@ -288,3 +288,15 @@ def test_read_files_against_the_reference_seqio(tmp_path, reads_driver):
     import gzip
     gz.write_bytes(gzip.compress(fa.read_bytes()))
     assert _product_reads(reads_driver, "fasta", gz) == _product_reads(reads_driver, "fasta", fa)
+
+
+def test_cli_revcom_is_the_reference_revcom(reads_driver):
+    """the mate of a pair is reverse-complemented before it is aligned (src/hmmufotu.cpp:609: revSeqI.nextSeq().revcom())"""
+    import subprocess
+    L = _ref()
+    rng = np.random.default_rng(9)
+    for s in ["ACGTUNRYMKSWBDHV", "A", "".join(rng.choice(list("ACGTUNRYMKSWBDHV"), size=301))]:
+        out = C.create_string_buffer(len(s) + 8)
+        assert L.ref_revcom(s.encode(), out, len(out)) == len(s)
+        mine = subprocess.run([reads_driver, "revcom", s], capture_output=True, text=True)
+        assert mine.returncode == 0 and mine.stdout.strip() == out.value.decode(), s
