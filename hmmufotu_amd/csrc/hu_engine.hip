@@ -722,6 +722,7 @@ struct HuKnobs {
 	int est_var = 0, place_var = 0;             /* alternative kernel variants (comparison / diagnostics)            */
 	int place_nosplit = 0;       /* column-order placement kernel even when the gap / base split applies             */
 	int place_em1 = 0;           /* k_place_w1: the EM of a branch on one wave (0: k_place_blk, EM steps across both waves) */
+	int place_lds_pad = 0;       /* KB of unused dynamic LDS per placement workgroup: fewer of them per CU (experiment) */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
@@ -731,7 +732,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"trace", &HuKnobs::trace},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1576,7 +1577,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 					if(S == 8 && em1) k_place_w1<8, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
 					else if(em1) k_place_w1<12, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
 					else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
-					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, (size_t)(b->knob.place_lds_pad > 0 && b->knob.place_lds_pad <= 44 ? b->knob.place_lds_pad : 0) * 1024, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 				}
 				else if(S == 8 && b->knob.place_em1) k_place_w1<8, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
 				else if(b->knob.place_em1) k_place_w1<12, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
