@@ -1391,3 +1391,48 @@ def test_build_database_on_device_and_write_it(tmp_path):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert np.allclose(outs[0]["ratio"], outs[1]["ratio"], rtol=1e-9, atol=1e-12)      # device-evaluated vs numpy-evaluated messages: 1e-9 apart
     D1.close(); D2.close()
+
+
+def test_align_with_misplaced_and_overlapping_seeds():
+    """Seed paths as a real index returns them on repeats and low-complexity reads: shifted off the true diagonal, with wrong insert / delete
+    counts, the 3' seed upstream of the 5' seed, the two seeds overlapping or identical, seeds touching the first / last profile column or
+    read base.  Any path with 0 < start <= end <= K and 0 < from <= to <= L is accepted by the reference (src/BandedHMMP7.cpp:773-892): the
+    band geometry, the phases rewriting each other's cells and the fall back to the full DP must come out as in the oracle, bit for bit."""
+    E = _engine()
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, _ = oracle_objects(db)
+    K = db.hmm.K
+    reads, vps0 = sim_reads(db, 64, 150)
+    rng = np.random.default_rng(23)
+    seqs, vps = [], []
+    for i, r in enumerate(reads):
+        L = len(r.seq)
+        v = vps0[i].copy()
+        kind = i % 8
+        for p in range(2):
+            if v[p, 0] == 0:
+                continue
+            if kind == 0:                      # shifted along the profile: off the true diagonal by up to 25 columns
+                sh = int(rng.integers(-25, 26)); v[p, 0] += sh; v[p, 1] += sh
+            elif kind == 1:                    # shifted along the read
+                sh = int(rng.integers(-10, 11)); v[p, 2] += sh; v[p, 3] += sh
+            elif kind == 2:                    # wrong gap counts: a band much wider / narrower than the path
+                v[p, 4] = int(rng.integers(0, 30)); v[p, 5] = int(rng.integers(0, 30))
+            elif kind == 3:                    # a longer path on the profile than on the read and the other way round
+                v[p, 1] += int(rng.integers(0, 15)); v[p, 3] += int(rng.integers(0, 6))
+        if kind == 4 and v[1, 0] > 0:          # 3' seed first
+            v = v[::-1].copy()
+        if kind == 5 and v[1, 0] > 0:          # overlapping seeds: the second starts inside the first
+            v[1] = v[0]; v[1, 0] += 5; v[1, 1] += 5; v[1, 2] += 5; v[1, 3] += 5
+        if kind == 6:                          # at the edges of the profile and of the read
+            v[0] = [1, 20, 1, 20, 0, 0]; v[1] = [K - 19, K, L - 19, L, 0, 0]
+        if kind == 7 and v[1, 0] > 0:          # the same seed twice
+            v[1] = v[0]
+        for p in range(2):                     # keep what the reference would accept; anything else means "no seed"
+            s, e, f, t, ni, nd = (int(x) for x in v[p])
+            if not (0 < s <= e <= K and 0 < f <= t <= L and ni >= 0 and nd >= 0):
+                v[p] = 0
+        if v[0, 0] == 0 and v[1, 0] != 0:
+            v[0] = v[1]; v[1] = 0
+        seqs.append(r.seq); vps.append(v)
+    _check_alignments(E, db, H, seqs, np.stack(vps))
