@@ -723,6 +723,7 @@ struct HuKnobs {
 	int place_nosplit = 0;       /* column-order placement kernel even when the gap / base split applies             */
 	int place_em1 = 0;           /* k_place_w1: the EM of a branch on one wave (0: k_place_blk, EM steps across both waves) */
 	int place_lds_pad = 0;       /* KB of unused dynamic LDS per placement workgroup: fewer of them per CU (experiment) */
+	int est_lds_pad = 0;         /* the same for the estimate kernel                                                  */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
@@ -732,7 +733,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"trace", &HuKnobs::trace},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1391,7 +1392,8 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		else if(spt <= 2) k_estimate_prod<2, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
+		/* measured and not kept: <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
+		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, (size_t)(b->knob.est_lds_pad > 0 && b->knob.est_lds_pad <= 60 ? b->knob.est_lds_pad : 0) * 1024, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
 		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		else k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		#undef EST_ARGS
