@@ -1580,7 +1580,8 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 					else if(em1) k_place_w1<12, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
 					/* regions of <= 1,024 sites (150-base reads): the whole v message in LDS (VL = 3, 24 KB per workgroup), 168 VGPRs, three waves per
 					 * SIMD: FIVE workgroups per CU instead of four (the LDS holds five) — the kernel's time goes with the resident candidates
-					 * (DESIGN.md section 7): 4.18 -> 3.78 ms per 8,192 reads at gg_97 scale, 853 k -> 896 k reads/s.  Same arithmetic (results equal to 1e-12, iteration counts identical). */
+					 * (DESIGN.md section 7): 4.18 -> 3.78 ms per 8,192 reads at gg_97 scale, 853 k -> 896 k reads/s.  Same arithmetic (results equal to 1e-12, iteration counts identical).
+					 * Measured and not kept: the model constants read from global memory instead of 1.5 KB of LDS, which lets a sixth workgroup in — 32 B of scratch, 3.97 ms. */
 					else if(S == 8 && var != 6) k_place_blk<8, 2, 3, 0, 3, false, 3, 6><<<(unsigned) nc, 128, 3 * 8 * 128 * sizeof(double), b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 					else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);   /* place_var = 6: v in registers, two waves per SIMD */
 					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, (size_t)(b->knob.place_lds_pad > 0 && b->knob.place_lds_pad <= 44 ? b->knob.place_lds_pad : 0) * 1024, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
