@@ -724,6 +724,7 @@ struct HuKnobs {
 	int place_em1 = 0;           /* k_place_w1: the EM of a branch on one wave (0: k_place_blk, EM steps across both waves) */
 	int place_lds_pad = 0;       /* KB of unused dynamic LDS per placement workgroup: fewer of them per CU (experiment) */
 	int est_lds_pad = 0;         /* the same for the estimate kernel                                                  */
+	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
@@ -733,7 +734,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"trace", &HuKnobs::trace},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1090,7 +1091,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 					const int mode = kb.viterbi_mode ? kb.viterbi_mode : (kb.viterbi_dec1 ? 1 : 0);   /* 1 = generic workgroup kernel, 2 = row-per-thread workgroup kernel */
 					const int haloWw = std::min(haloW, 512);
 					if(mode == 0 && maxLen <= 512) { /* one wave per sequence, no barrier */
-						const size_t wl = (size_t) 3 * haloWw * sizeof(double);
+						const size_t wl = (size_t) 3 * haloWw * sizeof(double) + (size_t)(kb.vit_lds_pad > 0 && kb.vit_lds_pad <= 40 ? kb.vit_lds_pad : 0) * 1024;
 						const int dgv = kb.vw_diag;
 						if(maxLen <= 256 && dgv == 1) { k_viterbi_wave<4, 1><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
 						else if(maxLen <= 256 && dgv == 2) { k_viterbi_wave<4, 2><<<b->nSeq, 64, wl, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dDec.p, tNN, tNB, tEC, tCC, b->dVit.p, haloWw); decRpl = 4; }
