@@ -725,6 +725,7 @@ struct HuKnobs {
 	int place_lds_pad = 0;       /* KB of unused dynamic LDS per placement workgroup: fewer of them per CU (experiment) */
 	int est_lds_pad = 0;         /* the same for the estimate kernel                                                  */
 	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
+	int scan_lds_pad = 0;        /* the same for the distance-only scan                                               */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
@@ -734,7 +735,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1244,7 +1245,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 			const dim3 grid4(tiles, (d.nNodesPad + 1023) / 1024);
 			if(dOnly && b->knob.dscan1 && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(dOnly && b->knob.dscan1) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
-			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, (size_t)(b->knob.scan_lds_pad > 0 && b->knob.scan_lds_pad <= 44 ? b->knob.scan_lds_pad : 0) * 1024, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
 			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
