@@ -292,6 +292,8 @@ __global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_
 	if(sg == 0 && read >= 0) bminD[(size_t) read * gridDim.y + blockIdx.y] = m;
 }
 
+/* Measured and not kept: two passes of eight reads per tile (32 counters per lane instead of 64: 128 VGPRs, four workgroups per CU, node planes
+ * loaded twice): 2.52 ms against 2.20 — the second pass over the quads costs more than the fourth workgroup hides. */
 template<class DT>
 __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32_t* __restrict__ rp,
 		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD, const uint2* __restrict__ tileSpan) {
