@@ -300,3 +300,24 @@ def test_cli_revcom_is_the_reference_revcom(reads_driver):
         assert L.ref_revcom(s.encode(), out, len(out)) == len(s)
         mine = subprocess.run([reads_driver, "revcom", s], capture_output=True, text=True)
         assert mine.returncode == 0 and mine.stdout.strip() == out.value.decode(), s
+
+
+def test_read_files_damaged(tmp_path, reads_driver):
+    """the reader under the sanitizers on input that is not a read file at all: random bytes, a gzip stream cut in the middle, a FASTQ
+    record cut after its second line, lines of 1 MB — it returns what it could read and never touches memory it does not own"""
+    import gzip, subprocess
+    rng = np.random.default_rng(12)
+    junk = tmp_path / "junk.fasta"; junk.write_bytes(rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes())
+    cut = tmp_path / "cut.fasta.gz"
+    whole = gzip.compress(b"".join(b">r%d d\n%s\n" % (i, b"ACGT" * 60) for i in range(2000)))
+    cut.write_bytes(whole[:len(whole) // 2])
+    fq = tmp_path / "cut.fastq"; fq.write_text("@a\nACGT\n+\nIIII\n@b\nACG")
+    longl = tmp_path / "long.fasta"; longl.write_text(">" + "x" * (1 << 20) + " " + "y" * (1 << 20) + "\n" + "A" * (3 << 20) + "\n>z\nAC\n")
+    for fmt, path in (("fasta", junk), ("fastq", junk), ("fasta", cut), ("fastq", fq), ("fasta", longl), ("fasta", tmp_path / "missing")):
+        r = subprocess.run([reads_driver, fmt, str(path)], capture_output=True)
+        assert r.returncode in (0, 3), (fmt, path, r.stderr[-1500:])      # 3 = could not open
+    recs = _product_reads(reads_driver, "fastq", fq)
+    assert recs == [("a", "", "ACGT")]                                      # the record cut short is dropped, not half-read
+    recs = _product_reads(reads_driver, "fasta", longl)
+    assert len(recs) == 2 and len(recs[0][0]) == 1 << 20 and len(recs[0][2]) == 3 << 20 and recs[1] == ("z", "", "AC")
+    assert len(_product_reads(reads_driver, "fasta", cut)) > 100            # what the intact part of the stream holds
