@@ -1396,8 +1396,11 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		/* measured and not kept: <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
 		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, (size_t)(b->knob.est_lds_pad > 0 && b->knob.est_lds_pad <= 60 ? b->knob.est_lds_pad : 0) * 1024, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
-		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		else k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* (512 threads x 4 sites measured slower here: 6.99 against 6.36 ms at R ~ 1,850) */
+		else if(var == 4) k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);    /* est_var = 4: 256 threads x 12 sites, 231 VGPRs, two workgroups of four waves per CU */
+		/* regions of 2,049 .. 3,072 columns (merged mate pairs): 512 threads x 6 sites, 120 VGPRs — the same two pairs per CU as with 256 x 12, but sixteen
+		 * waves instead of eight work on them and a pair's life is shorter: 5.67 -> 4.92 ms per 4,096 pairs of 2 x 250 bases, 265.6 k -> 276.6 k pairs/s */
+		else k_estimate_prod<6, 8, 2><<<egl, 512, 0, b->stream>>>(EST_ARGS, order, xm);
 		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());

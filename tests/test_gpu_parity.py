@@ -1030,7 +1030,7 @@ def test_pe_full_pipeline_against_oracle_batch():
 
 def test_wide_region_kernels():
     """paired-end reads whose merged alignment spans ~2,400 CS columns: the 4-wave / 12-sites-per-thread placement
-    kernel and the 8- and 12-sites-per-thread estimate kernels (the 250 bp single-end benchmark uses the 2-wave / 6-site ones)"""
+    kernel and the 512-thread / 6-sites-per-thread estimate kernel (the 250 bp single-end benchmark uses the 2-wave / 256-thread ones)"""
     E = _engine()
     from hmmufotu_amd import synth
     from oracle import oracle_py as O
@@ -1052,12 +1052,17 @@ def test_wide_region_kernels():
     ok = recs["status"] == 1
     assert ok.sum() >= 8 and (recs["status"] == ref["aln_ints"][:, 7]).all()
     span = (recs["cs_end"] - recs["cs_start"])[ok]
-    assert span.max() > 1536, span                                 # beyond the 2-wave kernel's 12 x 128 sites
+    assert span.max() > 2048, span                                 # beyond the 2-wave placement kernel's 12 x 128 sites and the 256-thread estimate kernel's 8 x 256
     assert np.array_equal(recs["cost"], ref["cost"])
     assert (best["n_cand"] == ref["n_cand"]).all()
     tot = classify_batch(ref, B.candidates(), best, db.parent)
     assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
     print("wide-region parity", tot)
+    # the shipped estimate kernel for such regions runs 512 threads x 6 sites; est_var = 4 is the 256 x 12 form: same estimates
+    er, ew, el = B.estimates()
+    B.set_knob("est_var", 4); B.assign(opts)
+    er4, ew4, el4 = B.estimates()
+    assert np.array_equal(er, er4, equal_nan=True) and np.array_equal(ew, ew4, equal_nan=True) and np.nanmax(np.abs(el - el4) / np.maximum(np.abs(el), 1.0)) < 1e-12
     B.close(); D.close()
 
 
