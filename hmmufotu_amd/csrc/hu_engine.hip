@@ -1394,7 +1394,8 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		else if(spt <= 2) k_estimate_prod<2, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
 		else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		/* measured and not kept: <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
+		/* measured and not kept: <3, 8, 3> (512 threads x 3 sites, 66 VGPRs, three pairs per CU on 24 waves): 5.04 ms against 4.40;
+		 * <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
 		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, (size_t)(b->knob.est_lds_pad > 0 && b->knob.est_lds_pad <= 60 ? b->knob.est_lds_pad : 0) * 1024, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
 		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* (512 threads x 4 sites measured slower here: 6.99 against 6.36 ms at R ~ 1,850) */
 		else if(var == 4) k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);    /* est_var = 4: 256 threads x 12 sites, 231 VGPRs, two workgroups of four waves per CU */
