@@ -1599,6 +1599,9 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			}
 			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
 			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
+			/* 256 VGPRs: one candidate of four waves per CU.  Measured and not kept: six waves x 8 sites with the v message in LDS (72 KB; 156 VGPRs, two
+			 * candidates on twelve waves per CU): 8.53 ms against 8.2 per 4,096 pairs of 2 x 250 bases, 244 k against 277 k pairs/s — the sweeps read v
+			 * through the LDS return path and every EM step crosses six waves */
 			else PL_GO(12, 4, 3, 0, 1);
 			#undef PL_GO
 		}
