@@ -1602,7 +1602,11 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 			/* 256 VGPRs: one candidate of four waves per CU.  Measured and not kept: six waves x 8 sites with the v message in LDS (72 KB; 156 VGPRs, two
 			 * candidates on twelve waves per CU): 8.53 ms against 8.2 per 4,096 pairs of 2 x 250 bases, 244 k against 277 k pairs/s — the sweeps read v
 			 * through the LDS return path and every EM step crosses six waves */
-			else PL_GO(12, 4, 3, 0, 1);
+			/* regions of 2,049 .. 3,072 columns (merged mate pairs).  With everything in registers the kernel needs all 256 VGPRs (+ AGPRs): ONE candidate of
+			 * four waves per CU.  One component of v in LDS (VL = 1, 24 KB per workgroup) -> 239 VGPRs, two waves per SIMD, TWO candidates per CU:
+			 * 8.2 -> 4.96 ms per 4,096 pairs of 2 x 250 bases, 277 k -> 309 k pairs/s (the kernel's time goes with the resident candidates) */
+			else if(var == 9) PL_GO(12, 4, 3, 0, 1);     /* place_var = 9: the all-register form */
+			else k_place_blk<12, 4, 3, 0, 2, false, 1><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
 			#undef PL_GO
 		}
 		#undef PL_ARGS

@@ -1063,6 +1063,13 @@ def test_wide_region_kernels():
     B.set_knob("est_var", 4); B.assign(opts)
     er4, ew4, el4 = B.estimates()
     assert np.array_equal(er, er4, equal_nan=True) and np.array_equal(ew, ew4, equal_nan=True) and np.nanmax(np.abs(el - el4) / np.maximum(np.abs(el), 1.0)) < 1e-12
+    # the shipped placement kernel for such regions keeps one component of the v message in LDS (two candidates per CU); place_var = 9 is the
+    # all-register form (one per CU): same candidates, same iteration counts, same lengths
+    c0 = B.candidates()
+    B.set_knob("est_var", 0); B.set_knob("place_var", 9); B.assign(opts)
+    c9 = B.candidates()
+    assert np.array_equal(c0["c_node"], c9["c_node"]) and np.array_equal(c0["iters"], c9["iters"])
+    assert np.abs(c0["ratio"] - c9["ratio"]).max() < 1e-12 and np.abs(c0["wnr"] - c9["wnr"]).max() < 1e-12
     B.close(); D.close()
 
 
