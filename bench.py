@@ -52,9 +52,21 @@ def parse_args(argv=None):
     ap.add_argument("--uniform-starts", action="store_true", help="read starts uniform over the resident window (SURVEY §8d second run)")
     ap.add_argument("--partial-frac", type=float, default=0.0, help="fraction of the leaves that lose a prefix or suffix (partial reference sequences)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 15 s worth)")
+    ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("HU_BENCH_E2E_READS", 1 << 20)),
+                    help="distinct reads of the end-to-end block (host seed lookup + upload + engine + TSV formatting, measured after the timed region; 0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
                     help="control-flow rehearsal WITHOUT the engine (CPU, gloo): launch, rendezvous, barrier, gather, max-over-ranks, one JSON line; value is null")
     return ap.parse_args(argv)
+
+
+def kernel_source_hash():
+    """hash of the sources every kernel is compiled from: ties a PMC summary to the kernels that were running when it was taken"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hmmufotu_amd", "csrc")
+    for f in sorted(x for x in os.listdir(d) if x == "hu_engine.hip" or x == "hu_common.h" or (x.startswith("hu_kern_") and x.endswith(".h"))):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def free_port():
@@ -65,6 +77,11 @@ def free_port():
 def launch_ranks(args):
     """--gpus N > 1 without a launcher: start the N ranks as children (nothing in this process has touched the
     GPU or imported torch), forward rank 0's line, exit non-zero when any rank failed."""
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_TOOLS", "ROCP_TOOL_LIB")):
+        # the profiler's preloaded library has initialised the GPU in this process: starting the launcher from here is the launcher hop this
+        # pool forbids under rocprofv3.  Profile a multi-rank run with the rank program directly after `--`.
+        print("[bench] --gpus %d under rocprofv3: refusing to start the launcher from a profiled process" % args.gpus, file=sys.stderr, flush=True)
+        sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -175,17 +192,58 @@ def main():
             all_mates.append(list(mt)); all_mvps.append(np.stack([synth.read_vpaths(db.hmm, r) for r in mt]))
         else:
             all_reads.append(reads); all_vps.append(np.stack([synth.read_vpaths(db.hmm, r) for r in reads]))
-    # host copy of the columns the reads of batch 0 touch, for the CPU baseline (oracle), log space
-    cpu_win = None
+    # ---- end-to-end pool: --e2e-reads DISTINCT reads of the headline shape as one byte buffer (drawn from the log-space messages, like the batches)
+    pool = None
+    if rank == 0 and world == 1 and args.e2e_reads > 0 and not args.paired:
+        tp = time.time()
+        pool = synth_gpu.simulate_pool_gpu(db, up, down, args.e2e_reads, args.read_len, seed=777, amplicon_start=amp_start, amplicon_cols=amp_cols, device=dev)
+        log("end-to-end pool: %d distinct reads, %.1f MB (%.0fs)" % (len(pool[1]) - 1, pool[0].nbytes / 1e6, time.time() - tp))
+
+    # ---- CPU baseline, phase A (rank 0, N = 1): the oracle's alignment + getSeed on a bounded sample of batch 0, BEFORE the engine adopts the
+    # messages (it rewrites them in place into its packed form).  getSeed reads no message; estimateSeq / placeSeq read those of a read's <= 50
+    # seed nodes only, so the rows of the sample's seed nodes are gathered from the device here (a few GB) instead of a host copy of the
+    # window (40-200 GB) — which is what lets the leg run on the 400 k-node database of config 5.  Phase B (after the timed region) runs the
+    # rest of the task on those rows.  The same scan also yields the seed list under the reference's literal std::sort (tie-mode report).
+    cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0:
-        rs = all_reads[0] + (all_mates[0] if args.paired else [])
-        lo = max(db.win[0], min(r.cs_start for r in rs) - 40)
-        hi = min(db.win[0] + db.win[1], max(r.cs_end for r in rs) + 41)
-        if (hi - lo) * db.n_nodes * 64 < 40e9:
-            cpu_win = (lo, hi, up[:, lo - db.win[0]:hi - db.win[0]].contiguous().cpu().numpy(),
-                       down[:, lo - db.win[0]:hi - db.win[0]].contiguous().cpu().numpy())
-        else:
-            log("CPU baseline skipped: the reads span %d columns, too many for a host copy of the messages" % (hi - lo))
+        try:
+            from oracle import oracle_py as O
+            cores = O.max_threads()
+            m_o = O.Model(db.model.type_id, db.model.pi, db.model.par)
+            H_o = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
+            dummy = np.zeros((1, 1, 4))
+            T_a = O.Tree(db.parent, db.blen, db.seq, dummy, dummy, db.height, m_o, db.dg_r if db.dg_k > 0 else None, db.anno_id)
+            reads_c = [r.seq for r in all_reads[0]]
+            mates_c = [r.seq for r in all_mates[0]] if args.paired else None
+            mv_c = all_mvps[0] if args.paired else None
+
+            def phase_a(n, lib):
+                return O.pipeline_batch(H_o, T_a, reads_c[:n], all_vps[0][:n], mates=mates_c[:n] if mates_c else None, mvpaths=mv_c[:n] if mates_c else None,
+                                        threads=cores, mode=1, want_lib=lib)
+            n0 = min(len(reads_c), max(cores, 16))
+            tc = time.perf_counter(); phase_a(n0, False); d0 = time.perf_counter() - tc
+            ns = args.cpu_sample if args.cpu_sample > 0 else int(min(len(reads_c), max(n0, 12.0 / max(d0 / n0, 1e-6))))
+            ns = min(ns, len(reads_c))
+            tc = time.perf_counter(); p1 = phase_a(ns, True); dA = time.perf_counter() - tc
+            dA -= p1["extra_thread_sec"] / cores               # the libstdc++ order of the same scan is not part of the task
+            okA = p1["aln_ints"][:, 7] == 1
+            nodes = np.unique(np.concatenate([p1["seed_ids"].ravel(), p1["lib_ids"].ravel()])); nodes = nodes[nodes >= 0]
+            lo = max(db.win[0], int(p1["aln_ints"][okA, 4].min()) - 1); hi = min(db.win[0] + db.win[1], int(p1["aln_ints"][okA, 5].max()))
+            rows_up = np.empty((len(nodes), hi - lo, 4)); rows_dn = np.empty_like(rows_up)
+            nd_d = torch.tensor(nodes, device=dev)
+            for a0 in range(0, len(nodes), 1024):
+                ix = nd_d[a0:a0 + 1024]
+                rows_up[a0:a0 + 1024] = up[ix, lo - db.win[0]:hi - db.win[0]].cpu().numpy()
+                rows_dn[a0:a0 + 1024] = down[ix, lo - db.win[0]:hi - db.win[0]].cpu().numpy()
+            row_of = np.full(db.n_nodes, -1, np.int32); row_of[nodes] = np.arange(len(nodes))
+            cpu = dict(O=O, H=H_o, m=m_o, T_a=T_a, p1=p1, ns=ns, dA=dA, cores=cores, lo=lo, hi=hi, rows_up=rows_up, rows_dn=rows_dn, row_of=row_of,
+                       reads=reads_c, mates=mates_c, mv=mv_c)
+            log("CPU leg, phase A: %d reads aligned + seeded on %d threads in %.1fs; message rows of %d seed nodes x %d columns gathered (%.2f GB)"
+                % (ns, cores, dA, len(nodes), hi - lo, 2 * rows_up.nbytes / 1e9))
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            cpu = dict(failed=repr(ex))
     md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if db.dg_k > 0 else None)
     D = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, db.anno_id,
                                win_start=db.win[0], win_len=db.win[1] if win else 0, device=local, msgs_on_device=True)
@@ -291,16 +349,19 @@ def main():
                         uniform_starts=bool(args.uniform_starts), win=args.win)
     if args.partial_frac:
         workload_key["partial_frac"] = args.partial_frac
-    pmc, pmc_src = {}, None
+    pmc, pmc_src, pmc_hash = {}, None, None
+    src_hash = kernel_source_hash()
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted((x for x in os.listdir(pdir) if x.endswith("_pmc_summary.json")), reverse=True):
         try:
             j = json.load(open(os.path.join(pdir, f)))
             if j.get("workload") == workload_key:
-                pmc, pmc_src = j["kernels"], "profiles/" + f
+                pmc, pmc_src, pmc_hash = j["kernels"], "profiles/" + f, j.get("kernel_source_hash")
                 break
         except Exception:
             pass
+
+    pmc_stale = bool(pmc) and pmc_hash != src_hash       # counters of other kernel sources than the ones running: quoted, but tagged
 
     def pmc_entry(stage):
         for pre in pmc_prefix[stage]:
@@ -317,65 +378,126 @@ def main():
                  achieved=alg[k] / (iso[k] * 1e-3) / 1e9, unit="GB/s", frac=alg[k] / (iso[k] * 1e-3) / 1e9 / peak,
                  traffic=tr, hbm_measured_frac=(tr / (iso[k] * 1e-3) / 1e9 / peak if tr else None))
         if ent.get("valu_issue_cycles_per_launch"):       # typed instruction counts x measured issue cycles (profiles/isa_cost.py), over 1,024 SIMDs
-            e["valu_issue_frac"] = ent["valu_issue_cycles_per_launch"] / 1024.0 / (iso[k] * 1e-3 * ent.get("clock_hz", 2.4e9))
+            e["valu_issue_frac"] = ent["valu_issue_cycles_per_launch"] / 1024.0 / (iso[k] * 1e-3 * ent.get("clock_hz", 2.37e9))   # 2.37 GHz: measured, profiles/r02d_clocks.json
         kern.append(e)
     dom = max(kern, key=lambda x: x["ms_isolated"])
-    roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], traffic=dom["traffic"],
+    # What binds the dominant kernel is FP64 VALU issue at the occupancy its per-site state allows, not HBM: `bound` says so.
+    # `frac` stays the contract's number (algorithmic bytes / isolated time / HBM peak); the two measured roofs sit beside it.
+    roof = dict(bound="valu_fp64_issue", kernel=dom["kernel"], achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], traffic=dom["traffic"],
                 ms=dom["ms_isolated"], timing="HIP events on the batch's stream, one batch in flight (the kernel's own cost)",
                 ms_in_timed_region=dom["ms_in_timed_region"], frac_in_timed_region=dom["algorithmic_bytes"] / (dom["ms_in_timed_region"] * 1e-3) / 1e9 / peak,
                 hbm_measured_frac=dom["hbm_measured_frac"], valu_issue_frac=dom.get("valu_issue_frac"), traffic_source=pmc_src,
-                binding_resource="FP64 VALU issue (see DESIGN.md §8); the algorithmic-bytes fraction is reported as the contract asks")
+                pmc_kernel_source_hash=pmc_hash, kernel_source_hash=src_hash, pmc_stale=pmc_stale,
+                hbm_roof=dict(achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], measured_frac=dom["hbm_measured_frac"]),
+                valu_roof=dict(frac=dom.get("valu_issue_frac"), unit="issue cycles of the kernel's vector instructions / (1,024 SIMDs x clock x isolated time)"),
+                note="frac = ALGORITHMIC bytes (SURVEY.md section 8d per-unit figures x the launch's units: int8 node sites, FP64 messages, no reuse credited) / isolated time / "
+                     "8 TB/s.  Kernels whose frac exceeds 1 (roofline_kernels: seed scan, top-k, estimate) do the reference's work on fewer bytes — three bit-planes instead "
+                     "of int8 sites, sixteen reads per node tile, only the 128-column quads that hold read bases, no pair row for the top-k, reads sharing a seed node meeting "
+                     "in one XCD's L2 — checked bit for bit against the reference's own pDist / the oracle; hbm_measured_frac (PMC bytes) and valu_issue_frac are the roofs "
+                     "that say how busy the chip is.  pmc_stale = the PMC summary was taken on other kernel sources than are running now.")
     bytes_per_read = (D.n_nodes - 1) * R + S * 65 * R + C * 64 * R + (2 if args.paired else 1) * (args.read_len + 136 * Wp) + args.cs_len + 128
     step_traffic = sum(k["traffic"] for k in kern) if all(k["traffic"] for k in kern) else None
     path = dict(bytes_per_read=bytes_per_read, achieved=bytes_per_read * value / world / 1e9, unit="GB/s per GPU",
                 frac=bytes_per_read * value / world / 1e9 / peak, mean_R=R, mean_candidates=C,
                 hbm_measured_bytes_per_step=step_traffic,
-                hbm_measured_frac=(step_traffic / (dt / args.steps) / 1e9 / peak if step_traffic else None), traffic_source=pmc_src)
+                hbm_measured_frac=(step_traffic / (dt / args.steps) / 1e9 / peak if step_traffic else None), traffic_source=pmc_src, pmc_stale=pmc_stale)
 
     shape = "%s %d bp" % ("PE 2 x" if args.paired else "SE", args.read_len)
+    free_b, total_b = torch.cuda.mem_get_info(local)
     out = dict(metric=metric, value=value, unit="reads/s" if not args.paired else "pairs/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="%s synthetic DB (%d nodes x %d CS columns, K=%d), GTR%s, %s %s reads, "
                                     "batch %d reads/step/GPU, %d batches in flight" % ("SILVA-scale" if args.leaves >= 150000 else "gg_97_otus-scale" if args.leaves >= 90000 else "reduced-scale", D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
                                                                                          shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb),
-                           db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world),
+                           db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world,
+                           hbm_in_use_gb=(total_b - free_b) / 1e9, hbm_total_gb=total_b / 1e9),
                timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
-                            "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: the product CLI's end-to-end rate is "
-                            "profiles/r02_cli_throughput.json",
+                            "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: `end_to_end` below measures them in this same process",
                host_cores_busy_per_rank=round(host_cores_busy, 1), host_cpus=os.cpu_count(),
                rccl_ranks=rccl_ranks, backend=backend if world > 1 else None, gathered_records=(int(len(gathered)) if world > 1 else None),
                roofline=roof, roofline_kernels=kern, roofline_path=path,
                kernel_ms={k: round(v, 3) for k, v in acc.items()}, kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},
                host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
-    # ---- CPU baseline: the oracle (line-faithful port) on this box's host cores, rank 0, N=1 only; doubles as the
-    # full-scale parity check: every difference of the final pick must be a documented near-tie (oracle/parity.py)
-    if rank == 0 and world == 1 and args.cpu_sample != 0 and cpu_win is not None:
+    # ---- end to end in this process: host seed lookup (hu_seed_index_lookup over the leaf rows' own index) -> read upload -> engine -> TSV lines,
+    # over the pool of distinct reads drawn before the database was packed; one worker thread per batch object, chunks dealt in order of completion
+    if pool is not None:
         try:
-            from oracle import oracle_py as O, parity
-            lo, hi, up_h, down_h = cpu_win
-            assert lo <= int(st[ok].min()) and int(en[ok].max()) < hi
-            m = O.Model(db.model.type_id, db.model.pi, db.model.par)
-            H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
-            T = O.Tree(db.parent, db.blen, db.seq, up_h, down_h, db.height, m, db.dg_r if db.dg_k > 0 else None, db.anno_id,
-                       win_start=lo, win_len=hi - lo)
-            cores = O.max_threads()
-            reads = [r.seq for r in all_reads[0]]
-            mates = [r.seq for r in all_mates[0]] if args.paired else None
-            mv = all_mvps[0] if args.paired else None
+            import ctypes as Ct
+            import queue
+            import threading
+            cat, offs = pool
+            nr = len(offs) - 1
+            tb = time.perf_counter()
+            ix = E.SeedIndex(db.parent, db.seq, db.hmm, 20)
+            t_index = time.perf_counter() - tb
+            chunks = [(a0, min(nr, a0 + args.batch)) for a0 in range(0, nr, args.batch)]
+            id_arrays = [(Ct.c_char_p * (b0 - a0))(*[b"r%d" % i for i in range(a0, b0)]) for a0, b0 in chunks]
+            anno_strs = [b"taxon%d" % int(x) for x in db.anno_id]
+            anno_arr = (Ct.c_char_p * len(anno_strs))(*anno_strs)
+            for B_ in batches:
+                B_.profile(False)
+            stage = [dict(lookup=0.0, upload=0.0, engine=0.0, tsv=0.0) for _ in range(nb)]
+            done = [0] * nb; tsv_bytes = [0] * nb; placed = [0] * nb
+            q = queue.Queue()
+            for c_ in range(len(chunks)):
+                q.put(c_)
 
-            def cpu(n):
-                return O.pipeline_batch(H, T, reads[:n], all_vps[0][:n], mates=mates[:n] if mates else None,
-                                        mvpaths=mv[:n] if mates else None, threads=cores, want_cands=True)
-            n0 = min(len(reads), max(cores, 16))
+            def worker(w):
+                B_ = batches[w]
+                while True:
+                    try:
+                        c_ = q.get_nowait()
+                    except queue.Empty:
+                        return
+                    a0, b0 = chunks[c_]
+                    sub = cat[offs[a0]:offs[b0]]; so = offs[a0:b0 + 1] - offs[a0]
+                    x0 = time.perf_counter(); vp = ix.lookup_packed(sub, so, 50, 0)
+                    x1 = time.perf_counter(); B_.set_reads_packed(sub, so, vp)
+                    x2 = time.perf_counter(); B_.assign(opts)
+                    x3 = time.perf_counter(); tsv_bytes[w] += B_.format_tsv_bytes(id_arrays[c_], None, anno_arr)
+                    x4 = time.perf_counter()
+                    st_ = stage[w]; st_["lookup"] += x1 - x0; st_["upload"] += x2 - x1; st_["engine"] += x3 - x2; st_["tsv"] += x4 - x3
+                    done[w] += b0 - a0
+                    placed[w] += int((B_.placements()["c_node"] >= 0).sum())
+            te = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(w,)) for w in range(nb)]
+            [t.start() for t in th]; [t.join() for t in th]
+            torch.cuda.synchronize()
+            de = time.perf_counter() - te
+            out["end_to_end"] = dict(value=sum(done) / de, unit="reads/s", reads=int(sum(done)), distinct_reads=int(nr), seconds=de, placed=int(sum(placed)),
+                                     tsv_mb=sum(tsv_bytes) / 1e6, workers=nb,
+                                     stages="hu_seed_index_lookup (5' + 3' seeds, depth-32 suffix index over the leaf rows) -> hu_batch_set_reads (upload) -> hu_assign_batch -> "
+                                            "hu_batch_format_tsv_ptr (one line per read incl. the csLen-character alignment)",
+                                     stage_busy_sec={k: round(sum(s_[k] for s_ in stage), 2) for k in stage[0]},
+                                     seed_index_build_sec=round(t_index, 1), seed_index_gb=ix.bytes / 1e9,
+                                     excluded="FASTA parsing and the file write (profiles/measure_cli.py times the product CLI with both)")
+            log("end to end: %.0f reads/s over %d distinct reads (%.1fs; index build %.1fs)" % (sum(done) / de, nr, de, t_index))
+            del ix
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            out["end_to_end"] = dict(value=None, failed=repr(ex))
+
+    # ---- CPU baseline, phase B: estimateSeq / filterPlacements / placeSeq / calcQValues of the oracle on the seeds of phase A, on this box's host
+    # cores; doubles as the full-scale parity check — ids: every difference of the final pick must be a documented near-tie (oracle/parity.py);
+    # numbers: relative error of every candidate's estimated loglik and placed ratio / wnr / height, and iteration counts — and carries the
+    # tie-mode report (SURVEY.md H1 ii): the same reads under the reference's literal std::sort seed order.
+    if cpu is not None and "failed" in cpu:
+        out["cpu_baseline"] = dict(value=None, unit=out["unit"], cores=0, kind="port", sample="failed: " + cpu["failed"])
+    elif cpu is not None:
+        try:
+            from oracle import parity
+            O = cpu["O"]; ns = cpu["ns"]; cores = cpu["cores"]; p1 = cpu["p1"]
+            T_b = O.Tree(db.parent, db.blen, db.seq, cpu["rows_up"], cpu["rows_dn"], db.height, cpu["m"], db.dg_r if db.dg_k > 0 else None, db.anno_id,
+                         win_start=cpu["lo"], win_len=cpu["hi"] - cpu["lo"])
+            T_b.set_rows(cpu["row_of"])
+            reads, mates, mv = cpu["reads"], cpu["mates"], cpu["mv"]
             tc = time.perf_counter()
-            cpu(n0)
-            d0 = time.perf_counter() - tc
-            ns = args.cpu_sample if args.cpu_sample > 0 else int(min(len(reads), max(n0, 15.0 / max(d0 / n0, 1e-6))))
-            tc = time.perf_counter()
-            r1 = cpu(ns)
-            d1 = time.perf_counter() - tc
+            r1 = O.pipeline_batch(cpu["H"], T_b, reads[:ns], all_vps[0][:ns], mates=mates[:ns] if mates else None, mvpaths=mv[:ns] if mates else None,
+                                  threads=cores, want_cands=True, mode=2, seeds=(p1["seed_cnt"], p1["seed_ids"]))
+            dB = time.perf_counter() - tc
             per = []
             for i in range(ns):
                 k = int(r1["n_cand"][i]); a, b = int(cand["offs"][i]), int(cand["offs"][i + 1])
@@ -383,14 +505,49 @@ def main():
                                                 cand["c_node"][a:b], db.parent, pos=int(r1["best_pos"][i]) if k else None))
             tot = parity.summarize(per)
             agree = float((r1["best_nodes"][:ns, 0] == best["c_node"][:ns]).mean())
-            out["cpu_baseline"] = dict(value=ns / d1, unit=out["unit"], cores=cores, kind="port",
-                                       sample="first %d reads of batch 0 (same DB, same reads), OpenMP one read per task" % ns,
-                                       stage_cpu_sec=dict(zip(["align", "seed", "estimate", "place"], [round(float(x), 2) for x in r1["stage_sec"]])),
+            # numbers: candidate by candidate (matched by branch inside a read)
+            _, cplaces = B.candidate_places()
+            rel = dict(est_loglik=[], ratio=[], wnr=[], height=[]); it_out = it_em = ncmp = nan_mismatch = 0
+            for i in range(ns):
+                k = int(r1["n_cand"][i]); a = int(cand["offs"][i]); b = int(cand["offs"][i + 1])
+                pos = {int(nn): j for j, nn in enumerate(r1["cand_node"][i, :k])}
+                for c in range(a, b):
+                    j = pos.get(int(cand["c_node"][c]))
+                    if j is None:
+                        continue
+                    ncmp += 1
+                    pairs = (("est_loglik", cand["est_loglik"][c], r1["cand_est"][i, j]), ("ratio", cand["ratio"][c], r1["cand_placed"][i, j, 0]),
+                             ("wnr", cand["wnr"][c], r1["cand_placed"][i, j, 1]), ("height", cplaces["height"][c], r1["cand_placed"][i, j, 2]))
+                    for nm, g, o_ in pairs:
+                        if np.isnan(g) or np.isnan(o_):
+                            nan_mismatch += int(np.isnan(g) != np.isnan(o_))
+                        else:
+                            rel[nm].append(abs(g - o_) / max(abs(o_), 1e-3))
+                    it_out += int((int(cand["iters"][c]) & 255) != int(r1["cand_iters"][i, j, 0]))
+                    it_em += int((int(cand["iters"][c]) >> 8) != int(r1["cand_iters"][i, j, 1]))
+            num = {nm: dict(max_rel=float(np.max(v)) if v else None, p99_rel=float(np.percentile(v, 99)) if v else None) for nm, v in rel.items()}
+            # tie-mode report on the same sample
+            tt = time.perf_counter()
+            tper, tsum = O.tie_report(cpu["H"], cpu["T_a"], reads[:ns], all_vps[0][:ns], mates[:ns] if mates else None, mv[:ns] if mates else None,
+                                      threads=cores, phase1=p1, tree2=T_b)
+            tsum["seconds"] = round(time.perf_counter() - tt, 1)
+            tsum["what"] = ("the same reads with the seeds kept under the reference's literal std::sort on dist alone (libstdc++ introsort's tie permutation, "
+                            "src/HmmUFOtu_main.cpp:139 + src/hmmufotu.cpp:646-647) against the product's (dist, node id) order; both from one scan per read")
+            out["cpu_baseline"] = dict(value=ns / (cpu["dA"] + dB), unit=out["unit"], cores=cores, kind="port",
+                                       sample="first %d reads of batch 0 (same DB, same reads), OpenMP one read per task; alignment + getSeed timed before the engine packs "
+                                              "the messages (%.1f s), estimate / filter / place / q-values after the GPU run on the gathered rows of the seed nodes (%.1f s)" % (ns, cpu["dA"], dB),
+                                       stage_cpu_sec=dict(zip(["align", "seed", "estimate", "place"],
+                                                              [round(float(x), 2) for x in (p1["stage_sec"][0], p1["stage_sec"][1], r1["stage_sec"][2], r1["stage_sec"][3])])),
                                        best_branch_agreement_with_gpu=agree,
                                        best_branch_diffs=tot["best_differs"], unexplained_best_branch_diffs=tot["best_unexplained"],
                                        candidate_order=dict(swaps_explained_near_tie=tot["swaps_explained"], swaps_unexplained=tot["swaps_unexplained"],
                                                             candidate_set_differs=tot["set_differs"]),
-                                       unexplained_detail=[repr(d) for r_ in per for d in r_["detail"]][:20])
+                                       unexplained_detail=[repr(d) for r_ in per for d in r_["detail"]][:20],
+                                       max_rel=dict(candidates_compared=ncmp, tolerance=1e-6, **num, nan_placement_mismatches=nan_mismatch,
+                                                    outer_iteration_mismatches=it_out, em_iteration_mismatches=it_em,
+                                                    note="relative to max(|oracle|, 1e-3), every candidate of every sampled read matched by branch; est_loglik = estimateSeq's, "
+                                                         "ratio / wnr / height = placeSeq's; iterations = outer loops of the joint optimisation and passes of the 2-node EM"),
+                                       tie_mode=tsum)
         except Exception as ex:                             # the baseline must never sink the measurement
             import traceback
             traceback.print_exc()

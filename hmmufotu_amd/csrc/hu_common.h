@@ -6,6 +6,9 @@
 #include <functional>
 #include <istream>
 #include <vector>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include "../../include/hmmufotu_amd.h"
 
 #define HU_MAX_DGK 16
@@ -82,6 +85,12 @@ struct HuRegion {
 	int64_t off;               /* first cell of this region in the read's scratch                 */
 	int64_t doff;              /* first byte of this region in the read's decision scratch: one byte per cell in
 	                            * anti-diagonal order, [dg][q] with pitch (i1 - i0 + 1) rounded up to 16                        */
+	/* the CORNER BLOCK of the region: rows ci0 .. i1 x columns cj0 .. j1, the only cells a later phase can look up (their row is at or
+	 * below the row above the first later phase, their column likewise: consecutive phases share a corner).  The one-wave kernel
+	 * (k_viterbi_wave) files (M, I, D) of these cells alone, column-major with a pitch of i1 - ci0 + 1, at cell `coff` of the read's
+	 * corner scratch — a few cells per read, where the value-filing kernels keep every cell of every phase (`off`: 2-3 MB per read) */
+	int32_t ci0, cj0;
+	int64_t coff;
 };
 #define HU_MAX_REGIONS 6
 #define HU_READ_NEEDS_VALUES 8   /* internal: the decision-byte traceback met a cell whose predecessor a later phase
@@ -94,10 +103,18 @@ struct HuReadDesc {
 	int64_t scratchOff;        /* first cell of the read in the DP scratch                        */
 	int64_t traceOff;
 	int64_t decOff;            /* first byte of the read in the decision scratch                  */
+	int64_t cornerOff;         /* first cell of the read in the corner scratch (k_viterbi_wave)   */
 	HuRegion reg[HU_MAX_REGIONS];
 };
 
 void hu_set_error(const char* fmt, ...);
+/* The exception barrier of the C ABI ("never abort inside the library").  Every extern "C" entry point is a
+ * function-try-block whose handler calls this INSIDE catch(...): the exception in flight becomes a status code and a message in the
+ * calling thread's hu_last_error() — std::bad_alloc / std::length_error (a size the host cannot back) -> HU_ERR_NOMEM, std::system_error
+ * (a thread that cannot start) and anything else -> HU_ERR_STATE.  What it cannot turn into a status is a fault of the GPU itself (an
+ * out-of-bounds access of a kernel ends the process from inside the HIP runtime): those are kept out by validating every index a
+ * kernel forms from caller data before the launch. */
+int hu_catch_all(const char* fn) noexcept;
 
 /* model constants of the table-driven placement kernel (k_place_blk), one buffer of doubles per database */
 #define HU_PC_LAM 0              /* [4]      eigenvalues                                                      */
@@ -139,3 +156,19 @@ int hu_read_ptu_sink(const char* path, HuTreeHost& out, const std::function<int(
 int hu_read_hmm_stream(std::istream& in, const char* name, HuProfileHost& out, std::vector<double>& EM, std::vector<double>& EI,
 		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L);
 int hu_read_model_text(std::istream& in, hu_model_desc& m);
+
+/* work() on up to nt threads, the caller being one of them (work is a self-scheduling loop: fewer helpers only means larger shares).
+ * An exception inside a helper is carried to the calling thread and rethrown there once every helper has been joined — a std::thread
+ * destroyed while joinable, or an exception leaving a thread body, would end the process; a helper that cannot be started is done without. */
+template<class F> void hu_run_threads(unsigned nt, F work) {
+	std::exception_ptr first;
+	std::mutex m;
+	auto guarded = [&] { try { work(); } catch(...) { std::lock_guard<std::mutex> lk(m); if(!first) first = std::current_exception(); } };
+	std::vector<std::thread> th;
+	try { th.reserve(nt); for(unsigned t = 1; t < nt; ++t) th.emplace_back(guarded); } catch(...) { }
+	guarded();
+	for(auto& t : th) t.join();
+	if(first) std::rethrow_exception(first);
+}
+/* runs f when the scope is left, by return or by exception */
+template<class F> struct HuScope { F f; explicit HuScope(F f) : f(f) {} ~HuScope() { f(); } HuScope(const HuScope&) = delete; HuScope& operator=(const HuScope&) = delete; };

@@ -16,6 +16,8 @@
 #include <chrono>
 #include <fstream>
 #include <sstream>
+#include <new>
+#include <stdexcept>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 #include "hu_kern_align.h"
@@ -42,8 +44,10 @@ struct HuPool {
 	uint64_t gen = 0;
 	int active = 0;
 	bool quit = false;
+	std::exception_ptr err;      /* first exception of a work item of the current run: rethrown on the calling thread (hu_catch_all turns it into a status) */
 	explicit HuPool(unsigned nt) {
-		for(unsigned t = 0; t < nt; ++t) th.emplace_back([this] {
+		try { th.reserve(nt); } catch(...) { return; }
+		for(unsigned t = 0; t < nt; ++t) try { th.emplace_back([this] {
 			uint64_t seen = 0;
 			for(;;) {
 				{
@@ -56,18 +60,25 @@ struct HuPool {
 				std::lock_guard<std::mutex> lk(m);
 				if(--active == 0) cvDone.notify_all();
 			}
-		});
+		}); } catch(...) { break; }       /* a helper that cannot be started (std::system_error) is done without */
 	}
-	void work() { for(;;) { size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk); for(size_t i = a; i < e; ++i) fn(i); } }
+	void work() noexcept {
+		for(;;) {
+			size_t a = next.fetch_add(chunk); if(a >= n) break; size_t e = std::min(n, a + chunk);
+			try { for(size_t i = a; i < e; ++i) fn(i); }
+			catch(...) { std::lock_guard<std::mutex> lk(m); if(!err) err = std::current_exception(); next = n; }   /* nothing leaves a thread body; the rest of the run is dropped */
+		}
+	}
 	template<class F> void run(size_t count, F f) {
 		{
 			std::lock_guard<std::mutex> lk(m);
-			fn = f; n = count; next = 0; active = (int) th.size(); ++gen;
+			fn = f; n = count; next = 0; active = (int) th.size(); err = nullptr; ++gen;
 		}
 		cvGo.notify_all();
 		work();                                   /* the caller works too */
 		std::unique_lock<std::mutex> lk(m);
 		cvDone.wait(lk, [&] { return active == 0; });
+		if(err) { std::exception_ptr e = err; err = nullptr; lk.unlock(); std::rethrow_exception(e); }
 	}
 	~HuPool() { { std::lock_guard<std::mutex> lk(m); quit = true; } cvGo.notify_all(); for(auto& t : th) t.join(); }
 };
@@ -160,7 +171,7 @@ template<class X> static int dev_upload(hu_db* db, X** p, const X* src, size_t n
 	return HU_OK;
 }
 
-extern "C" int hu_device_count(void) {
+extern "C" int hu_device_count(void) try {
 	int n = 0;
 	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
 	int ok = 0;
@@ -169,7 +180,7 @@ extern "C" int hu_device_count(void) {
 		if(hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
 	}
 	return ok;
-}
+} catch(...) { return hu_catch_all("hu_device_count"); }
 
 static int init_sym_map() {
 	int8_t m[128];
@@ -196,21 +207,23 @@ static int8_t host_sym(char c) {
 
 /* ------------------------------------------------------------------------------ database */
 extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu_model_desc* model,
-		int device, hu_db** out) {
+		int device, hu_db** out) try {
 	if(!prof || !tree || !model || !out) { hu_set_error("hu_db_create: null argument"); return HU_ERR_ARG; }
 	*out = nullptr;
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
 	HIPCHK(hipSetDevice(device));
 	hu_db* db = new hu_db;
+	bool built = false;
+	HuScope guard([&] { if(!built) hu_db_destroy(db); });      /* a half-built database frees itself on every way out, an exception included */
 	db->device = device;
 	int rc = db->prof.init(prof);
 	if(rc == HU_OK) rc = hu_model_prepare(model, &db->mdl);
-	if(rc != HU_OK) { delete db; return rc; }
+	if(rc != HU_OK) return rc;
 	db->mdesc = *model;
 	const int n = tree->n_nodes, L = tree->cs_len;
-	if(n < 2 || n >= (1 << 24) || L != prof->L) { hu_set_error("tree: n_nodes %d / cs_len %d inconsistent with profile L %d", n, L, prof->L); delete db; return HU_ERR_ARG; }
+	if(n < 2 || n >= (1 << 24) || L != prof->L) { hu_set_error("tree: n_nodes %d / cs_len %d inconsistent with profile L %d", n, L, prof->L); return HU_ERR_ARG; }
 	const int64_t winStart = tree->win_len > 0 ? tree->win_start : 0, winLen = tree->win_len > 0 ? tree->win_len : L;
-	if(winStart < 0 || winStart + winLen > L) { hu_set_error("tree: message window out of range"); delete db; return HU_ERR_ARG; }
+	if(winStart < 0 || winStart + winLen > L) { hu_set_error("tree: message window out of range"); return HU_ERR_ARG; }
 	db->parent.assign(tree->parent, tree->parent + n);
 	db->blen.assign(tree->blen, tree->blen + n);
 	db->height.assign(tree->height, tree->height + n);
@@ -221,9 +234,9 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 	int root = -1, nroot = 0;
 	for(int i = 0; i < n; ++i) {
 		if(db->parent[i] < 0) { root = i; nroot++; }
-		else if(db->parent[i] >= n) { hu_set_error("tree: parent of node %d out of range", i); delete db; return HU_ERR_ARG; }
+		else if(db->parent[i] >= n) { hu_set_error("tree: parent of node %d out of range", i); return HU_ERR_ARG; }
 	}
-	if(nroot != 1) { hu_set_error("tree: %d roots", nroot); delete db; return HU_ERR_ARG; }
+	if(nroot != 1) { hu_set_error("tree: %d roots", nroot); return HU_ERR_ARG; }
 	HuDbDev& d = db->dev;
 	memset(&d, 0, sizeof(d));
 	d.nNodes = n; d.csLen = L; d.root = root;
@@ -231,7 +244,7 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 	d.W = (L + 31) / 32; d.WQ = (L + 127) / 128;
 	d.winStart = winStart; d.winLen = winLen;
 	d.K = prof->K; d.L = L;
-	auto fail = [&](int code) { hu_db_destroy(db); return code; };
+	auto fail = [&](int code) { return code; };
 	/* scan order of the CS columns: the profile (match) columns first, then the rest, both ascending */
 	std::vector<int32_t> posCol((size_t) d.WQ * 128, -1), colPos(L, -1);
 	{
@@ -345,11 +358,12 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		if((rc = dev_upload(db, &q, pc, (size_t) HU_PC_COUNT)) != HU_OK) return fail(rc); d.placeConst = q;
 	}
 	if((rc = init_sym_map()) != HU_OK) return fail(rc);
+	built = true;
 	*out = db;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_db_create"); }
 
-extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) {
+extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) try {
 	if(!hmm_path || !ptu_path || !out) { hu_set_error("hu_db_load: null argument"); return HU_ERR_ARG; }
 	*out = nullptr;
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
@@ -364,11 +378,12 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	double* stage[2] = {nullptr, nullptr};
 	hipStream_t st = nullptr;
 	hipEvent_t ev[2] = {nullptr, nullptr};
-	auto cleanup = [&](bool keepMsgs) {
+	bool keepMsgs = false;
+	HuScope guard([&] { /* on every way out, an exception of the reader included */
 		for(int i = 0; i < 2; ++i) { if(stage[i]) (void) hipHostFree(stage[i]); if(ev[i]) (void) hipEventDestroy(ev[i]); }
 		if(st) (void) hipStreamDestroy(st);
 		if(!keepMsgs) { if(dUp) (void) hipFree(dUp); if(dDown) (void) hipFree(dDown); }
-	};
+	});
 	size_t row = 0; int turn = 0; hipError_t herr = hipSuccess;
 	const std::function<int(bool, int64_t, const double*)> sink = [&](bool isDown, int64_t node, const double* data) -> int {
 		if(!dUp) { /* first message: n and csLen are known */
@@ -390,9 +405,9 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	if(rc == HU_OK && st && (herr = hipStreamSynchronize(st)) != hipSuccess) rc = HU_ERR_DEVICE;
 	if(rc != HU_OK) {
 		if(herr != hipSuccess) hu_set_error("hu_db_load: moving the messages to the device failed: %s", hipGetErrorString(herr));
-		cleanup(false); return rc;
+		return rc;
 	}
-	if(K > t.csLen) { hu_set_error("HMM profile size is greater than the tree's CS length"); cleanup(false); return HU_ERR_ARG; }
+	if(K > t.csLen) { hu_set_error("HMM profile size is greater than the tree's CS length"); return HU_ERR_ARG; }
 	hu_profile_desc pd{K, t.csLen, EM.data(), EI.data(), T.data(), p2cs.data()};
 	hu_tree_desc td;
 	memset(&td, 0, sizeof(td));
@@ -400,10 +415,10 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	td.up = dUp; td.down = dDown; td.msgs_on_device = 1;
 	td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
 	rc = hu_db_create(&pd, &td, &t.model, device, out);
-	cleanup(rc == HU_OK);
+	keepMsgs = rc == HU_OK;
 	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; (*out)->allocs.push_back(dUp); (*out)->allocs.push_back(dDown); }   /* the database owns them */
 	return rc;
-}
+} catch(...) { return hu_catch_all("hu_db_load"); }
 
 /* PTUnrooted::save (src/PhyloTreeUnrooted.cpp:537-567 and :116-129, :595-603, :632-670, :672-697; src/DigitalSeq.cpp:96-104;
  * src/util/ProgEnv.cpp:24-28): the database file hmmufotu / hu_db_load read.  The messages may live on the device (98 GB at
@@ -431,7 +446,7 @@ static std::string model_text_of(const hu_model_desc& m) {
 	return o;
 }
 extern "C" int hu_ptu_write(const char* path, const hu_tree_desc* t, const char* const* names, const char* const* annos, const hu_model_desc* model,
-		const char* model_text, double dg_alpha, const double* dg_breaks) {
+		const char* model_text, double dg_alpha, const double* dg_breaks) try {
 	if(!path || !t || !model || t->n_nodes < 2 || t->cs_len < 1 || !t->parent || !t->blen || !t->seq || !t->up || !t->down || !t->height) { hu_set_error("hu_ptu_write: bad argument"); return HU_ERR_ARG; }
 	if(model->type < 0 || model->type > HU_JC69 || model->dg_k < 0 || model->dg_k > HU_MAX_DGK) { hu_set_error("hu_ptu_write: bad model"); return HU_ERR_ARG; }
 	if(t->win_len > 0 && t->win_len != t->cs_len) { hu_set_error("hu_ptu_write: the file format holds whole messages, not a column window"); return HU_ERR_ARG; }
@@ -516,10 +531,10 @@ extern "C" int hu_ptu_write(const char* path, const hu_tree_desc* t, const char*
 	f.flush();
 	if(!f) { hu_set_error("writing PTU file '%s' failed", path); return HU_ERR_IO; }
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_ptu_write"); }
 
 /* the reference's own text forms, parsed from memory: what operator<<(ostream&, const BandedHMMP7&) and DNASubModel::write emit */
-extern "C" int hu_profile_parse_text(const char* text, int64_t len, int32_t* K, int32_t* L, double* EM, double* EI, double* T, int32_t* p2cs) {
+extern "C" int hu_profile_parse_text(const char* text, int64_t len, int32_t* K, int32_t* L, double* EM, double* EI, double* T, int32_t* p2cs) try {
 	if(!text || len < 0 || !K || !L) { hu_set_error("hu_profile_parse_text: bad argument"); return HU_ERR_ARG; }
 	std::istringstream in(std::string(text, (size_t) len));
 	HuProfileHost prof; std::vector<double> vEM, vEI, vT; std::vector<int32_t> vp; int k = 0, l = 0;
@@ -529,17 +544,17 @@ extern "C" int hu_profile_parse_text(const char* text, int64_t len, int32_t* K, 
 	if(EM) memcpy(EM, vEM.data(), vEM.size() * 8); if(EI) memcpy(EI, vEI.data(), vEI.size() * 8);
 	if(T) memcpy(T, vT.data(), vT.size() * 8); if(p2cs) memcpy(p2cs, vp.data(), vp.size() * 4);
 	return HU_OK;
-}
-extern "C" int hu_model_parse_text(const char* text, int64_t len, hu_model_desc* out) {
+} catch(...) { return hu_catch_all("hu_profile_parse_text"); }
+extern "C" int hu_model_parse_text(const char* text, int64_t len, hu_model_desc* out) try {
 	if(!text || len < 0 || !out) { hu_set_error("hu_model_parse_text: bad argument"); return HU_ERR_ARG; }
 	std::istringstream in(std::string(text, (size_t) len));
 	return hu_read_model_text(in, *out);
-}
+} catch(...) { return hu_catch_all("hu_model_parse_text"); }
 
 /* host-only parse of the two files (no device needed): used by the format tests */
 extern "C" int hu_files_parse(const char* hmm_path, const char* ptu_path, int32_t* K, int32_t* L, int32_t* n_nodes, int32_t* root,
 		double* EM, double* EI, double* T, int32_t* p2cs, double* entryC, double* exitC,
-		int32_t* parent, double* blen, int8_t* seq, double* height, double* up, double* down, hu_model_desc* model, int fill) {
+		int32_t* parent, double* blen, int8_t* seq, double* height, double* up, double* down, hu_model_desc* model, int fill) try {
 	int k = 0, l = 0;
 	HuProfileHost prof; std::vector<double> vEM, vEI, vT; std::vector<int32_t> vp;
 	if(hmm_path) {
@@ -566,20 +581,20 @@ extern "C" int hu_files_parse(const char* hmm_path, const char* ptu_path, int32_
 		}
 	}
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_files_parse"); }
 
-extern "C" void hu_db_destroy(hu_db* db) {
+extern "C" void hu_db_destroy(hu_db* db) try {
 	if(!db) return;
 	for(void* p : db->allocs) (void) hipFree(p);
 	delete db;
-}
-extern "C" int hu_db_info(const hu_db* db, int32_t* K, int32_t* cs_len, int32_t* n_nodes, int32_t* root, int64_t* hbm_bytes) {
+} catch(...) { (void) hu_catch_all("hu_db_destroy"); }
+extern "C" int hu_db_info(const hu_db* db, int32_t* K, int32_t* cs_len, int32_t* n_nodes, int32_t* root, int64_t* hbm_bytes) try {
 	if(!db) return HU_ERR_ARG;
 	if(K) *K = db->dev.K; if(cs_len) *cs_len = db->dev.csLen; if(n_nodes) *n_nodes = db->dev.nNodes;
 	if(root) *root = db->dev.root; if(hbm_bytes) *hbm_bytes = db->hbmBytes;
 	return HU_OK;
-}
-extern "C" int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double* T, int32_t* p2cs, double* entry_cost, double* exit_cost) {
+} catch(...) { return hu_catch_all("hu_db_info"); }
+extern "C" int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double* T, int32_t* p2cs, double* entry_cost, double* exit_cost) try {
 	if(!db) return HU_ERR_ARG;
 	const HuProfileHost& p = db->prof;
 	if(EM) memcpy(EM, p.EM.data(), p.EM.size() * 8); if(EI) memcpy(EI, p.EI.data(), p.EI.size() * 8);
@@ -587,18 +602,18 @@ extern "C" int hu_db_get_profile(const hu_db* db, double* EM, double* EI, double
 	if(entry_cost) memcpy(entry_cost, p.entryC.data(), p.entryC.size() * 8);
 	if(exit_cost) memcpy(exit_cost, p.exitC.data(), p.exitC.size() * 8);
 	return HU_OK;
-}
-extern "C" int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, int8_t* seq, double* height) {
+} catch(...) { return hu_catch_all("hu_db_get_profile"); }
+extern "C" int hu_db_get_tree(const hu_db* db, int32_t* parent, double* blen, int8_t* seq, double* height) try {
 	if(!db) return HU_ERR_ARG;
 	if(parent) memcpy(parent, db->parent.data(), db->parent.size() * 4); if(blen) memcpy(blen, db->blen.data(), db->blen.size() * 8);
 	if(seq) memcpy(seq, db->seq.data(), db->seq.size()); if(height) memcpy(height, db->height.data(), db->height.size() * 8);
 	return HU_OK;
-}
-extern "C" const char* hu_db_get_annotation(const hu_db* db, int32_t node) {
+} catch(...) { return hu_catch_all("hu_db_get_tree"); }
+extern "C" const char* hu_db_get_annotation(const hu_db* db, int32_t node) try {
 	if(!db || node < 0 || node >= (int32_t) db->annos.size()) return "";
 	return db->annos[node].c_str();
-}
-extern "C" int hu_db_get_model(const hu_db* db, hu_model_desc* out) { if(!db || !out) return HU_ERR_ARG; *out = db->mdesc; return HU_OK; }
+} catch(...) { (void) hu_catch_all("hu_db_get_annotation"); return ""; }
+extern "C" int hu_db_get_model(const hu_db* db, hu_model_desc* out) try { if(!db || !out) return HU_ERR_ARG; *out = db->mdesc; return HU_OK; } catch(...) { return hu_catch_all("hu_db_get_model"); }
 
 __global__ void k_model_pr(HuModelDev mdl, int n, const double* __restrict__ t, double* __restrict__ P) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,7 +627,7 @@ __global__ void k_model_pr(HuModelDev mdl, int n, const double* __restrict__ t, 
 		for(int r = 0; r < 4; ++r) P[(size_t) i * 16 + r * 4 + col] = c[r];
 	}
 }
-extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P) {
+extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P) try {
 	if(!db || n < 0) return HU_ERR_ARG;
 	HIPCHK(hipSetDevice(db->device));
 	DBuf<double> dt, dP;
@@ -624,11 +639,11 @@ extern "C" int hu_db_model_pr(const hu_db* db, int n, const double* t, double* P
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpy(P, dP.p, (size_t) n * 128, hipMemcpyDeviceToHost));
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_db_model_pr"); }
 
 /* ------------------------------------------------------------------------------ tree pre-evaluation */
 extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent, const double* blen, int8_t* seq,
-		const hu_model_desc* model, int device, int64_t win_start, int64_t win_len, double* up_dev, double* down_dev, double* height) {
+		const hu_model_desc* model, int device, int64_t win_start, int64_t win_len, double* up_dev, double* down_dev, double* height) try {
 	if(n < 2 || cs_len < 1 || !parent || !blen || !seq || !model || !up_dev || !down_dev) { hu_set_error("hu_tree_evaluate: bad argument"); return HU_ERR_ARG; }
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
 	if(win_len <= 0) { win_start = 0; win_len = cs_len; }
@@ -661,8 +676,8 @@ extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent
 	HuTreeDev t;
 	t.n = n; t.csLen = cs_len; t.root = root; t.winStart = win_start; t.winLen = win_len; t.up = up_dev; t.down = down_dev;
 	int32_t *dPar = nullptr, *dOff = nullptr, *dIdx = nullptr, *dOrd = nullptr; double* dLen = nullptr; int8_t* dSeq = nullptr;
-	auto cleanup = [&]() { (void) hipFree(dPar); (void) hipFree(dOff); (void) hipFree(dIdx); (void) hipFree(dOrd); (void) hipFree(dLen); (void) hipFree(dSeq); };
-	#define TCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { hu_set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return HU_ERR_DEVICE; } } while(0)
+	HuScope guard([&] { (void) hipFree(dPar); (void) hipFree(dOff); (void) hipFree(dIdx); (void) hipFree(dOrd); (void) hipFree(dLen); (void) hipFree(dSeq); });
+	#define TCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { hu_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return HU_ERR_DEVICE; } } while(0)
 	TCHK(hipMalloc((void**) &dPar, (size_t) n * 4)); TCHK(hipMalloc((void**) &dOff, (size_t)(n + 1) * 4)); TCHK(hipMalloc((void**) &dIdx, childIdx.size() * 4));
 	TCHK(hipMalloc((void**) &dOrd, (size_t) n * 4)); TCHK(hipMalloc((void**) &dLen, (size_t) n * 8)); TCHK(hipMalloc((void**) &dSeq, (size_t) n * cs_len));
 	TCHK(hipMemcpy(dPar, parent, (size_t) n * 4, hipMemcpyHostToDevice)); TCHK(hipMemcpy(dOff, cnt.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
@@ -683,13 +698,12 @@ extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent
 	TCHK(hipDeviceSynchronize());
 	TCHK(hipMemcpy(seq, dSeq, (size_t) n * cs_len, hipMemcpyDeviceToHost));
 	#undef TCHK
-	cleanup();
 	if(height) { /* calcNodeHeight: distance to the nearest descendant leaf (src/PhyloTreeUnrooted.cpp:274-287) */
 		for(int i = 0; i < n; ++i) height[i] = cnt[i] == cnt[i + 1] ? 0.0 : kInf;
 		for(int h = n - 1; h > 0; --h) { const int u = order[h], p = parent[u]; height[p] = std::min(height[p], height[u] + blen[u]); }
 	}
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_tree_evaluate"); }
 
 /* ------------------------------------------------------------------------------ batch */
 
@@ -727,6 +741,9 @@ struct HuKnobs {
 	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
 	int scan_lds_pad = 0;        /* the same for the distance-only scan                                               */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
+	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
+	                              * host pool, 2 = std::length_error on the calling thread of the finish stage, 3 = std::runtime_error in a pool worker
+	                              * of the TSV formatter.  Never set by the product */
 };
 struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
@@ -735,7 +752,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace},
+	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -793,6 +810,7 @@ struct hu_batch {
 	std::vector<HuReadDesc> hDescs;
 	std::vector<char> hBases;
 	PinnedVec<HuVitOut> hVit;
+	int64_t cellsTotal = 0, cornerTotal = 0;   /* DP cells of all phases of all sequences / of their corner blocks (set with the reads) */
 	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
 	int nFullRedo = 0;          /* sequences of the last align call whose banded DP found no path: full DP, one launch */
 	PinnedVec<HuAlnDev> hAlns;
@@ -816,7 +834,7 @@ struct Timer {
 	~Timer() { if(b->profile) { (void) hipEventRecord(b->ev[2 * id + 1], b->stream); b->evSet[id] = true; } }
 };
 
-extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) {
+extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) try {
 	if(!db || !out || max_reads < 1) { hu_set_error("hu_batch_create: bad argument"); return HU_ERR_ARG; }
 	HIPCHK(hipSetDevice(db->device));
 	hu_batch* b = new hu_batch;
@@ -835,24 +853,24 @@ extern "C" int hu_batch_create(hu_db* db, int max_reads, hu_batch** out) {
 	}
 	*out = b;
 	return HU_OK;
-}
-extern "C" int hu_batch_set_knob(hu_batch* b, const char* name, int value) {
+} catch(...) { return hu_catch_all("hu_batch_create"); }
+extern "C" int hu_batch_set_knob(hu_batch* b, const char* name, int value) try {
 	if(!b || !name) return HU_ERR_ARG;
 	for(const HuKnobEntry& e : kKnobs) if(strcmp(e.name, name) == 0) { b->knob.*(e.field) = value; return HU_OK; }
 	hu_set_error("hu_batch_set_knob: no knob named '%s'", name);
 	return HU_ERR_ARG;
-}
-extern "C" void hu_batch_destroy(hu_batch* b) {
+} catch(...) { return hu_catch_all("hu_batch_set_knob"); }
+extern "C" void hu_batch_destroy(hu_batch* b) try {
 	if(!b) return;
 	(void) hipSetDevice(b->db->device);
 	(void) hipStreamSynchronize(b->stream);
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;      /* the DBuf members free their device memory */
-}
-extern "C" int hu_batch_sync(hu_batch* b) { if(!b) return HU_ERR_ARG; HIPCHK(hipStreamSynchronize(b->stream)); return HU_OK; }
-extern "C" int hu_batch_profile(hu_batch* b, int enable) { if(!b) return HU_ERR_ARG; b->profile = enable != 0; return HU_OK; }
-extern "C" int hu_batch_timings(hu_batch* b, float* ms) {
+} catch(...) { (void) hu_catch_all("hu_batch_destroy"); }
+extern "C" int hu_batch_sync(hu_batch* b) try { if(!b) return HU_ERR_ARG; HIPCHK(hipStreamSynchronize(b->stream)); return HU_OK; } catch(...) { return hu_catch_all("hu_batch_sync"); }
+extern "C" int hu_batch_profile(hu_batch* b, int enable) try { if(!b) return HU_ERR_ARG; b->profile = enable != 0; return HU_OK; } catch(...) { return hu_catch_all("hu_batch_profile"); }
+extern "C" int hu_batch_timings(hu_batch* b, float* ms) try {
 	if(!b || !ms) return HU_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(b->stream));
 	for(int i = 0; i < HU_T_COUNT; ++i) {
@@ -861,7 +879,7 @@ extern "C" int hu_batch_timings(hu_batch* b, float* ms) {
 		ms[i] = b->ms[i];
 	}
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_batch_timings"); }
 
 /* banded phases of calcViterbiScores as region descriptors (src/BandedHMMP7.cpp:794-881) */
 static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */, HuReadDesc& rd) {
@@ -913,8 +931,22 @@ static void build_regions(const hu_db* db, int L, const int32_t* vp /* [2][6] */
 		if(down_to > L) down_to = L;
 		add(last.end, down_end, last.to, down_to, 0, 0, nullptr);
 	}
+	/* corner blocks (HuRegion::ci0 / cj0 / coff): what a later phase can look up of an earlier one */
+	int64_t coff = 0;
+	for(int r = 0; r < rd.nRegions; ++r) {
+		HuRegion& g = rd.reg[r];
+		int nearI = INT32_MAX, nearJ = INT32_MAX;
+		for(int r2 = r + 1; r2 < rd.nRegions; ++r2) {
+			const HuRegion& g2 = rd.reg[r2];
+			if(g2.i1 >= g2.i0 && g2.j1 >= g2.j0) { nearI = std::min(nearI, g2.i0 - 1); nearJ = std::min(nearJ, g2.j0 - 1); }
+		}
+		g.ci0 = std::max(g.i0, nearI); g.cj0 = std::max(g.j0, nearJ); g.coff = coff;
+		if(nearI == INT32_MAX || g.ci0 > g.i1 || g.cj0 > g.j1 || g.i1 < g.i0 || g.j1 < g.j0) { g.ci0 = g.i1 + 1; g.cj0 = g.j1 + 1; }   /* empty block */
+		else coff += (int64_t)(g.i1 - g.ci0 + 1) * (g.j1 - g.cj0 + 1);
+	}
 	rd.scratchOff = off; /* total cells for now; turned into an offset by the caller */
 	rd.decOff = doff;    /* likewise: total decision bytes */
+	rd.cornerOff = coff; /* likewise: total corner cells */
 }
 
 static int upload_descs(hu_batch* b) {
@@ -925,7 +957,7 @@ static int upload_descs(hu_batch* b) {
 }
 
 extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const int64_t* offs, const int32_t* vpaths,
-		const char* mates, const int64_t* moffs, const int32_t* mvpaths) {
+		const char* mates, const int64_t* moffs, const int32_t* mvpaths) try {
 	if(!b || n < 0 || n > b->maxReads || (n > 0 && (!bases || !offs))) { hu_set_error("hu_batch_set_reads: bad argument"); return HU_ERR_ARG; }
 	if(mates && !moffs) { hu_set_error("hu_batch_set_reads: mates without offsets"); return HU_ERR_ARG; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -937,7 +969,7 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 		const int64_t l = (offs[r + 1] - offs[r]) + (mates ? moffs[r + 1] - moffs[r] : 0);
 		if(l > b->maxBases) b->maxBases = (int) std::min<int64_t>(l, 1 << 30);
 	}
-	int64_t cells = 0, tr = 0, decs = 0;
+	int64_t cells = 0, tr = 0, decs = 0, corners = 0;
 	for(int s = 0; s < b->nSeq; ++s) {
 		const bool isMate = s >= n;
 		const int r = isMate ? s - n : s;
@@ -953,9 +985,10 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 			b->hBases.insert(b->hBases.end(), src, src + len64);
 			const int32_t* vp = isMate ? (mvpaths ? mvpaths + (size_t) r * 12 : nullptr) : (vpaths ? vpaths + (size_t) r * 12 : nullptr);
 			build_regions(b->db, rd.len, vp, rd);
-			const int64_t c = rd.scratchOff, dc = rd.decOff;
+			const int64_t c = rd.scratchOff, dc = rd.decOff, cc = rd.cornerOff;
 			rd.scratchOff = cells; cells += c;
 			rd.decOff = decs; decs += dc;
+			rd.cornerOff = corners; corners += cc;
 		}
 		else { rd.len = 0; rd.nRegions = 0; }
 		rd.traceOff = tr;
@@ -963,7 +996,7 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 	}
 	int rc;
 	if((rc = b->dBases.ensure(b->hBases.size() + 1)) != HU_OK) return rc;
-	if((rc = b->dScratch.ensure((size_t) cells * 3 + 1)) != HU_OK) return rc;
+	b->cellsTotal = cells; b->cornerTotal = corners;    /* the DP scratch is sized by hu_align_batch: which kernel runs decides how much it needs */
 	if((rc = b->dDec.ensure((size_t) decs + 1)) != HU_OK) return rc;
 	if((rc = b->dTraces.ensure((size_t) tr + 1)) != HU_OK) return rc;
 	if((rc = b->dVit.ensure(b->nSeq)) != HU_OK) return rc;
@@ -971,7 +1004,7 @@ extern "C" int hu_batch_set_reads(hu_batch* b, int n, const char* bases, const i
 	if((rc = upload_descs(b)) != HU_OK) return rc;
 	b->state = ST_READS;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_batch_set_reads"); }
 
 static int ensure_read_buffers(hu_batch* b) {
 	const HuDbDev& d = b->db->dev;
@@ -1054,11 +1087,11 @@ static int set_aligned_impl(hu_batch* b, int n, const int8_t* codes, hipMemcpyKi
 	b->state = ST_ALIGNED;
 	return HU_OK;
 }
-extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) {
+extern "C" int hu_batch_set_aligned(hu_batch* b, int n, const int8_t* codes, const int32_t* start, const int32_t* end) try {
 	return set_aligned_impl(b, n, codes, hipMemcpyHostToDevice, start, end);
-}
+} catch(...) { return hu_catch_all("hu_batch_set_aligned"); }
 
-extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_READS || b->fromCodes) { hu_set_error("hu_align_batch: no reads set"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1079,6 +1112,10 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 		bool usedDec = false;
 		int decRpl = 0;
 		const size_t vlds = (size_t) 9 * ldsRows * sizeof(double);
+		/* The one-wave kernel files (M, I, D) only of the corner blocks (a few cells per read); every other kernel keeps all three values of
+		 * every cell of every phase: 2-3 MB per 250-base read, 16 GB per batch of 8,192 — allocated only when such a kernel is going to run. */
+		const bool wavePath = vlds <= 96 * 1024 && !kb.viterbi_hbm && !kb.viterbi_values && !(kb.viterbi_mode ? kb.viterbi_mode : (kb.viterbi_dec1 ? 1 : 0)) && maxLen <= 512;
+		if((rc = b->dScratch.ensure((size_t)(wavePath ? b->cornerTotal : b->cellsTotal) * 3 + 1)) != HU_OK) return rc;
 		{
 			Timer t(b, HU_T_VITERBI);
 			if(vlds <= 96 * 1024 && !kb.viterbi_hbm) { /* LDS-staged wavefront; longer reads take the HBM-staged kernel */
@@ -1127,7 +1164,40 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 			int nRedo = 0;
 			for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_VALUES) nRedo++;
 			b->nVitRedo = nRedo;
-			if(nRedo) {
+			if(nRedo && wavePath) { /* the batch holds corner scratch only: the few sequences to redo get a full-size scratch of their own, in launches of <= 48 M cells */
+				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+				std::vector<int> rs;
+				for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_VALUES) rs.push_back(s);
+				const int64_t cap = 48ll << 20;
+				for(size_t at = 0; at < rs.size();) {
+					std::vector<HuReadDesc> rdv; std::vector<HuVitOut> hv;
+					int64_t cells = 0; size_t e = at;
+					for(; e < rs.size(); ++e) {
+						HuReadDesc rd = b->hDescs[rs[e]];
+						int64_t c = 0;                         /* cells of all its phases, as build_regions laid them out */
+						for(int g = 0; g < rd.nRegions; ++g) if(rd.reg[g].j1 >= rd.reg[g].j0 && rd.reg[g].i1 >= rd.reg[g].i0) c += (int64_t)(rd.reg[g].j1 - rd.reg[g].j0 + 1) * (rd.reg[g].i1 - rd.reg[g].i0 + 1);
+						if(!rdv.empty() && cells + c > cap) break;
+						rd.scratchOff = cells; cells += c;
+						rdv.push_back(rd); hv.push_back(b->hVit[rs[e]]);
+					}
+					DBuf<double> scr; DBuf<HuReadDesc> dd; DBuf<HuVitOut> vo;
+					if((rc = scr.ensure((size_t) cells * 3 + 1)) != HU_OK || (rc = dd.ensure(rdv.size())) != HU_OK || (rc = vo.ensure(rdv.size())) != HU_OK) return rc;
+					HIPCHK(hipMemcpyAsync(dd.p, rdv.data(), rdv.size() * sizeof(HuReadDesc), hipMemcpyHostToDevice, b->stream));
+					HIPCHK(hipMemcpyAsync(vo.p, hv.data(), hv.size() * sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
+					k_viterbi_lds<<<(unsigned) rdv.size(), HU_VIT_THREADS, vlds, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p, ldsRows, HU_READ_NEEDS_VALUES);
+					k_viterbi_trace<<<((unsigned) rdv.size() + 63) / 64, 64, 0, b->stream>>>(d, dd.p, scr.p, b->dTraces.p, tNN, tNB, vo.p, (int) rdv.size());
+					HIPCHK(hipGetLastError());
+					HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
+					HIPCHK(hipStreamSynchronize(b->stream));     /* the temporaries die here */
+					for(size_t k = 0; k < rdv.size(); ++k) {
+						b->hVit[rs[at + k]] = hv[k];               /* the trace is written at the sequence's own traceOff */
+						HIPCHK(hipMemcpyAsync(b->dVit.p + rs[at + k], &b->hVit[rs[at + k]], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
+					}
+					HIPCHK(hipStreamSynchronize(b->stream));
+					at = e;
+				}
+			}
+			else if(nRedo) {
 				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
 				k_viterbi_lds<<<b->nSeq, HU_VIT_THREADS, vlds, b->stream>>>(d, b->dDescs.p, b->dBases.p, b->dScratch.p, b->dTraces.p, tNN, tNB, tEC, tCC, b->dVit.p, ldsRows, HU_READ_NEEDS_VALUES);
 				k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
@@ -1199,11 +1269,12 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) {
 	}
 	b->state = ST_ALIGNED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_align_batch"); }
 
+__global__ void k_seed_drop_empty(int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int32_t* __restrict__ seedCnt);
 static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p, (const uint2*) b->dRSpan.p}; }
 
-extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch: reads are not aligned"); return HU_ERR_STATE; }
 	if(o->max_nseed < 1 || o->max_nseed > HU_MAX_SEEDS) { hu_set_error("max_nseed must be in 1..%d", HU_MAX_SEEDS); return HU_ERR_ARG; }
@@ -1267,6 +1338,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 				k_parent_pairs<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, b->n, b->dPairs.p, b->pair16 ? 1 : 0, b->dSeedCnt.p, b->dSeedId.p, b->dParDN.p);
 			}
 		}
+		k_seed_drop_empty<<<(b->n + 255) / 256, 256, 0, b->stream>>>(b->n, b->dStart.p, b->dEnd.p, b->dSeedCnt.p);
 		HIPCHK(hipGetLastError());
 		if(stat) {
 			uint32_t h[16];
@@ -1279,6 +1351,16 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) {
 	b->seedCap = o->max_nseed;
 	b->state = ST_SEEDED;
 	return HU_OK;
+} catch(...) { return hu_catch_all("hu_seed_batch"); }
+
+/* A read whose region is empty (not aligned, outside the resident message window, a segment of no columns) has no seeds, whatever the
+ * top-k made of its all-zero distance row ("reads without bases take the first nodes by id"): the stages behind form message addresses
+ * from (node, region start), and with no seeds none of them touches such a read.  This is the guard at the source for the fault of
+ * round 2 (gpurun_out/t_r2e.log: an out-of-window read kept the region (0, -1), its seed list named node 0, and k_estimate_prod loaded
+ * up[(0 * winLen + (0 - winStart)) * 4] — 40 columns BEFORE the first message of the window: a GPU memory fault, which ends the process). */
+__global__ void k_seed_drop_empty(int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int32_t* __restrict__ seedCnt) {
+	const int r = blockIdx.x * 256 + threadIdx.x;
+	if(r < n && rend[r] < rstart[r]) seedCnt[r] = 0;
 }
 
 /* given seed nodes: their (d, N) and their parents' over the current regions, straight from the bit-planes (no scan) */
@@ -1295,7 +1377,7 @@ __global__ void k_seed_given(HuDbDev db, HuReadPlanes R, int n, const int32_t* _
 	}
 }
 
-extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride) {
+extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const int32_t* ids, const int32_t* dist_ids, int stride) try {
 	if(!b || (b->n > 0 && (!n_seeds || !ids)) || stride < 1) { hu_set_error("hu_seed_batch_given: bad argument"); return HU_ERR_ARG; }
 	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch_given: reads are not aligned"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1328,6 +1410,7 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 			Timer t(b, HU_T_SEED_PDIST);
 			k_seed_given<<<((unsigned) n * HU_MAX_SEEDS + 255) / 256, 256, 0, b->stream>>>(d, read_planes(b), b->n, b->dGiven.p, b->dGiven.p + n,
 					dist_ids ? b->dGiven.p + n + n * HU_MAX_SEEDS : nullptr, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p);
+			k_seed_drop_empty<<<(b->n + 255) / 256, 256, 0, b->stream>>>(b->n, b->dStart.p, b->dEnd.p, b->dSeedCnt.p);
 		}
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
@@ -1336,7 +1419,7 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 	for(size_t r = 0; r < n; ++r) b->seedCap = std::max(b->seedCap, (int) n_seeds[r]);
 	b->state = ST_SEEDED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_seed_batch_given"); }
 
 /* (read, seed) slots -> sort key = seed node (invalid slots last) */
 __global__ void k_seed_sortkeys(int n, const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
@@ -1346,7 +1429,7 @@ __global__ void k_seed_sortkeys(int n, const int32_t* __restrict__ seedCnt, cons
 	val[i] = (uint32_t) i;
 }
 
-extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("hu_estimate_batch: no seeds"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1412,12 +1495,12 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) {
 	}
 	b->state = ST_ESTIMATED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_estimate_batch"); }
 
 static bool cmpLoglik(const HostPlace& l, const HostPlace& r) { return l.loglik < r.loglik; }
 static bool cmpQPlace(const HostPlace& l, const HostPlace& r) { return l.qPlace < r.qPlace; }
 
-extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_ESTIMATED) { hu_set_error("hu_filter_batch: no estimates"); return HU_ERR_STATE; }
 	if(!(o->max_error >= 0)) { hu_set_error("max_error must be >= 0"); return HU_ERR_ARG; }
@@ -1437,7 +1520,9 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 	b->candOffs.assign(n + 1, 0);
 	b->tmpPlaces.resize(n * HU_MAX_SEEDS);       /* per read: its <= 64 estimates, sorted in place; the first candOffs-many are kept */
 	const double maxError = o->max_error;
+	const int fault = b->knob.inject_fault;
 	parallel_for(n, [&](size_t r) {
+		if(fault == 1 && r + 1 == n) throw std::bad_alloc();
 		HostPlace* pl = b->tmpPlaces.data() + r * HU_MAX_SEEDS;
 		const int cnt = b->hAlns[r].status == HU_READ_OK ? b->hSeedCnt[r] : 0;
 		for(int s = 0; s < cnt; ++s) {
@@ -1472,7 +1557,7 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) {
 	});
 	b->state = ST_FILTERED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_filter_batch"); }
 
 __global__ void k_cand_sortkeys(int nc, const HuCand* __restrict__ cands, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1480,7 +1565,7 @@ __global__ void k_cand_sortkeys(int nc, const HuCand* __restrict__ cands, uint32
 	key[i] = (uint32_t) cands[i].node; val[i] = (uint32_t) i;
 }
 
-extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_FILTERED) { hu_set_error("hu_place_batch: candidates are not filtered"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1624,16 +1709,17 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) {
 	b->fixedRoot = o->fix_root_loglik != 0 && nc > 0;
 	b->state = ST_PLACED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_place_batch"); }
 
 static double add_scaled(double a, double c) { double s = std::max(a, c); return std::log(std::exp(a - s) + std::exp(c - s)) + s; }
 static double p2q(double p) { return -10 * std::log(p) / std::log(10.0); }
 
-extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_PLACED) { hu_set_error("hu_finish_batch: candidates are not placed"); return HU_ERR_STATE; }
 	const hu_db* db = b->db;
 	const size_t n = (size_t) b->n;
+	if(b->knob.inject_fault == 2) throw std::length_error("injected");
 	b->best.assign(n, hu_place_rec());
 	/* the root message is re-initialised to INVALID_LOGLIK = 1 before treeLoglik reads it, so every
 	 * placement's final loglik is (end-start+1) * log(sum_i pi_i e^1) (src/PhyloTreeUnrooted.cpp:918-922,
@@ -1702,9 +1788,9 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) {
 	});
 	b->state = ST_FINISHED;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_finish_batch"); }
 
-extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) try {
 	int rc;
 	if(!b || !o) return HU_ERR_ARG;
 	auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1722,14 +1808,14 @@ extern "C" int hu_assign_batch(hu_batch* b, const hu_opts* o) {
 	auto t4 = now();
 	b->wall[0] = ms(t0, t1); b->wall[1] = ms(t1, t2); b->wall[2] = ms(t2, t3); b->wall[3] = ms(t3, t4);
 	return rc;
-}
+} catch(...) { return hu_catch_all("hu_assign_batch"); }
 /* ------------------------------------------------------------------------------ chimera check (-C)
  * src/hmmufotu.cpp:653-691 as batch passes: each of the num_seg segments, then the two alt placements, is one
  * run of the given-seed / estimate / filter / place stages in the work batch over per-read regions. */
-extern "C" void hu_default_chimera_opts(const hu_opts* o, hu_chimera_opts* co) {
+extern "C" void hu_default_chimera_opts(const hu_opts* o, hu_chimera_opts* co) try {
 	if(!co) return;
 	co->num_seg = 2; co->reserved = 0; co->max_chimera_error = (o ? o->max_error : 20.0) / co->num_seg; co->min_chimera_lod = 0;
-}
+} catch(...) { (void) hu_catch_all("hu_default_chimera_opts"); }
 static hu_place_rec to_rec(const HostPlace& p, int32_t nCand);
 struct SegPlace { HostPlace p; int32_t start, end; };
 static bool cmpSegLoglik(const SegPlace& l, const SegPlace& r) { return l.p.loglik < r.p.loglik; }
@@ -1746,7 +1832,7 @@ static int segment_pass(hu_batch* w, hu_batch* b, const hu_opts* o, double maxEr
 	return hu_finish_batch(w, &so);
 }
 
-extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out) {
+extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out) try {
 	if(!b || !w || !o || !co || (b->n > 0 && !out) || b == w) { hu_set_error("hu_chimera_batch: bad argument"); return HU_ERR_ARG; }
 	if(w->db != b->db || w->maxReads < b->n) { hu_set_error("hu_chimera_batch: the work batch must sit on the same database and hold %d reads", b->n); return HU_ERR_ARG; }
 	if(b->state < ST_SEEDED) { hu_set_error("hu_chimera_batch: reads are not seeded"); return HU_ERR_STATE; }
@@ -1821,12 +1907,12 @@ extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, cons
 		c.is_chimera = s5.p.aNode != s3.p.aNode && c.lod > co->min_chimera_lod;
 	}
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_chimera_batch"); }
 /* host wall-clock of the last hu_assign_batch: align | seed+estimate+filter | place | finish (ms) */
-extern "C" int hu_batch_wall(hu_batch* b, double* ms4) { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; }
+extern "C" int hu_batch_wall(hu_batch* b, double* ms4) try { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; } catch(...) { return hu_catch_all("hu_batch_wall"); }
 
 /* ------------------------------------------------------------------------------ host helpers */
-extern "C" int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6) {
+extern "C" int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6) try {
 	if(!db || !cs || !out6) return HU_ERR_ARG;
 	(void) cs_end; (void) cs_to;
 	const std::vector<int32_t>& cs2p = db->prof.cs2p;
@@ -1844,7 +1930,7 @@ extern "C" int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, co
 	}
 	out6[0] = start; out6[1] = end; out6[2] = from; out6[3] = to; out6[4] = nIns; out6[5] = nDel;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_build_align_path"); }
 
 extern "C" const char* hu_tsv_header(void) {
 	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"
@@ -1878,7 +1964,9 @@ static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* 
 		const bool flagged = chi && a.status == HU_READ_OK && chi[r].is_chimera;
 		return which != 1 ? !(a.status != HU_READ_OK || flagged) : (a.status == HU_READ_CHIMERA || flagged);
 	};
+	const int fault = b->knob.inject_fault;
 	parallel_for(n, [&](size_t r) { /* an upper bound of the line's length */
+		if(fault == 3 && r + 1 == n) throw std::runtime_error("injected");
 		if(!wanted(r)) { off[r + 1] = 0; return; }
 		size_t len = strlen(ids[r]) + (descs && descs[r] ? strlen(descs[r]) : 0) + (size_t) L + 6 * 12 + 40 + 16 /* tabs, newline */ + 2 * 12 + 16 + 12 + 5 * 40;
 		if(info) {
@@ -1936,21 +2024,21 @@ static int64_t format_copy(hu_batch* b, int64_t need, char* buf, int64_t cap) {
 	return need;
 }
 extern "C" int64_t hu_batch_format_tsv(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
-		char* buf, int64_t cap) {
+		char* buf, int64_t cap) try {
 	return format_copy(b, format_tsv_impl(b, ids, descs, annos, nullptr, 0, 0), buf, cap);
-}
+} catch(...) { return hu_catch_all("hu_batch_format_tsv"); }
 extern "C" int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
-		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap) {
+		const hu_chimera_rec* chi, int chimera_info, int which, char* buf, int64_t cap) try {
 	if(which < 0 || which > 2) { hu_set_error("hu_batch_format_tsv_chimera: which must be 0, 1 or 2"); return HU_ERR_ARG; }
 	return format_copy(b, format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which), buf, cap);
-}
+} catch(...) { return hu_catch_all("hu_batch_format_tsv_chimera"); }
 extern "C" int64_t hu_batch_format_tsv_ptr(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
-		const hu_chimera_rec* chi, int chimera_info, int which, const char** text) {
+		const hu_chimera_rec* chi, int chimera_info, int which, const char** text) try {
 	if(which < 0 || which > 2 || !text) { hu_set_error("hu_batch_format_tsv_ptr: bad argument"); return HU_ERR_ARG; }
 	const int64_t need = format_tsv_impl(b, ids, descs, annos, chi, chimera_info, which);
 	*text = need >= 0 ? b->tsvBuf.data() : nullptr;
 	return need;
-}
+} catch(...) { return hu_catch_all("hu_batch_format_tsv_ptr"); }
 extern "C" const char* hu_tsv_header_chimera(void) {
 	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"
 	       "seg5_taxon_id\tseg3_taxon_id\tseg5_taxon_anno\tseg3_taxon_anno\tchimera_lod\t"
@@ -1958,7 +2046,7 @@ extern "C" const char* hu_tsv_header_chimera(void) {
 }
 
 /* ------------------------------------------------------------------------------ results */
-extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align, char* trace, int trace_stride) {
+extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* align, char* trace, int trace_stride) try {
 	if(!b) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("no alignments yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1982,8 +2070,8 @@ extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* al
 		}
 	}
 	return HU_OK;
-}
-extern "C" int hu_batch_get_codes(hu_batch* b, int8_t* codes, int32_t* start, int32_t* end) {
+} catch(...) { return hu_catch_all("hu_batch_get_alignments"); }
+extern "C" int hu_batch_get_codes(hu_batch* b, int8_t* codes, int32_t* start, int32_t* end) try {
 	if(!b) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("no alignments yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -1991,8 +2079,8 @@ extern "C" int hu_batch_get_codes(hu_batch* b, int8_t* codes, int32_t* start, in
 	if(start) memcpy(start, b->hStart.data(), (size_t) b->n * 4);
 	if(end) memcpy(end, b->hEnd.data(), (size_t) b->n * 4);
 	return HU_OK;
-}
-extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N) {
+} catch(...) { return hu_catch_all("hu_batch_get_codes"); }
+extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N) try {
 	if(!b || read < 0 || read >= b->n) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("no seed scan yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -2033,14 +2121,14 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 	}
 	for(int i = 0; i < nn; ++i) { if(d) d[i] = (int32_t)(v[i] >> 16); if(N) N[i] = (int32_t)(v[i] & 0xffffu); }
 	return HU_OK;
-}
-extern "C" int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N) {
+} catch(...) { return hu_catch_all("hu_batch_get_pdist"); }
+extern "C" int hu_batch_get_seeds(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N) try {
 	return hu_batch_get_seeds_strided(b, n_seeds, ids, d, N, HU_MAX_SEEDS);
-}
-extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik) {
+} catch(...) { return hu_catch_all("hu_batch_get_seeds"); }
+extern "C" int hu_batch_get_estimates(hu_batch* b, double* ratio, double* wnr, double* loglik) try {
 	return hu_batch_get_estimates_strided(b, ratio, wnr, loglik, HU_MAX_SEEDS);
-}
-extern "C" int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N, int stride) {
+} catch(...) { return hu_catch_all("hu_batch_get_estimates"); }
+extern "C" int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t* ids, int32_t* d, int32_t* N, int stride) try {
 	if(!b || stride < 1) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("no seeds yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -2063,8 +2151,8 @@ extern "C" int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t
 		}
 	}
 	return HU_OK;
-}
-extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double* wnr, double* loglik, int stride) {
+} catch(...) { return hu_catch_all("hu_batch_get_seeds_strided"); }
+extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double* wnr, double* loglik, int stride) try {
 	if(!b || stride < 1) return HU_ERR_ARG;
 	if(b->state < ST_ESTIMATED) { hu_set_error("no estimates yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
@@ -2082,8 +2170,8 @@ extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double
 		if(loglik) loglik[w] = ok ? e[k].loglik : NAN;
 	}
 	return HU_OK;
-}
-extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters) {
+} catch(...) { return hu_catch_all("hu_batch_get_estimates_strided"); }
+extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters) try {
 	if(!b) return HU_ERR_ARG;
 	if(b->state < ST_FILTERED) { hu_set_error("no candidates yet"); return HU_ERR_STATE; }
 	if(offs) memcpy(offs, b->candOffs.data(), b->candOffs.size() * 8);
@@ -2093,7 +2181,7 @@ extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_no
 		if(est_loglik) est_loglik[c] = p.estLoglik; if(iters) iters[c] = p.iters;
 	}
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_batch_get_candidates"); }
 static hu_place_rec to_rec(const HostPlace& p, int32_t nCand) {
 	hu_place_rec r;
 	r.c_node = p.cNode; r.p_node = p.pNode; r.a_node = p.aNode; r.n_cand = nCand;
@@ -2101,16 +2189,16 @@ static hu_place_rec to_rec(const HostPlace& p, int32_t nCand) {
 	r.q_place = p.qPlace; r.q_taxon = p.qTaxon; r.anno_dist = p.annoDist(); r.est_loglik = p.estLoglik; r.root_loglik = p.rootLoglik;
 	return r;
 }
-extern "C" int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs) {
+extern "C" int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs) try {
 	if(!b || !recs) return HU_ERR_ARG;
 	if(b->state < ST_FINISHED) { hu_set_error("batch is not finished"); return HU_ERR_STATE; }
 	for(size_t r = 0; r + 1 < b->candOffs.size(); ++r)
 		for(int64_t c = b->candOffs[r]; c < b->candOffs[r + 1]; ++c) recs[c] = to_rec(b->places[c], (int32_t)(b->candOffs[r + 1] - b->candOffs[r]));
 	return HU_OK;
-}
-extern "C" int hu_batch_get_placements(hu_batch* b, hu_place_rec* best) {
+} catch(...) { return hu_catch_all("hu_batch_get_candidate_places"); }
+extern "C" int hu_batch_get_placements(hu_batch* b, hu_place_rec* best) try {
 	if(!b || !best) return HU_ERR_ARG;
 	if(b->state < ST_FINISHED) { hu_set_error("batch is not finished"); return HU_ERR_STATE; }
 	memcpy(best, b->best.data(), b->best.size() * sizeof(hu_place_rec));
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_batch_get_placements"); }

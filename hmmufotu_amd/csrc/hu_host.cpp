@@ -9,6 +9,8 @@
 #include <limits>
 #include <map>
 #include <sstream>
+#include <new>
+#include <stdexcept>
 #include "hu_common.h"
 
 static thread_local char g_err[512] = "";
@@ -20,6 +22,14 @@ void hu_set_error(const char* fmt, ...) {
 	va_end(ap);
 }
 extern "C" const char* hu_last_error(void) { return g_err; }
+
+int hu_catch_all(const char* fn) noexcept {
+	try { throw; }
+	catch(const std::bad_alloc&) { hu_set_error("%s: out of host memory (std::bad_alloc)", fn); return HU_ERR_NOMEM; }
+	catch(const std::length_error& e) { hu_set_error("%s: a size the host cannot hold (%s)", fn, e.what()); return HU_ERR_NOMEM; }
+	catch(const std::exception& e) { hu_set_error("%s: %s", fn, e.what()); return HU_ERR_STATE; }
+	catch(...) { hu_set_error("%s: unknown exception", fn); return HU_ERR_STATE; }
+}
 
 extern "C" void hu_default_opts(hu_opts* o) {
 	o->align_mode = HU_MODE_GLOBAL;
@@ -152,13 +162,13 @@ void hu_place_consts(const HuModelDev& m, double* pc) {
 }
 
 /* host-only export for CPU tests of the spectral forms */
-extern "C" int hu_model_spectral(const hu_model_desc* d, double* U, double* lam, double* U1) {
+extern "C" int hu_model_spectral(const hu_model_desc* d, double* U, double* lam, double* U1) try {
 	HuModelDev m;
 	int rc = hu_model_prepare(d, &m);
 	if(rc != HU_OK) return rc;
 	memcpy(U, m.U, sizeof(m.U)); memcpy(lam, m.lam, sizeof(m.lam)); memcpy(U1, m.U1, sizeof(m.U1));
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_model_spectral"); }
 
 /* ------------------------------------------------------------------ profile (BandedHMMP7) */
 /* post-load chain of operator>> (src/BandedHMMP7.cpp:104-109): extend_index,

@@ -740,14 +740,17 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 		return;
 	}
 	const char* __restrict__ x = bases + rd.baseOff;
-	double* scr = scratch + rd.scratchOff * 3;
+	double* scr = scratch + rd.cornerOff * 3;        /* the CORNER scratch: only cells a later phase looks up are filed (HuRegion::coff) */
 	uint8_t* dcs = dec + rd.decOff;
 	VitCtx ctx = { &rd, scr, tNN, tNB };
 	auto look = [&](int upto, int ii, int jj, double& m, double& iv, double& d) {
 		for(int rr = upto - 1; rr >= 0; --rr) {
 			const HuRegion& gg = sreg[rr];
 			if(reg_contains(gg, ii, jj)) {
-				const int64_t idx = (gg.off + (int64_t)(jj - gg.j0) * (gg.i1 - gg.i0 + 1) + (ii - gg.i0)) * 3;
+				/* every cell this kernel looks up lies in the row above / the column left of / inside a LATER phase than gg, hence in gg's
+				 * corner block (rows >= ci0, columns >= cj0); a cell outside it was never filed and reads as "not computed" */
+				if(ii < gg.ci0 || jj < gg.cj0) { m = iv = d = INFINITY; return; }
+				const int64_t idx = (gg.coff + (int64_t)(jj - gg.cj0) * (gg.i1 - gg.ci0 + 1) + (ii - gg.ci0)) * 3;
 				m = scr[idx]; iv = scr[idx + 1]; d = scr[idx + 2];
 				return;
 			}
@@ -807,8 +810,8 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				if(reg_contains(g2, i, j)) later = true;
 				if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
 			}
-			if(near) {
-				const int64_t idx = (g.off + (int64_t)(j - g.j0) * ni + (i - g.i0)) * 3;
+			if(near && i >= g.ci0 && j >= g.cj0) {
+				const int64_t idx = (g.coff + (int64_t)(j - g.cj0) * (g.i1 - g.ci0 + 1) + (i - g.ci0)) * 3;
 				scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
 			}
 			if(!later) {

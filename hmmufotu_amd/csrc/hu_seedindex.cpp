@@ -74,7 +74,7 @@ static void finish_index(hu_seed_index* ix) {
 }
 
 extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32_t* parent, const int8_t* seq,
-		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) {
+		int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) try {
 	if(!parent || !seq || !p2cs || !out || n_nodes < 1 || cs_len < 1 || cs_len > 65535 || seed_len < HU_SX_DIRK || seed_len > 31) {
 		hu_set_error("hu_seed_index_create: bad argument (seed length must be in %d..31)", HU_SX_DIRK); return HU_ERR_ARG;
 	}
@@ -129,17 +129,14 @@ extern "C" int hu_seed_index_create(int32_t n_nodes, int32_t cs_len, const int32
 		std::atomic<int> next{0};
 		auto work = [&] { for(;;) { const int b = next.fetch_add(1); if(b >= 256) break;
 			std::sort(ents.begin() + cnt[b], ents.begin() + cnt[b + 1], [](const Ent& x, const Ent& y) { return x.key != y.key ? x.key < y.key : x.pos < y.pos; }); } };
-		std::vector<std::thread> th;
-		for(unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-		work();
-		for(auto& t : th) t.join();
+		hu_run_threads(nt, work);
 	}
 	ix->sa.resize(ents.size());
 	for(size_t i = 0; i < ents.size(); ++i) ix->sa[i] = ents[i].pos;
 	finish_index(ix);
 	*out = ix;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_seed_index_create"); }
 /* ------------------------------------------------------------------------------------------
  * Reading the reference's own index file, <DB>.csfm (CSFMIndex::save / load, src/CSFMIndex.cpp:176-230):
  *     string alphabet name (size_t length + bytes) | char gapCh | uint16 csLen | int32 concatLen | int32 C[256] |
@@ -236,7 +233,7 @@ bool read_rrr(Reader& R, PlainBits& out) {
 }
 }
 
-extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) {
+extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_t* p2cs, int32_t seed_len, hu_seed_index** out) try {
 	if(!path || !p2cs || !out || seed_len < HU_SX_DIRK || seed_len > 31) { hu_set_error("hu_seed_index_load_csfm: bad argument (seed length must be in %d..31)", HU_SX_DIRK); return HU_ERR_ARG; }
 	FILE* f = fopen(path, "rb");
 	if(!f) { hu_set_error("cannot open %s", path); return HU_ERR_IO; }
@@ -267,10 +264,7 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 	auto par = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& body) {
 		std::atomic<size_t> next{0};
 		auto work = [&] { for(;;) { const size_t a = next.fetch_add(grain); if(a >= n) break; body(a, std::min(n, a + grain)); } };
-		std::vector<std::thread> th;
-		for(unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-		work();
-		for(auto& t : th) t.join();
+		hu_run_threads(nt, work);
 	};
 	/* the BWT symbols (WaveletTreeNoptrs::access, WaveletTreeNoptrs.cpp:301-323) */
 	std::vector<uint8_t> L(N);
@@ -386,17 +380,17 @@ extern "C" int hu_seed_index_load_csfm(const char* path, int32_t K, const int32_
 	finish_index(ix);
 	*out = ix;
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_seed_index_load_csfm"); }
 
-extern "C" void hu_seed_index_destroy(hu_seed_index* ix) { delete ix; }
+extern "C" void hu_seed_index_destroy(hu_seed_index* ix) try { delete ix; } catch(...) { (void) hu_catch_all("hu_seed_index_destroy"); }
 /* number of distinct seed_len-mers indexed */
-extern "C" int64_t hu_seed_index_size(const hu_seed_index* ix) { return ix ? ix->distinct : 0; }
+extern "C" int64_t hu_seed_index_size(const hu_seed_index* ix) try { return ix ? ix->distinct : 0; } catch(...) { return hu_catch_all("hu_seed_index_size"); }
 /* resident bytes of the index; positions = number of indexed k-mer starts */
-extern "C" int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions) {
+extern "C" int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions) try {
 	if(!ix) return 0;
 	if(positions) *positions = (int64_t) ix->sa.size();
 	return (int64_t)(ix->sa.size() * 4 + ix->dir.size() * 4 + ix->cols.size() * 2 + ix->text.size() * 8 + ix->seqEnd.size() * 4 + ix->cs2p.size() * 4);
-}
+} catch(...) { return hu_catch_all("hu_seed_index_bytes"); }
 
 /* locateFirst + buildAlignPath for the k-mer read[from0 .. from0+seedLen): returns 1 and fills out6 when
  * the k-mer occurs and yields a valid path, else 0 */
@@ -434,7 +428,7 @@ static int lookup_one(const hu_seed_index* ix, const char* read, int from0, int3
 
 /* every occurrence of one seed, in index order: (sequence, residue offset in it, first CS column 0-based); for tests of
  * the hit semantics.  Returns the number of occurrences (cap entries written). */
-extern "C" int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap) {
+extern "C" int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap) try {
 	if(!ix || !kmer) return 0;
 	const int k = ix->seedLen;
 	uint64_t key = 0;
@@ -455,11 +449,11 @@ extern "C" int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char
 		++n;
 	}
 	return n;
-}
+} catch(...) { return hu_catch_all("hu_seed_index_occurrences"); }
 
 /* CSFMIndex::locateFirst for one seed of the index's length (src/CSFMIndex.cpp:92-119): 1-based CS columns of its first and last
  * base at the first hit (0, 0 without a hit), and the number of hits (CSFMIndex::count, :43-64).  Returns 1 on a hit. */
-extern "C" int hu_seed_index_locate_first(const hu_seed_index* ix, const char* kmer, int32_t* cs_start, int32_t* cs_end, int64_t* count) {
+extern "C" int hu_seed_index_locate_first(const hu_seed_index* ix, const char* kmer, int32_t* cs_start, int32_t* cs_end, int64_t* count) try {
 	if(cs_start) *cs_start = 0;
 	if(cs_end) *cs_end = 0;
 	if(count) *count = 0;
@@ -481,11 +475,11 @@ extern "C" int hu_seed_index_locate_first(const hu_seed_index* ix, const char* k
 	if(cs_start) *cs_start = cols[0] + 1;
 	if(cs_end) *cs_end = cols[k - 1] + 1;
 	return 1;
-}
+} catch(...) { return hu_catch_all("hu_seed_index_locate_first"); }
 
 /* the two seed scans of alignSeq (src/HmmUFOtu_main.cpp:50-84) for n reads; vpaths [n][2][6] */
 extern "C" int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
-		int align_mode, int32_t* vpaths) {
+		int align_mode, int32_t* vpaths) try {
 	if(!ix || n < 0 || (n && (!bases || !offs || !vpaths))) { hu_set_error("hu_seed_index_lookup: bad argument"); return HU_ERR_ARG; }
 	const int seedLen = ix->seedLen;
 	auto one = [&](int r) {
@@ -505,8 +499,6 @@ extern "C" int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* 
 	if(nt > 16) nt = 16;
 	if(n < 1024 || nt <= 1) { for(int r = 0; r < n; ++r) one(r); return HU_OK; }
 	std::atomic<int> next{0};
-	std::vector<std::thread> th;
-	for(unsigned t = 0; t < nt; ++t) th.emplace_back([&] { for(;;) { int a = next.fetch_add(256); if(a >= n) break; int e = std::min(n, a + 256); for(int r = a; r < e; ++r) one(r); } });
-	for(auto& t : th) t.join();
+	hu_run_threads(nt, [&] { for(;;) { int a = next.fetch_add(256); if(a >= n) break; int e = std::min(n, a + 256); for(int r = a; r < e; ++r) one(r); } });
 	return HU_OK;
-}
+} catch(...) { return hu_catch_all("hu_seed_index_lookup"); }

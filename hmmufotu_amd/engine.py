@@ -256,6 +256,14 @@ class SeedIndex:
                                                  _p(vp, C.c_int32)))
         return vp
 
+    def lookup_packed(self, cat, offs, seed_region=50, align_mode=0):
+        """the same on reads that are already one byte buffer + offsets [n + 1] (what a FASTA parser holds)"""
+        offs = np.ascontiguousarray(offs, np.int64); n = len(offs) - 1
+        vp = np.zeros((n, 2, 6), np.int32)
+        _chk(load_library().hu_seed_index_lookup(self.h, C.c_int(n), cat.ctypes.data_as(C.c_char_p) if isinstance(cat, np.ndarray) else cat,
+                                                 _p(offs, C.c_int64), C.c_int(seed_region), C.c_int(align_mode), _p(vp, C.c_int32)))
+        return vp
+
     def __del__(self):
         try:
             load_library().hu_seed_index_destroy(self.h)
@@ -367,6 +375,24 @@ class Batch:
         _chk(load_library().hu_batch_set_reads(self.h, C.c_int(n), cat, _p(offs, C.c_int64), _p(vp, C.c_int32) if vp is not None else None,
                                                mcat if mates is not None else None, _p(moffs, C.c_int64) if mates is not None else None,
                                                _p(mvp, C.c_int32) if mates is not None and mvp is not None else None))
+
+    def set_reads_packed(self, cat, offs, vpaths):
+        """SE reads as one uint8 buffer + offsets [n + 1] (relative to the buffer's start): no per-read Python objects"""
+        offs = np.ascontiguousarray(offs, np.int64); n = len(offs) - 1
+        self.n = n
+        vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 2, 6)
+        _chk(load_library().hu_batch_set_reads(self.h, C.c_int(n), cat.ctypes.data_as(C.c_char_p), _p(offs, C.c_int64), _p(vp, C.c_int32), None, None, None))
+
+    def format_tsv_bytes(self, id_array, desc_array=None, anno_array=None) -> int:
+        """formats the batch's assignment lines (hu_batch_format_tsv_ptr) from prepared (c_char_p * n) arrays and returns their length;
+        the text stays in the batch's buffer"""
+        lib = load_library()
+        lib.hu_batch_format_tsv_ptr.restype = C.c_int64
+        txt = C.c_char_p()
+        need = lib.hu_batch_format_tsv_ptr(self.h, id_array, desc_array, anno_array, None, C.c_int(0), C.c_int(0), C.byref(txt))
+        if need < 0:
+            _chk(int(need))
+        return int(need)
 
     def set_aligned(self, codes, start, end):
         codes = np.ascontiguousarray(codes, np.int8)

@@ -159,3 +159,36 @@ def simulate_reads_gpu(db, up, down, n_reads, read_len, seed, amplicon_start, am
         s = synth.BASES[base[i, cols]].tobytes().decode()
         out.append(synth.SimRead(s, cols + start[i], int(nodes[i]), float(rc[i]), int(start[i]), int(start[i] + S - 1)))
     return out
+
+
+def simulate_pool_gpu(db, up, down, n_reads, read_len, seed, amplicon_start, amplicon_cols, jitter=30, device="cuda:0", chunk=32768):
+    """n_reads DISTINCT single-end reads by the recipe of simulate_reads_gpu, returned packed — one uint8 buffer of bases and
+    offsets [n + 1] — without a Python object per read (bench.py's end-to-end pool of a million reads)."""
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    w0, wl = db.win
+    S = amplicon_cols + 1
+    gw = torch.tensor(db.gap_wfrac, device=device)
+    lut = torch.tensor(np.frombuffer(b"ACGT", np.uint8).copy(), device=device)
+    parts, lens = [], []
+    for a in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - a)
+        nodes = rng.integers(1, db.n_nodes, size=m); rc = rng.random(m)
+        start = np.clip(amplicon_start + rng.integers(-jitter, jitter + 1, size=m), w0, w0 + wl - amplicon_cols - 1)
+        v = db.blen[nodes]
+        Pu = torch.tensor(synth.model_P(db.model, v * rc), device=device)[:, None]
+        Pv = torch.tensor(synth.model_P(db.model, v * (1 - rc)), device=device)[:, None]
+        nd = torch.tensor(nodes, device=device)
+        col = torch.tensor(start - w0, device=device)[:, None] + torch.arange(S, device=device)[None, :]
+        ll = _conv(Pu, up[nd[:, None], col])[:, 0] + _conv(Pv, down[nd[:, None], col])[:, 0]
+        ll = ll - ll.max(-1, keepdim=True).values
+        p = torch.exp(ll); p = p / p.sum(-1, keepdim=True)
+        x = torch.rand((m, S), device=device, generator=gen, dtype=torch.float64)
+        base = (x[:, :, None] > torch.cumsum(p, -1)).sum(-1).clamp_(max=3)
+        keep = ~(torch.rand((m, S), device=device, generator=gen, dtype=torch.float64) <= gw[col + w0])
+        keep &= torch.cumsum(keep.to(torch.int32), 1) <= read_len
+        parts.append(lut[base[keep]].cpu().numpy()); lens.append(keep.sum(1).cpu().numpy())
+        del ll, p, x, base, keep
+    lens = np.concatenate(lens).astype(np.int64)
+    offs = np.zeros(n_reads + 1, np.int64); offs[1:] = np.cumsum(lens)
+    return np.concatenate(parts), offs

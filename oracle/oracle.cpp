@@ -102,6 +102,9 @@ void* orc_tree_new(int nNodes, int csLen, const int* parent, const double* blen,
 	return t;
 }
 void orc_tree_free(void* t) { delete (Tree*) t; }
+/* up / down hold the message rows of SOME nodes only: rowOf[node] = row, or -1 (a tree of 4 x 10^5 nodes holds 2 x 10^11 bytes of
+ * messages; the per-read task reads those of its <= 50 seed nodes).  NULL: row = node */
+void orc_tree_set_rows(void* t, const int* rowOf) { ((Tree*) t)->rowOf = rowOf; }
 
 int orc_get_seed(void* tr, const int8_t* seq, int start, int end, double maxDiff, double maxHeight, int tieMode, int maxNSeed,
 		long* ids, long* d, long* N, double* dist) {
@@ -195,16 +198,25 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 		const OrcOpts* o, int nThreads,
 		int* ai, double* cost, char* alignOut, int* bi, double* bd, int* nCand, double* stageSec,
 		int* candNode /* optional [nReads][64]: candidates in filterPlacements order */, double* candEst /* their estimated logliks */,
-		double* candRatio0 /* their estimated ratios */, int* bestPos /* position of the final pick in that order */) {
+		double* candRatio0 /* their estimated ratios */, int* bestPos /* position of the final pick in that order */,
+		double* candPlaced /* optional [nReads][64][3]: placed ratio, wnr, height of each candidate, same order */,
+		int* candIters /* optional [nReads][64][2]: outer iterations, EM passes */,
+		int mode /* 0: the whole task; 1: stop after getSeed (seedCnt / seedIds are outputs); 2: seeds GIVEN (seedCnt / seedIds are inputs, in
+		          * the order estimateSeq is to see them): what runs when the tree holds message rows of the seed nodes only (orc_tree_set_rows) */,
+		int* seedCnt /* [nReads] */, int* seedIds /* [nReads][64] */,
+		int* libIds /* mode 1, optional [nReads][64]: the same scan ordered by the reference's literal std::sort on dist alone (TIE_LIBSTDCXX) */,
+		int* tieInfo /* mode 1, optional [nReads][4]: nodes of the whole tree at the stable list's cut-off distance, of them inside the list,
+		              * 1 when both lists end at the same distance, 1 when a NaN dist made std::sort undefined (lists equal by fallback) */,
+		double* extraSec /* mode 1, optional: thread-seconds spent on the libstdc++ order (not part of the task; subtract from the wall) */) {
 	HmmHandle* H = (HmmHandle*) hmm; Tree* t = (Tree*) tr;
 	const int L = H->h.L;
 	AssignOpts opts = to_opts(o);
 	if(nThreads <= 0) nThreads = omp_get_max_threads();
 	if((int) H->work.size() < nThreads) H->work.resize(nThreads);
-	double acc[4] = {0, 0, 0, 0};
+	double acc[4] = {0, 0, 0, 0}, accExtra = 0;
 	#pragma omp parallel num_threads(nThreads)
 	{
-		double loc[4] = {0, 0, 0, 0};
+		double loc[4] = {0, 0, 0, 0}, locExtra = 0;
 		VitWork& w = H->work[omp_get_thread_num()];
 		std::vector<int8_t> dseq(L);
 		#pragma omp for schedule(dynamic, 4)
@@ -239,9 +251,41 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			int m = orc_digitize(aln.align.data(), L, dseq.data());
 			if(m != L) { a8[7] = 0; continue; }
 			const int start = aln.csStart - 1, end = aln.csEnd - 1;
-			std::vector<PTLoc> seeds = getSeed(*t, dseq.data(), start, end, opts.maxDiff, opts.maxHeight, opts.tieMode, (size_t) opts.maxNSeed);
+			std::vector<PTLoc> seeds, scan;
+			bool scanNaN = false;
+			if(mode == 2) { /* the given nodes, in the given order; their distance as getSeed measures it */
+				for(int k = 0; k < seedCnt[r] && k < 64; ++k) {
+					PTLoc l; l.start = start; l.end = end; l.id = seedIds[64 * (size_t) r + k];
+					pdist_counts(t->S((int) l.id), dseq.data(), start, end, l.d, l.N);
+					l.dist = static_cast<double>(l.d) / l.N;
+					seeds.push_back(l);
+				}
+			}
+			else if(mode == 1 && libIds) { /* getSeed in its two halves: the scan is shared with the libstdc++ order below */
+				scan = scanSeeds(*t, dseq.data(), start, end, opts.maxHeight, scanNaN);
+				seeds = orderSeeds(scan, scanNaN, opts.maxDiff, opts.tieMode, (size_t) opts.maxNSeed);
+			}
+			else seeds = getSeed(*t, dseq.data(), start, end, opts.maxDiff, opts.maxHeight, opts.tieMode, (size_t) opts.maxNSeed);
 			auto t2 = std::chrono::steady_clock::now();
 			loc[1] += std::chrono::duration<double>(t2 - t1).count();
+			if(mode == 1) {
+				seedCnt[r] = (int) std::min<size_t>(seeds.size(), 64);
+				for(int k = 0; k < seedCnt[r]; ++k) seedIds[64 * (size_t) r + k] = (int) seeds[k].id;
+				if(libIds) { /* the reference's own order of the same scan: src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647 */
+					std::vector<PTLoc> lib = orderSeeds(scan, scanNaN, opts.maxDiff, TIE_LIBSTDCXX, (size_t) opts.maxNSeed);
+					for(size_t k = 0; k < lib.size() && k < 64; ++k) libIds[64 * (size_t) r + k] = (int) lib[k].id;
+					if(tieInfo && !seeds.empty()) {
+						const double cut = seeds.back().dist;
+						int tied = 0, tiedIn = 0;
+						for(const PTLoc& l : scan) if(l.dist == cut) tied++;
+						for(const PTLoc& l : seeds) if(l.dist == cut) tiedIn++;
+						int* ti = tieInfo + 4 * (size_t) r;
+						ti[0] = tied; ti[1] = tiedIn; ti[2] = !lib.empty() && lib.back().dist == cut; ti[3] = scanNaN;
+					}
+					locExtra += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+				}
+				continue;
+			}
 			std::vector<Placement> places;
 			for(const PTLoc& l : seeds) places.push_back(estimateSeq(*t, dseq.data(), l, opts.weighted != 0, opts.tieTol));
 			filterPlacements(places, opts.maxError);
@@ -253,6 +297,10 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			auto t3 = std::chrono::steady_clock::now();
 			loc[2] += std::chrono::duration<double>(t3 - t2).count();
 			for(Placement& p : places) placeSeq(*t, dseq.data(), p, opts.maxHeight, opts.fixRootLoglik != 0);
+			for(size_t k = 0; k < places.size() && k < 64; ++k) { /* still in filterPlacements order */
+				if(candPlaced) { double* c = candPlaced + (64 * (size_t) r + k) * 3; c[0] = places[k].ratio; c[1] = places[k].wnr; c[2] = places[k].height; }
+				if(candIters) { int* c = candIters + (64 * (size_t) r + k) * 2; c[0] = places[k].iters; c[1] = places[k].emIters; }
+			}
 			if(opts.onlyML)
 				std::sort(places.rbegin(), places.rend(), [](const Placement& l, const Placement& r) { return l.loglik < r.loglik; });
 			else {
@@ -269,10 +317,12 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 			}
 		}
 		#pragma omp critical
-		for(int k = 0; k < 4; ++k) acc[k] += loc[k];
+		{ for(int k = 0; k < 4; ++k) acc[k] += loc[k]; accExtra += locExtra; }
 	}
 	if(stageSec) for(int k = 0; k < 4; ++k) stageSec[k] = acc[k];
+	if(extraSec) *extraSec = accExtra;
 }
+
 
 int orc_max_threads(void) { return omp_get_max_threads(); }
 

@@ -18,6 +18,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <limits>
@@ -100,8 +102,11 @@ struct Tree {
 	long winStart = 0;                // messages are stored for columns [winStart, winStart+winLen)
 	long winLen = 0;
 
-	const double* U(int node, int j) const { return up + ((size_t) node * winLen + (j - winStart)) * 4; }
-	const double* D(int node, int j) const { return down + ((size_t) node * winLen + (j - winStart)) * 4; }
+	const int* rowOf = nullptr;       /* optional: up / down hold the rows of some nodes only (row of a node, -1 = absent: reading it is a test-harness bug) */
+
+	size_t row(int node) const { if(!rowOf) return (size_t) node; if(rowOf[node] < 0) { std::fprintf(stderr, "oracle: messages of node %d are not resident\n", node); std::abort(); } return (size_t) rowOf[node]; }
+	const double* U(int node, int j) const { return up + (row(node) * winLen + (j - winStart)) * 4; }
+	const double* D(int node, int j) const { return down + (row(node) * winLen + (j - winStart)) * 4; }
 	const int8_t* S(int node) const { return seq + (size_t) node * csLen; }
 };
 
@@ -127,10 +132,10 @@ enum TieMode { TIE_STABLE = 0, TIE_LIBSTDCXX = 1 };
  * TIE_LIBSTDCXX: literal std::sort on dist only (the reference's semantics; falls back to
  * stable when a NaN dist would make std::sort undefined).  TIE_STABLE: (dist, id)
  * lexicographic, NaN last — the deterministic order the GPU top-k implements. */
-inline std::vector<PTLoc> getSeed(const Tree& t, const int8_t* seq, int start, int end,
-		double maxDiff, double maxHeight, int tieMode, size_t maxNSeed) {
+/* the loop of getSeed: every non-root node within maxHeight with its distance, in node order */
+inline std::vector<PTLoc> scanSeeds(const Tree& t, const int8_t* seq, int start, int end, double maxHeight, bool& hasNaN) {
 	std::vector<PTLoc> locs;
-	bool hasNaN = false;
+	hasNaN = false;
 	for(int i = 0; i < t.nNodes; ++i) {
 		if(i != t.root && t.height[i] <= maxHeight) {
 			PTLoc l; l.start = start; l.end = end; l.id = i;
@@ -140,6 +145,10 @@ inline std::vector<PTLoc> getSeed(const Tree& t, const int8_t* seq, int start, i
 			locs.push_back(l);
 		}
 	}
+	return locs;
+}
+/* the sort, the maxDiff cut and the caller's truncation, on a copy of the scan */
+inline std::vector<PTLoc> orderSeeds(std::vector<PTLoc> locs, bool hasNaN, double maxDiff, int tieMode, size_t maxNSeed) {
 	if(locs.empty()) return locs;
 	if(tieMode == TIE_LIBSTDCXX && !hasNaN)
 		std::sort(locs.begin(), locs.end());
@@ -158,12 +167,19 @@ inline std::vector<PTLoc> getSeed(const Tree& t, const int8_t* seq, int start, i
 	if(locs.size() > maxNSeed) locs.erase(locs.end() - (locs.size() - maxNSeed), locs.end());
 	return locs;
 }
+inline std::vector<PTLoc> getSeed(const Tree& t, const int8_t* seq, int start, int end,
+		double maxDiff, double maxHeight, int tieMode, size_t maxNSeed) {
+	bool hasNaN;
+	std::vector<PTLoc> locs = scanSeeds(t, seq, start, end, maxHeight, hasNaN);
+	return orderSeeds(std::move(locs), hasNaN, maxDiff, tieMode, maxNSeed);
+}
 
 struct Placement {
 	int start = 0, end = 0;
 	int cNode = -1, pNode = -1, aNode = -1;
 	double wuv = NAN, ratio = NAN, wnr = NAN, loglik = NAN, height = NAN, qPlace = NAN, qTaxon = NAN;
-	double estLoglik = NAN; int iters = 0;
+	double estLoglik = NAN; int iters = 0; /* outer iterations of the joint optimisation */
+	int emIters = 0;  /* passes through the 2-node EM loop, summed over both branches and all outer iterations (diagnostic: the engine reports the same count) */
 	double annoDist() const { return aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr; }
 };
 
@@ -257,7 +273,7 @@ inline void catP(const Tree& t, double len, double* P) {
 }
 
 /* 2-node Felsenstein EM (src/PhyloTreeUnrooted.cpp:749-798); U/V are n messages of 4 */
-inline double optimizeBranchLength2(const Tree& t, const V4* U, const V4* V, int n, double w0, double maxL) {
+inline double optimizeBranchLength2(const Tree& t, const V4* U, const V4* V, int n, double w0, double maxL, int* steps = nullptr) {
 	double q0 = std::exp(-w0), p0 = 1 - q0, p = p0, q = q0;
 	const double* pi = t.model.pi;
 	std::vector<double> eA(n), eB(n);
@@ -272,6 +288,7 @@ inline double optimizeBranchLength2(const Tree& t, const V4* U, const V4* V, int
 		eA[j] = std::exp(logA - scale); eB[j] = std::exp(logB - scale);
 	}
 	for(int iter = 0; iter < MAX_ITER && p >= 0 && p <= 1; ++iter) {
+		if(steps) ++*steps;
 		p = 0; int N = 0;
 		for(int j = 0; j < n; ++j) {
 			if(!ok[j]) continue;
@@ -316,15 +333,15 @@ inline void placeSeq(const Tree& t, const int8_t* seq, Placement& place, double 
 	const double w0j = wur0 + wvr0;
 	double wur = wur0, wvr = wvr0, wnr = wnr0;
 	double PU[16 * 16], PV[16 * 16], PN[16 * 16];
-	int iter = 0;
+	int iter = 0, em = 0;
 	for(; iter < MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
 		catP(t, lenUR, PU); catP(t, lenVR, PV);
 		for(int j = 0; j < n; ++j) RN[j] = nodeLoglik2(t, PU, Um[j].v, PV, Vm[j].v);
-		wnr = optimizeBranchLength2(t, RN.data(), Nm.data(), n, lenNR, 1);
+		wnr = optimizeBranchLength2(t, RN.data(), Nm.data(), n, lenNR, 1, &em);
 		lenNR = wnr;
 		catP(t, lenNR, PN);
 		for(int j = 0; j < n; ++j) RU[j] = nodeLoglik2(t, PV, Vm[j].v, PN, Nm[j].v);
-		wur = optimizeBranchLength2(t, RU.data(), Um.data(), n, lenUR, w0j);
+		wur = optimizeBranchLength2(t, RU.data(), Um.data(), n, lenUR, w0j, &em);
 		lenUR = wur;
 		wvr = w0j - wur;
 		lenVR = wvr;
@@ -347,7 +364,7 @@ inline void placeSeq(const Tree& t, const int8_t* seq, Placement& place, double 
 	place.ratio = wurF / w0;
 	place.height = t.height[u] + wurF;
 	if(place.ratio <= 0.5 || t.height[v] > maxHeight) place.aNode = u; else place.aNode = v;
-	place.iters = iter;
+	place.iters = iter; place.emIters = em;
 }
 
 inline double add_scaled(double a, double b) { double s = std::max(a, b); return std::log(std::exp(a - s) + std::exp(b - s)) + s; }

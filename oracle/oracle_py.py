@@ -137,6 +137,11 @@ class Tree:
                                                _p(self.height, C.c_double), _p(self.anno, C.c_int) if self.anno is not None else None,
                                                model.h, C.c_int(len(self.dgr)), _p(self.dgr, C.c_double), C.c_long(win_start), C.c_long(win_len)))
 
+    def set_rows(self, row_of):
+        """up / down hold the message rows of some nodes only: row_of [n_nodes] int32, -1 = absent (None: row = node)"""
+        self.row_of = None if row_of is None else np.ascontiguousarray(row_of, np.int32)
+        lib().orc_tree_set_rows(self.h, _p(self.row_of, C.c_int) if self.row_of is not None else None)
+
     def get_seed(self, seq, start, end, max_diff=float("inf"), max_height=float("inf"), tie=0, max_n=50):
         seq = np.ascontiguousarray(seq, np.int8)
         ids = np.zeros(max(max_n, 1), np.int64); d = np.zeros_like(ids); N = np.zeros_like(ids); dist = np.zeros(len(ids))
@@ -210,10 +215,15 @@ def tree_evaluate(parent, blen, leaf_seq, model: Model, dg_r=None):
     return up, down, seq, h
 
 
-def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, want_align=False, want_cands=False):
+def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, want_align=False, want_cands=False,
+                   mode=0, seeds=None, want_lib=False):
     """Whole per-read task on the CPU (OpenMP over reads).  reads/mates: list of str.
     want_cands: also the candidates of every read in filterPlacements order (node, estimated loglik, estimated ratio;
-    rows padded with -1 / NaN to 64) and the position of the final pick in that order."""
+    rows padded with -1 / NaN to 64), their placed (ratio, wnr, height) and (outer, EM) iteration counts, and the position of the
+    final pick in that order.
+    mode 0: the whole task.  mode 1: alignment + getSeed only; returns seed_cnt / seed_ids [n][64] (and with want_lib the list under the
+    reference's literal std::sort, lib_ids, + tie_info, from the same scan).  mode 2: the rest of the task on GIVEN seed lists
+    (seeds = (cnt [n], ids [n][64])) — the tree then only needs the message rows of those nodes (Tree.set_rows)."""
     opts = opts or default_opts()
     n = len(reads)
     cat = "".join(reads).encode(); offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
@@ -228,15 +238,79 @@ def pipeline_batch(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None
     ce = np.full((n, 64), np.nan) if want_cands else None
     cr = np.full((n, 64), np.nan) if want_cands else None
     bp = np.full(n, -1, np.int32) if want_cands else None
+    cp = np.full((n, 64, 3), np.nan) if want_cands else None
+    ci = np.zeros((n, 64, 2), np.int32) if want_cands else None
+    if mode == 2:
+        scnt = np.ascontiguousarray(seeds[0], np.int32); sids = np.ascontiguousarray(seeds[1], np.int32).reshape(n, 64)
+    else:
+        scnt = np.zeros(n, np.int32); sids = np.full((n, 64), -1, np.int32)
+    lids = np.full((n, 64), -1, np.int32) if (mode == 1 and want_lib) else None
+    tinfo = np.zeros((n, 4), np.int32) if lids is not None else None
+    extra = C.c_double(0)
     lib().orc_pipeline_batch(hmm.h, tree.h, C.c_int(n), cat, _p(offs, C.c_long),
                              mcat if mates is not None else None, _p(moffs, C.c_long) if mates is not None else None,
                              _p(vp, C.c_int), _p(mvp, C.c_int) if mates is not None else None, C.byref(opts), C.c_int(threads),
                              _p(ai, C.c_int), _p(cost, C.c_double), _p(aln, C.c_char) if aln is not None else None,
                              _p(bi, C.c_int), _p(bd, C.c_double), _p(nc, C.c_int), _p(st, C.c_double),
                              _p(cn, C.c_int) if want_cands else None, _p(ce, C.c_double) if want_cands else None,
-                             _p(cr, C.c_double) if want_cands else None, _p(bp, C.c_int) if want_cands else None)
+                             _p(cr, C.c_double) if want_cands else None, _p(bp, C.c_int) if want_cands else None,
+                             _p(cp, C.c_double) if want_cands else None, _p(ci, C.c_int) if want_cands else None,
+                             C.c_int(mode), _p(scnt, C.c_int), _p(sids, C.c_int), _p(lids, C.c_int) if lids is not None else None,
+                             _p(tinfo, C.c_int) if tinfo is not None else None, C.byref(extra))
     return dict(aln_ints=ai, cost=cost, align=aln, best_nodes=bi, best_vals=bd, n_cand=nc, stage_sec=st,
-                cand_node=cn, cand_est=ce, cand_ratio0=cr, best_pos=bp)
+                cand_node=cn, cand_est=ce, cand_ratio0=cr, best_pos=bp, cand_placed=cp, cand_iters=ci,
+                seed_cnt=scnt, seed_ids=sids, lib_ids=lids, tie_info=tinfo, extra_thread_sec=extra.value)
+
+
+def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, opts=None, threads=0, phase1=None, tree2=None):
+    """SURVEY.md H1(ii): the per-read task under the reference's seed order (first max_nseed of a literal std::sort on dist alone,
+    src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647) against the product's (dist, node id) order.  Both lists come from ONE scan
+    per read (pipeline_batch mode 1, want_lib); the reads whose ordered lists differ are run through the rest of the task on each
+    list (mode 2; reads with equal lists give estimateSeq the same inputs in the same order and cannot differ).
+    phase1: a mode-1 result to reuse; tree2: the tree for the mode-2 runs (e.g. one holding only the seed nodes' message rows).
+    Returns (per_read dict of arrays, summary dict)."""
+    opts = opts or default_opts()
+    n = len(reads)
+    p1 = phase1 if phase1 is not None else pipeline_batch(hmm, tree, reads, vpaths, mates, mvpaths, opts, threads, mode=1, want_lib=True)
+    ok = p1["aln_ints"][:, 7] == 1
+    cnt, sid, lid, ti = p1["seed_cnt"], p1["seed_ids"], p1["lib_ids"], p1["tie_info"]
+    order_diff = ok & (sid != lid).any(axis=1)
+    only_lib = np.array([len(set(lid[i, :cnt[i]]) - set(sid[i, :cnt[i]])) if order_diff[i] else 0 for i in range(n)])
+    set_diff = only_lib > 0
+    idx = np.nonzero(order_diff)[0]
+    pick_mask = np.zeros(n, np.int32); filt_diff = np.zeros(n, bool); via_tie = np.zeros(n, bool)
+    picks = np.full((n, 2, 3), -1, np.int32)
+    if len(idx):
+        t2 = tree2 if tree2 is not None else tree
+        sub = lambda x: None if x is None else [x[i] for i in idx]
+        vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 2, 6)[idx]
+        mvp = None if mvpaths is None else np.ascontiguousarray(mvpaths, np.int32).reshape(n, 2, 6)[idx]
+        rs = pipeline_batch(hmm, t2, sub(reads), vp, sub(mates), mvp, opts, threads, want_cands=True, mode=2, seeds=(cnt[idx], sid[idx]))
+        rl = pipeline_batch(hmm, t2, sub(reads), vp, sub(mates), mvp, opts, threads, want_cands=True, mode=2, seeds=(cnt[idx], lid[idx]))
+        for k, i in enumerate(idx):
+            cs = set(rs["cand_node"][k, :rs["n_cand"][k]]); cl = set(rl["cand_node"][k, :rl["n_cand"][k]])
+            filt_diff[i] = cs != cl
+            bs, bl = rs["best_nodes"][k, :3], rl["best_nodes"][k, :3]
+            picks[i, 0], picks[i, 1] = bs, bl
+            pick_mask[i] = int(bs[0] != bl[0]) | (int(bs[1] != bl[1]) << 1) | (int(bs[2] != bl[2]) << 2)
+            if filt_diff[i] or pick_mask[i]:
+                only_l = set(lid[i, :cnt[i]]) - set(sid[i, :cnt[i]]); only_s = set(sid[i, :cnt[i]]) - set(lid[i, :cnt[i]])
+                via_tie[i] = bool((cl & only_l) or (cs & only_s))
+    pick = pick_mask != 0
+    # a seed that only one list holds can only come from the tie at the cut-off: both lists are valid ascending sorts of the same
+    # distances, so they hold every node below the cut-off distance and end AT it (tie_info[:, 2])
+    summ = dict(reads=int(ok.sum()), max_nseed=int(opts.maxNSeed),
+                seed_order_differs=int(order_diff.sum()), seed_set_differs=int(set_diff.sum()),
+                seed_set_diffs_all_exact_cutoff_ties=bool((ti[set_diff, 2] == 1).all() and (ti[set_diff, 0] > ti[set_diff, 1]).all()),
+                mean_nodes_tied_at_cutoff=float(ti[ok, 0].mean()) if ok.any() else 0.0,
+                reads_whose_cutoff_tie_reaches_beyond_the_list=int(((ti[:, 0] > ti[:, 1]) & ok).sum()),
+                reads_with_nan_dist=int((ti[:, 3] != 0).sum()),
+                filtered_candidate_set_differs=int(filt_diff.sum()),
+                final_c_node_differs=int(((pick_mask & 1) != 0).sum()), final_p_node_differs=int(((pick_mask & 2) != 0).sum()),
+                final_a_node_differs=int(((pick_mask & 4) != 0).sum()), final_pick_differs=int(pick.sum()),
+                final_pick_diffs_traced_to_a_cutoff_tie=int(via_tie[pick].sum()))
+    return dict(order_differs=order_diff, seeds_only_in_libstdcxx=only_lib, filtered_set_differs=filt_diff, pick_mask=pick_mask,
+                picks=picks, via_cutoff_seed=via_tie, phase1=p1), summ
 
 
 def max_threads():

@@ -6,15 +6,23 @@
 # Outputs under gpurun_out/<tag>/; profiles/make_pmc_summary.py turns them into the tracked summaries.
 set -o pipefail
 tag=$1; shift
+# one rank only: with --gpus N > 1 bench.py would start its launcher from a process the profiler's preloaded library has already
+# initialised on the GPU — a launcher hop under rocprofv3, which this pool forbids (bench.py refuses it too)
+prev=""
+for a in "$@"; do
+	if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "collect_pmc.sh profiles ONE rank: --gpus $a refused" >&2; exit 2; fi
+	case "$a" in --gpus=1) ;; --gpus=*) echo "collect_pmc.sh profiles ONE rank: $a refused" >&2; exit 2;; esac
+	prev="$a"
+done
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-short="--steps 2 --warmup 0 --cpu-sample 0 --inflight 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --cpu-sample 0 "$@" > $out/bench_profiled.json 2> $out/stats.err || exit 1
+short="--steps 2 --warmup 0 --cpu-sample 0 --inflight 1 --e2e-reads 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --cpu-sample 0 --e2e-reads 0 "$@" > $out/bench_profiled.json 2> $out/stats.err || exit 1
 echo "stats pass done"
 # the same with ONE batch in flight: every launch alone on the GPU -> the average duration bench.py's `roofline.ms` (isolated) must agree with
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python3 $root/bench.py --cpu-sample 0 --inflight 1 --steps 8 --warmup 2 "$@" > $out/bench_profiled_inflight1.json 2> $out/stats1.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python3 $root/bench.py --cpu-sample 0 --e2e-reads 0 --inflight 1 --steps 8 --warmup 2 "$@" > $out/bench_profiled_inflight1.json 2> $out/stats1.err || exit 1
 echo "stats (one batch in flight) pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $root/bench.py $short "$@" > $out/fetch.json 2> $out/fetch.err || exit 1
 echo "fetch pass done"

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """gpurun_out/<tag>/ (profiles/collect_pmc.sh) -> the tracked summaries:
      profiles/<tag>_pmc_summary.json    per kernel: HBM bytes per launch, SQ / L2 counters, VALU instructions by type and the
-                                        issue cycles they cost; `workload` = the key bench.py matches before quoting it
+                                        issue cycles they cost; `workload` = the key bench.py matches before quoting it;
+                                        `kernel_source_hash` = bench.py's hash of the kernel sources of the profiled run (a bench run
+                                        on other sources tags the quoted counters pmc_stale)
      profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats rows of the engine's kernels
      profiles/<tag>_summary.md          one table
    HBM bytes: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM: gfx950 tallies the 128-B requests
@@ -65,7 +67,7 @@ for k in sorted(set(fe) | set(sq)):
     out[k] = e
 note = ("rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 0 --cpu-sample 0 --inflight 1 <workload flags>` (one batch in flight: every dispatch "
         "alone on the GPU), counters averaged over a kernel's launches; see the header of profiles/make_pmc_summary.py for the corrections")
-json.dump(dict(note=note, workload=workload, bench_config=bench.get("config"), kernels=out), open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
+json.dump(dict(note=note, workload=workload, bench_config=bench.get("config"), kernel_source_hash=(bench.get("roofline") or {}).get("kernel_source_hash"), kernels=out), open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))))
 mine = [r for r in rows if clean(r['Name']).startswith('k_')]
 with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:

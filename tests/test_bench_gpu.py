@@ -31,10 +31,20 @@ def test_two_ranks_launched_by_bench_itself():
 
 
 def test_single_rank_line_has_the_contract_fields_and_zero_unexplained_differences():
-    j = _run(["--cpu-sample", "96"] + SMALL)
+    j = _run(["--cpu-sample", "96", "--e2e-reads", "500"] + SMALL)
     assert j["n_gpus"] == 1 and j["unit"] == "reads/s" and j["dtype"] == "f64" and j["vs_baseline"] is None
     r = j["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
     assert c["unexplained_best_branch_diffs"] == 0 and c["candidate_order"]["swaps_unexplained"] == 0 and c["candidate_order"]["candidate_set_differs"] == 0
+    # numbers at the tolerance of the north star, iteration counts equal, and the tie-mode report is there
+    mr = c["max_rel"]
+    assert mr["candidates_compared"] > 96 and mr["outer_iteration_mismatches"] == 0 and mr["nan_placement_mismatches"] == 0
+    for k in ("est_loglik", "ratio", "wnr", "height"):
+        assert mr[k]["max_rel"] <= 1e-6, (k, mr[k])
+    t = c["tie_mode"]
+    assert t["reads"] == 96 and t["seed_set_diffs_all_exact_cutoff_ties"] and t["final_pick_differs"] == t["final_pick_diffs_traced_to_a_cutoff_tie"]
+    assert r["bound"] == "valu_fp64_issue" and "hbm_roof" in r and "valu_roof" in r and len(r["kernel_source_hash"]) == 16
+    e = j["end_to_end"]
+    assert e["reads"] == 500 and e["value"] > 0 and e["placed"] > 400 and e["tsv_mb"] > 0.5

@@ -130,3 +130,44 @@ def test_engine_against_oracle_on_config_1():
             print("config 1: placements on zero-length branches (NaN ratio on both sides):", int((~fin).sum()))
     print("config 1:", tot)
     B.close(); D.close()
+
+
+
+def test_tie_mode_report_on_config_1():
+    """SURVEY.md H1(ii): the reference keeps the first 50 of a std::sort on dist alone (src/HmmUFOtu_main.cpp:139,
+    src/hmmufotu.cpp:646-647); the product keeps (dist, node id).  Both orders are taken from one scan of the tree for all 1,000
+    reads of config 1 and the disagreement is counted — on the seed lists, after filterPlacements and on the final
+    cNode / pNode / aNode — and every seed that only one list holds must sit exactly at the cut-off distance (a tie).
+    The second phase runs on a tree that holds ONLY the seed nodes' message rows (the form bench.py uses at full scale)."""
+    from oracle import oracle_py as O
+    db, reads, vps = cfg1()
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
+    T = O.Tree(db.parent, db.blen, db.seq, db.up, db.down, db.height, m, None, db.anno_id)
+    rd = [r.seq for r in reads]
+    whole = O.pipeline_batch(H, T, rd, vps, threads=4, want_cands=True)
+    p1 = O.pipeline_batch(H, T, rd, vps, threads=4, mode=1, want_lib=True)
+    # phase 2 on compact rows: only the nodes some list names
+    nodes = np.unique(np.concatenate([p1["seed_ids"].ravel(), p1["lib_ids"].ravel()])); nodes = nodes[nodes >= 0]
+    row_of = np.full(db.n_nodes, -1, np.int32); row_of[nodes] = np.arange(len(nodes))
+    T2 = O.Tree(db.parent, db.blen, db.seq, db.up[nodes], db.down[nodes], db.height, m, None, db.anno_id, win_start=0, win_len=db.cs_len)
+    T2.set_rows(row_of)
+    # the two-phase form of the task is the task: same candidates, same picks, same numbers
+    two = O.pipeline_batch(H, T2, rd, vps, threads=4, want_cands=True, mode=2, seeds=(p1["seed_cnt"], p1["seed_ids"]))
+    assert (two["cand_node"] == whole["cand_node"]).all() and (two["best_nodes"] == whole["best_nodes"]).all()
+    assert np.array_equal(two["best_vals"], whole["best_vals"], equal_nan=True) and (two["cand_iters"] == whole["cand_iters"]).all()
+    per, summ = O.tie_report(H, T, rd, vps, threads=4, phase1=p1, tree2=T2)
+    print("config 1 tie-mode report:", summ)
+    assert summ["reads"] == 1000 and summ["seed_set_diffs_all_exact_cutoff_ties"] and summ["reads_with_nan_dist"] == 0
+    assert summ["final_pick_differs"] == summ["final_pick_diffs_traced_to_a_cutoff_tie"]
+    # the stable side is the task's own result; the libstdc++ side is what the oracle's literal std::sort mode returns
+    d = per["order_differs"]
+    assert (per["picks"][d, 0] == whole["best_nodes"][d, :3]).all()
+    cd = None
+    for i in np.nonzero(per["pick_mask"] != 0)[0][:10]:
+        a = H.align(rd[i], vps[i])
+        r = T.assign(O.digitize(a["align"]), a["csStart"] - 1, a["csEnd"] - 1, O.default_opts(tieMode=1))
+        assert (r["nodes"][0][:3] == per["picks"][i, 1]).all()
+    # measured on this fixture (248 candidate nodes, 50 kept: a fifth of the tree, so ties at the cut-off are the rule):
+    # 548 reads with differing seed sets, 99 with differing candidates after the filter, 19 with a different final branch
+    assert summ["seed_set_differs"] == 548 and summ["filtered_candidate_set_differs"] == 99 and summ["final_pick_differs"] == 19, summ

@@ -153,3 +153,22 @@ def test_native_ptu_writer_matches_the_python_writer_byte_for_byte(tmp_path):
         npar = {"GTR": 16, "TN93": 3, "HKY85": 2, "F81": 1, "K80": 1, "JC69": 0}[model]
         assert np.array_equal(np.array(list(got["model"].par))[:npar], np.asarray(db.model.par, float).ravel()[:npar])
         assert np.array_equal(got["up"], db.up) and np.array_equal(got["parent"], db.parent)
+
+
+def test_exception_barrier_returns_a_status_on_the_cpu():
+    """never abort inside the library.  Every extern "C" entry is a function-try-block; a C++ exception becomes a
+    status code + hu_last_error().  Here (no GPU): a length no std::string can hold makes hu_profile_parse_text throw std::length_error
+    before a byte is read — the call must come back with HU_ERR_NOMEM, and the library must go on working."""
+    import ctypes as C
+    from hmmufotu_amd import engine as E
+    lib = E.load_library()
+    lib.hu_last_error.restype = C.c_char_p
+    K = C.c_int32(0); L = C.c_int32(0)
+    rc = lib.hu_profile_parse_text(b"HMMER3/f\n", C.c_int64(1 << 62), C.byref(K), C.byref(L), None, None, None, None)
+    assert rc == -4, rc                                                   # HU_ERR_NOMEM
+    msg = lib.hu_last_error().decode()
+    assert "hu_profile_parse_text" in msg and ("size" in msg or "memory" in msg), msg
+    md = E.ModelDesc()
+    assert lib.hu_model_parse_text(b"x", C.c_int64(1 << 62), C.byref(md)) == -4
+    # still alive, and an honest parse error is still a parse error
+    assert lib.hu_profile_parse_text(b"junk", C.c_int64(4), C.byref(K), C.byref(L), None, None, None, None) == -3

@@ -831,6 +831,74 @@ def test_edge_cases_small_tree_short_reads_and_window():
     B.close(); Dw2.close(); Dfull.close(); Dwin.close()
 
 
+def test_abi_returns_status_codes_and_never_aborts():
+    """The failure of gpurun_out/t_r2e.log (round 2) and its neighbours, through the C ABI: (1) reads outside the resident column window —
+    aligned ones and hu_batch_set_aligned ones, whose empty region once sat at column 0 and sent k_estimate_prod 40 columns before the
+    first resident message of node 0 (a GPU memory fault: the process died inside hu_assign_batch) — come back with a per-read status and
+    NO seeds, and the batch goes on; (2) an over-large max_reads and an over-large n are a status; (3) C++ exceptions raised inside the
+    stages — on the calling thread and inside a worker of the host pool (fault injection knob) — are a status + message, after which
+    the same batch still works."""
+    E = _engine()
+    import ctypes as C
+    lib = E.load_library()
+    lib.hu_last_error.restype = C.c_char_p
+    db = get_db(120, 700, "GTR", dg_k=4)
+    reads, vps = sim_reads(db, 8, 120)
+    md = E.model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r)
+    opts = E.default_opts()
+    Dfull = E.Database.from_synth(db)
+    B = E.Batch(Dfull, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts)
+    full = B.alignments(want_align=False)["recs"].copy(); want = B.placements().copy(); cd, st, en = B.codes(); B.close()
+    lo = int(np.sort(np.unique(full["cs_start"] - 1))[1]); hi = 690
+    out_ = (full["cs_start"] - 1) < lo
+    assert 0 < out_.sum() < len(reads) and lo > 0
+    Dw = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, db.up[:, lo:hi].copy(), db.down[:, lo:hi].copy(), db.height, md,
+                                db.anno_id, db.anno_dist, win_start=lo, win_len=hi - lo)
+    # (1a) aligned here: status 16, no seeds, nothing placed; the others as on the fully resident database
+    B = E.Batch(Dw, 8); B.set_reads([r.seq for r in reads], vps); B.assign(opts)
+    recs = B.alignments(want_align=False)["recs"]; cnt, ids, _, _ = B.seeds(); got = B.placements()
+    assert (recs["status"][out_] == 16).all() and (cnt[out_] == 0).all() and (cnt[~out_] > 0).all() and (got["c_node"][out_] == -1).all()
+    assert np.array_equal(got["c_node"][~out_], want["c_node"][~out_])
+    # (1b) handed over aligned (hu_batch_set_aligned), regions outside the window / inverted / beyond the consensus: refused per read
+    st2, en2 = st.copy(), en.copy()
+    k = int(np.nonzero(~out_)[0][0])
+    st2[k], en2[k] = 0, lo - 1                                              # wholly left of the window
+    B.set_aligned(cd, st2, en2); B.assign(opts)
+    recs = B.alignments(want_align=False)["recs"]; cnt, _, _, _ = B.seeds(); got2 = B.placements()
+    bad = out_.copy(); bad[k] = True
+    assert (recs["status"][bad] == 0).all() and (cnt[bad] == 0).all() and (got2["c_node"][bad] == -1).all()
+    assert np.array_equal(got2["c_node"][~bad], want["c_node"][~bad])
+    st3, en3 = st2.copy(), en2.copy(); st3[k], en3[k] = 650, 10 ** 6
+    B.set_aligned(cd, st3, en3); B.assign(opts)
+    assert (B.placements()["c_node"][bad] == -1).all()
+    # (2) sizes
+    hb = C.c_void_p()
+    assert lib.hu_batch_create(Dw.h, C.c_int(2 ** 31 - 1), C.byref(hb)) == 0          # nothing is sized by max_reads before reads arrive
+    lib.hu_batch_destroy(hb)
+    assert lib.hu_batch_create(Dw.h, C.c_int(0), C.byref(hb)) == -1
+    offs = np.zeros(10, np.int64)
+    assert lib.hu_batch_set_reads(B.h, C.c_int(9), b"ACGT", offs.ctypes.data_as(C.c_void_p), None, None, None, None) == -1    # n > max_reads
+    assert b"bad argument" in lib.hu_last_error()
+    # (3) exceptions: a worker of the host pool (needs >= 512 reads to spread over the pool), the calling thread, the formatter's pool
+    n = 600
+    rs = [reads[i % 8].seq for i in range(n)]; vv = np.stack([vps[i % 8] for i in range(n)])
+    Bb = E.Batch(Dfull, n); Bb.set_reads(rs, vv)
+    for code, what, status in ((1, b"memory", -4), (2, b"injected", -4)):
+        Bb.set_knob("inject_fault", code)
+        rc = lib.hu_assign_batch(Bb.h, C.byref(opts))
+        assert rc == status and what in lib.hu_last_error(), (code, rc, lib.hu_last_error())
+    Bb.set_knob("inject_fault", 3)
+    Bb.assign(opts)
+    txt = C.c_char_p(); lib.hu_batch_format_tsv_ptr.restype = C.c_int64
+    ids_ = (C.c_char_p * n)(*[b"r%d" % i for i in range(n)])
+    assert lib.hu_batch_format_tsv_ptr(Bb.h, ids_, None, None, None, C.c_int(0), C.c_int(0), C.byref(txt)) == -5 and b"injected" in lib.hu_last_error()
+    Bb.set_knob("inject_fault", 0)
+    Bb.assign(opts)                                                          # the same batch object still works
+    assert np.array_equal(Bb.placements()["c_node"][:8], want["c_node"])
+    assert len(Bb.format_tsv(["r%d" % i for i in range(n)]).strip("\n").split("\n")) == n
+    Bb.close(); B.close(); Dw.close(); Dfull.close()
+
+
 def test_topk_sampled_threshold_path(monkeypatch):
     """k_seed_topk's fast path (threshold bin estimated from one eighth of the pairs) on trees far below its
     default size limit: seed ids, order and (d, N) stay bit-exact, whether the estimate suffices or the exact
