@@ -193,11 +193,11 @@ def main():
         else:
             all_reads.append(reads); all_vps.append(np.stack([synth.read_vpaths(db.hmm, r) for r in reads]))
     # ---- end-to-end pool: --e2e-reads DISTINCT reads of the headline shape as one byte buffer (drawn from the log-space messages, like the batches)
-    pool = None
+    e2e_pool = None
     if rank == 0 and world == 1 and args.e2e_reads > 0 and not args.paired:
         tp = time.time()
-        pool = synth_gpu.simulate_pool_gpu(db, up, down, args.e2e_reads, args.read_len, seed=777, amplicon_start=amp_start, amplicon_cols=amp_cols, device=dev)
-        log("end-to-end pool: %d distinct reads, %.1f MB (%.0fs)" % (len(pool[1]) - 1, pool[0].nbytes / 1e6, time.time() - tp))
+        e2e_pool = synth_gpu.simulate_pool_gpu(db, up, down, args.e2e_reads, args.read_len, seed=777, amplicon_start=amp_start, amplicon_cols=amp_cols, device=dev)
+        log("end-to-end pool: %d distinct reads, %.1f MB (%.0fs)" % (len(e2e_pool[1]) - 1, e2e_pool[0].nbytes / 1e6, time.time() - tp))
 
     # ---- CPU baseline, phase A (rank 0, N = 1): the oracle's alignment + getSeed on a bounded sample of batch 0, BEFORE the engine adopts the
     # messages (it rewrites them in place into its packed form).  getSeed reads no message; estimateSeq / placeSeq read those of a read's <= 50
@@ -328,6 +328,7 @@ def main():
     R = float((en[ok] - st[ok] + 1).mean())
     best = B.placements()
     cand = B.candidates()
+    _, cplaces = B.candidate_places()        # fetched now: the end-to-end block below reuses the batch objects
     C = float(np.diff(cand["offs"]).mean())
     place_iters = dict(outer_mean=float((cand["iters"] & 255).mean()), outer_max=int((cand["iters"] & 255).max()),
                        em_mean=float((cand["iters"] >> 8).mean()), em_max=int((cand["iters"] >> 8).max()))
@@ -422,12 +423,12 @@ def main():
 
     # ---- end to end in this process: host seed lookup (hu_seed_index_lookup over the leaf rows' own index) -> read upload -> engine -> TSV lines,
     # over the pool of distinct reads drawn before the database was packed; one worker thread per batch object, chunks dealt in order of completion
-    if pool is not None:
+    if e2e_pool is not None:
         try:
             import ctypes as Ct
             import queue
             import threading
-            cat, offs = pool
+            cat, offs = e2e_pool
             nr = len(offs) - 1
             tb = time.perf_counter()
             ix = E.SeedIndex(db.parent, db.seq, db.hmm, 20)
@@ -506,7 +507,6 @@ def main():
             tot = parity.summarize(per)
             agree = float((r1["best_nodes"][:ns, 0] == best["c_node"][:ns]).mean())
             # numbers: candidate by candidate (matched by branch inside a read)
-            _, cplaces = B.candidate_places()
             rel = dict(est_loglik=[], ratio=[], wnr=[], height=[]); it_out = it_em = ncmp = nan_mismatch = 0
             for i in range(ns):
                 k = int(r1["n_cand"][i]); a = int(cand["offs"][i]); b = int(cand["offs"][i + 1])

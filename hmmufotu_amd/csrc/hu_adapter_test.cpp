@@ -8,6 +8,7 @@
 // row is all zero).  "files": hu_db_load on the two files.  "text": the profile and the model go through
 // hu_profile_parse_text / hu_model_parse_text — the text a maintainer gets from `os << hmm` and `model->write(os)` on loaded
 // reference objects — and the tree arrays through hu_db_create, as they would come from PTUnrooted's public getters.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -64,7 +65,8 @@ int main(int argc, char** argv) {
 			check(hu_db_create(&pd, &td, &md2, 0, &db));
 		}
 		hu_opts o; hu_default_opts(&o);
-		PerRead pr(db, o);
+		Engine ptu(db, o);
+		const size_t maxNSeed = (size_t) o.max_nseed;
 		std::ifstream in(argv[3]);
 		std::string line;
 		int r = 0;
@@ -72,17 +74,48 @@ int main(int argc, char** argv) {
 			if(line.empty()) continue;
 			std::istringstream ls(line);
 			std::string bases; ls >> bases;
-			std::vector<ViterbiAlignPath> seeds;
-			for(int k = 0; k < 2; ++k) { ViterbiAlignPath v; ls >> v.start >> v.end >> v.from >> v.to >> v.nIns >> v.nDel; if(v.start > 0) seeds.push_back(v); }
-			HmmAlignment a = pr.alignSeq(bases, seeds);
-			printf("ALN %d %d %d %d %d %d %d %d %.17g %s\n", r, a.status, a.seqStart, a.seqEnd, a.hmmStart, a.hmmEnd, a.csStart, a.csEnd, a.cost, a.isValid() ? a.align.c_str() : "-");
-			if(a.isValid()) {
-				std::vector<PTLoc> locs = pr.getSeed();
-				printf("SEED %d %zu", r, locs.size());
-				for(const PTLoc& l : locs) printf(" %ld:%.17g", l.id, l.dist);
+			std::vector<ViterbiAlignPath> vpaths;
+			for(int k = 0; k < 2; ++k) { ViterbiAlignPath v; ls >> v.start >> v.end >> v.from >> v.to >> v.nIns >> v.nDel; if(v.start > 0) vpaths.push_back(v); }
+			/* the task body of src/hmmufotu.cpp:621-733, call by call */
+			HmmAlignment aln = ptu.alignSeq(bases, vpaths);
+			printf("ALN %d %d %d %d %d %d %d %d %.17g %s\n", r, aln.status, aln.seqStart, aln.seqEnd, aln.hmmStart, aln.hmmEnd, aln.csStart, aln.csEnd, aln.cost, aln.isValid() ? aln.align.c_str() : "-");
+			if(aln.isValid()) {
+				DigitalSeq seq(aln.align);                                                                        /* :641 */
+				std::vector<PTLoc> seeds = getSeed(ptu, seq, aln.csStart - 1, aln.csEnd - 1, o.max_diff, o.max_height);   /* :645 */
+				if(seeds.size() > maxNSeed) seeds.erase(seeds.end() - (seeds.size() - maxNSeed), seeds.end());      /* :646-647 */
+				printf("SEED %d %zu", r, seeds.size());
+				for(const PTLoc& l : seeds) printf(" %ld:%.17g", l.id, l.dist);
 				printf("\n");
-				PTPlacement p = pr.place();
+				std::vector<PTPlacement> places = estimateSeq(ptu, seq, seeds, "unweighted");                       /* :720 */
+				printf("EST %d %zu", r, places.size());
+				for(const PTPlacement& p : places) printf(" %ld:%.17g:%.17g:%.17g", p.cNode, p.ratio, p.wnr, p.loglik);
+				printf("\n");
+				{ /* the member form on one location gives the same record */
+					const PTPlacement one = ptu.estimateSeq(seq, seeds[0], "unweighted");
+					printf("MEMBER %d %d\n", r, (int)(one.cNode == places[0].cNode && one.ratio == places[0].ratio && one.wnr == places[0].wnr && one.loglik == places[0].loglik));
+				}
+				filterPlacements(places, o.max_error);                                                           /* :722 */
+				printf("FILT %d %zu", r, places.size());
+				for(const PTPlacement& p : places) printf(" %ld", p.cNode);
+				printf("\n");
+				placeSeq(ptu, seq, places, o.max_height);                                                         /* :724 */
+				printf("PLACED %d %zu", r, places.size());
+				for(const PTPlacement& p : places) printf(" %ld:%ld:%.17g:%.17g:%.17g:%.17g", p.cNode, p.aNode, p.ratio, p.wnr, p.loglik, p.height);
+				printf("\n");
+				calcQValues(ptu, places, UNIFORM);                                                                /* :729 */
+				printf("Q %d %zu", r, places.size());
+				for(const PTPlacement& p : places) printf(" %ld:%.17g:%.17g", p.cNode, p.qPlace, p.qTaxon);
+				printf("\n");
+				std::sort(places.rbegin(), places.rend(), compareByQPlace);                                       /* :730 */
+				const PTPlacement& p = places[0];                                                                 /* :733 */
 				printf("PLACE %d %ld %ld %ld %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", r, p.cNode, p.pNode, p.aNode, p.start, p.end, p.ratio, p.wnr, p.loglik, p.height, p.qPlace, p.qTaxon);
+				if(r == 0 && places.size() > 1) { /* a caller that drops a placement between the stages: the later stages see the vector as it is */
+					std::vector<PTPlacement> fewer(places.begin() + 1, places.end());
+					calcQValues(ptu, fewer, UNIFORM);
+					printf("QDROP %d %zu", r, fewer.size());
+					for(const PTPlacement& q : fewer) printf(" %ld:%.17g", q.cNode, q.qPlace);
+					printf("\n");
+				}
 			}
 			++r;
 		}

@@ -723,19 +723,16 @@ struct HuKnobs {
 	int viterbi_dec1 = 0;        /* alias of viterbi_mode = 1                                                        */
 	int vw_diag = 0;             /* k_viterbi_wave diagnostics variant                                               */
 	int viterbi_force_redo = 0;  /* flag every traceback "needs values": the redo pass runs for all sequences        */
-	int pdist_v1 = 0;            /* the per-read insert loop scan kernel                                             */
 	int tile_unsorted = 0;       /* scan tiles in read order instead of sorted by region start                       */
 	int pairs32 = 0;             /* 32-bit (d, N) pairs even when every read has <= 255 bases                        */
 	int topk_fast_min = 16384;   /* trees smaller than this take the exact two-pass histogram in k_seed_topk         */
 	int topk_general = 0;        /* every read through the general top-k launch (k_seed_topk_d<DT, true>) instead of the straight kernel */
-	int dscan1 = 0;              /* the distance-only scan with one node per lane and scalar read planes (k_seed_dscan)             */
 	int scan_pairs = 0;          /* 1: the full (d, N) pair matrix + k_seed_topk on large trees too; -1: the distance-only scan even with many partial sequences */
 	int streaming_sep = 0;       /* one-wave streaming estimate / place kernels                                      */
 	int est_unsorted = 0, place_unsorted = 0;   /* launch in read order instead of node order                        */
 	int xcd_map = 1;             /* an eighth of the node-sorted list per XCD                                        */
 	int est_var = 0, place_var = 0;             /* alternative kernel variants (comparison / diagnostics)            */
 	int place_nosplit = 0;       /* column-order placement kernel even when the gap / base split applies             */
-	int place_em1 = 0;           /* k_place_w1: the EM of a branch on one wave (0: k_place_blk, EM steps across both waves) */
 	int place_lds_pad = 0;       /* KB of unused dynamic LDS per placement workgroup: fewer of them per CU (experiment) */
 	int est_lds_pad = 0;         /* the same for the estimate kernel                                                  */
 	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
@@ -749,10 +746,10 @@ struct HuKnobEntry { const char* name; int HuKnobs::* field; };
 static const HuKnobEntry kKnobs[] = {
 	{"viterbi_hbm", &HuKnobs::viterbi_hbm}, {"viterbi_values", &HuKnobs::viterbi_values}, {"viterbi_mode", &HuKnobs::viterbi_mode},
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
-	{"pdist_v1", &HuKnobs::pdist_v1}, {"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"dscan1", &HuKnobs::dscan1}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
+	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_em1", &HuKnobs::place_em1}, {"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault},
+	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -775,6 +772,7 @@ struct hu_batch {
 	HuKnobs knob;
 	int maxBases = 1 << 30;      /* most bases any read of the batch can have inside its region (set with the reads) */
 	bool fixedRoot = false;      /* the last place call computed the intended root logliks (hu_opts.fix_root_loglik) */
+	bool placesGiven = false;    /* the placed candidates came from the caller (hu_batch_set_candidates, placed): hu_finish_batch takes them as they are */
 	bool pair16 = false;         /* the pair matrix of the last seed scan holds 16-bit pairs (maxBases <= 255) */
 	int scanWidth = 0;           /* bytes per distance of the distance-only scan's matrix in dPairs (0 = none) */
 	int pairsKind = 0;           /* what dPairs holds after the last seed stage: 16 / 32-bit (d, N) pairs, or 0 = no pair matrix (distance-only scan, given seeds) */
@@ -1289,9 +1287,9 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 	 * more than 2 % of the reference sequences are partial (measured at gg_97 scale with 40 % of the leaves cut: 264 k reads/s on the
 	 * distance-only path, whose top-k then wades through thousands of barely overlapping candidates per read, 378 k on the pair matrix) */
 	const bool manyPartial = b->db->partialFrac > 0.02 && b->knob.scan_pairs != -1;
-	const bool dOnly = b->knob.scan_pairs != 1 && !manyPartial && !b->knob.pdist_v1 && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
+	const bool dOnly = b->knob.scan_pairs != 1 && !manyPartial && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
 	const bool narrow = !b->knob.pairs32 && b->maxBases <= 255;      /* 8-bit distances / 16-bit pairs */
-	b->pair16 = !dOnly && narrow && !b->knob.pdist_v1;
+	b->pair16 = !dOnly && narrow;
 	b->pairsKind = dOnly ? 0 : (b->pair16 ? 16 : 32);
 	b->scanWidth = dOnly ? (narrow ? 1 : 2) : 0;
 	if((rc = b->dPairs.ensure(std::max<size_t>(n, 1) * d.nNodesPad / (dOnly ? (narrow ? 4 : 2) : (b->pair16 ? 2 : 1)))) != HU_OK) return rc;
@@ -1314,11 +1312,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 		{
 			Timer t(b, HU_T_SEED_PDIST);
 			const dim3 grid4(tiles, (d.nNodesPad + 1023) / 1024);
-			if(dOnly && b->knob.dscan1 && narrow) k_seed_dscan<uint8_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
-			else if(dOnly && b->knob.dscan1) k_seed_dscan<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
-			else if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, (size_t)(b->knob.scan_lds_pad > 0 && b->knob.scan_lds_pad <= 44 ? b->knob.scan_lds_pad : 0) * 1024, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, (size_t)(b->knob.scan_lds_pad > 0 && b->knob.scan_lds_pad <= 44 ? b->knob.scan_lds_pad : 0) * 1024, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
-			else if(b->knob.pdist_v1) k_seed_pdist<HU_READ_TILE, 1><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dIns.p, b->dPairs.p, b->dSlotRead.p);
 			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
 			else k_seed_pdist2<uint32_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
 		}
@@ -1559,6 +1554,54 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) try {
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_filter_batch"); }
 
+extern "C" int hu_batch_set_candidates(hu_batch* b, const int64_t* offs, const hu_place_rec* recs, int placed) try {
+	if(!b || !offs) { hu_set_error("hu_batch_set_candidates: null argument"); return HU_ERR_ARG; }
+	if(b->state < ST_ALIGNED) { hu_set_error("hu_batch_set_candidates: reads are not aligned"); return HU_ERR_STATE; }
+	const hu_db* db = b->db;
+	const size_t n = (size_t) b->n;
+	if(offs[0] != 0) { hu_set_error("hu_batch_set_candidates: offs[0] must be 0"); return HU_ERR_ARG; }
+	for(size_t r = 0; r < n; ++r) {
+		const int64_t k = offs[r + 1] - offs[r];
+		if(k < 0 || k > HU_MAX_SEEDS || (k > 0 && (!recs || b->hAlns[r].status != HU_READ_OK || b->hEnd[r] < b->hStart[r]))) {
+			hu_set_error("hu_batch_set_candidates: read %zu: %lld candidates (0..%d, none for a read that is not placed)", r, (long long) k, HU_MAX_SEEDS); return HU_ERR_ARG;
+		}
+		for(int64_t c = offs[r]; c < offs[r + 1]; ++c) {
+			const int32_t u = recs[c].c_node;
+			if(u < 0 || u >= db->dev.nNodes || db->parent[u] < 0) { hu_set_error("hu_batch_set_candidates: read %zu names node %d (a branch is named by its child end: a non-root node)", r, u); return HU_ERR_ARG; }
+		}
+	}
+	HIPCHK(hipSetDevice(db->device));
+	b->candOffs.assign(offs, offs + n + 1);
+	const size_t nc = (size_t) offs[n];
+	b->places.resize(nc); b->hCands.resize(nc);
+	for(size_t r = 0; r < n; ++r) for(int64_t c = offs[r]; c < offs[r + 1]; ++c) {
+		const hu_place_rec& q = recs[c];
+		HostPlace p;
+		memset(&p, 0, sizeof(p));
+		p.seedIdx = (int32_t)(c - offs[r]); p.cNode = q.c_node; p.pNode = db->parent[q.c_node]; p.wuv = db->blen[q.c_node];
+		p.ratio = q.ratio; p.wnr = q.wnr; p.estLoglik = q.est_loglik; p.rootLoglik = NAN; p.qPlace = p.qTaxon = NAN;
+		if(placed) { p.loglik = q.loglik; p.height = q.height; p.aNode = q.a_node == p.pNode ? p.pNode : p.cNode; p.rootLoglik = q.root_loglik; }
+		else { p.loglik = q.est_loglik; p.aNode = p.ratio <= 0.5 ? p.cNode : p.pNode; }
+		b->places[c] = p;
+		HuCand cd; cd.read = (int32_t) r; cd.node = p.cNode; cd.ratio0 = p.ratio; cd.wnr0 = p.wnr;
+		b->hCands[c] = cd;
+	}
+	if(!placed && n) { /* gap / base site counts of the regions for the split placement kernel (the estimate stage may not have run on this batch) */
+		int rc;
+		if((rc = b->dPermCnt.ensure(n * 2)) != HU_OK) return rc;
+		b->hPermCnt.resize(n * 2);
+		(void) hipGetLastError();
+		k_site_count<<<b->n, 64, 0, b->stream>>>(db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPermCnt.p);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(b->hPermCnt.data(), b->dPermCnt.p, n * 8, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	b->placesGiven = placed != 0;
+	b->fixedRoot = false;
+	b->state = placed ? ST_PLACED : ST_FILTERED;
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_batch_set_candidates"); }
+
 __global__ void k_cand_sortkeys(int nc, const HuCand* __restrict__ cands, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if(i >= nc) return;
@@ -1606,33 +1649,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 				order = b->dSortV.p + nc;
 			}
 			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
-			if(var == 97 && spt2 <= 12 && spt2 > 8) { /* diagnostic: s_memtime stamps of k_place_w1, per wave role, averaged over the candidates, to stderr */
-				DBuf<long long> ddb;
-				if((rc = ddb.ensure(nc * 16)) != HU_OK) return rc;
-				bool split = b->hPermCnt.size() == (size_t) b->n * 2;
-				for(int r = 0; r < b->n && split; ++r) if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > 10 * 128 || b->hPermCnt[2 * r + 1] > 2 * 128)) split = false;
-				if(split) {
-					if((rc = b->dPerm.ensure((size_t) b->n * 12 * 128)) != HU_OK) return rc;
-					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, 10 * 128, 2 * 128, b->dPerm.p);
-					k_place_w1<12, 10, 2, true><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm, ddb.p);
-				}
-				else k_place_w1<12, 0, 2, true><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm, ddb.p);
-				std::vector<long long> hd(nc * 16);
-				HIPCHK(hipMemcpyAsync(hd.data(), ddb.p, nc * 16 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
-				HIPCHK(hipStreamSynchronize(b->stream));
-				double acc[16] = {0};
-				for(size_t c = 0; c < nc; ++c) { /* wave 0 of block c serves phase i when (c >> 3 & 1) == 0 */
-					const int s0 = ((c >> 3) & 1) == 0 ? 0 : 1;     /* index of the wave serving phase (i) */
-					for(int i = 0; i < 8; ++i) { acc[i] += (double) hd[(c * 2 + s0) * 8 + i]; acc[8 + i] += (double) hd[(c * 2 + (1 - s0)) * 8 + i]; }
-				}
-				const char* nm[8] = {"load", "exps+tables", "sweeps", "em", "barrier-wait", "hand-over", "total", "em-steps"};
-				for(int role = 0; role < 2; ++role) {
-					fprintf(stderr, "[place dbg] wave serving phase %s:", role == 0 ? "(i) " : "(ii)");
-					for(int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", nm[i], acc[role * 8 + i] / nc);
-					fprintf(stderr, "\n");
-				}
-			}
-			else if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
+			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
 				DBuf<long long> ddb;
 				if((rc = ddb.ensure(nc * 12)) != HU_OK) return rc;
 				long long* dd = ddb.p;
@@ -1652,7 +1669,6 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
 			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
 			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
-			else if(spt2 <= 4 && b->knob.place_em1 && var == 0) k_place_w1<4, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
 			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
 			else if(spt2 <= 12 && !(var == 7)) {
 				/* 8 or 12 sites per thread.  When every read of the batch fits, its gap sites and its base sites go to separate
@@ -1662,23 +1678,18 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 				bool split = !b->knob.place_nosplit && b->hPermCnt.size() == (size_t) b->n * 2;
 				for(int r = 0; r < b->n && split; ++r)
 					if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > G * 128 || b->hPermCnt[2 * r + 1] > (S - G) * 128)) split = false;
-				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", b->knob.place_em1 ? "EM on one wave" : "EM across both waves");
+				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", "EM across both waves");
 				if(split) {
 					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
 					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
-					const bool em1 = b->knob.place_em1 != 0;
-					if(S == 8 && em1) k_place_w1<8, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
-					else if(em1) k_place_w1<12, 10><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, b->dPerm.p, b->dPermCnt.p, xm);
 					/* regions of <= 1,024 sites (150-base reads): the whole v message in LDS (VL = 3, 24 KB per workgroup), 168 VGPRs, three waves per
 					 * SIMD: FIVE workgroups per CU instead of four (the LDS holds five) — the kernel's time goes with the resident candidates
 					 * (DESIGN.md section 7): 4.18 -> 3.78 ms per 8,192 reads at gg_97 scale, 853 k -> 896 k reads/s.  Same arithmetic (results equal to 1e-12, iteration counts identical).
 					 * Measured and not kept: the model constants read from global memory instead of 1.5 KB of LDS, which lets a sixth workgroup in — 32 B of scratch, 3.97 ms. */
-					else if(S == 8 && var != 6) k_place_blk<8, 2, 3, 0, 3, false, 3, 6><<<(unsigned) nc, 128, 3 * 8 * 128 * sizeof(double), b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+					if(S == 8 && var != 6) k_place_blk<8, 2, 3, 0, 3, false, 3, 6><<<(unsigned) nc, 128, 3 * 8 * 128 * sizeof(double), b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 					else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);   /* place_var = 6: v in registers, two waves per SIMD */
 					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, (size_t)(b->knob.place_lds_pad > 0 && b->knob.place_lds_pad <= 44 ? b->knob.place_lds_pad : 0) * 1024, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
 				}
-				else if(S == 8 && b->knob.place_em1) k_place_w1<8, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
-				else if(b->knob.place_em1) k_place_w1<12, 0><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, order, nullptr, nullptr, xm);
 				else if(S == 8) PL_GO(8, 2, 3, 0, 2);
 				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
 			}
@@ -1707,6 +1718,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 		HIPCHK(hipStreamSynchronize(b->stream));
 	}
 	b->fixedRoot = o->fix_root_loglik != 0 && nc > 0;
+	b->placesGiven = false;
 	b->state = ST_PLACED;
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_place_batch"); }
@@ -1741,10 +1753,13 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 		for(int j = 0; j < nsite; ++j) ll += siteLL;
 		for(int64_t c = lo; c < hi; ++c) { /* PTUnrooted::placeSeq const (src/PhyloTreeUnrooted.cpp:936-952) */
 			HostPlace& p = pl[c - lo];
-			const HuPlaceOut& po = b->hPlaceOut[c];
-			p.rootLoglik = b->fixedRoot ? b->hRootLL[c] : NAN;
-			p.loglik = b->fixedRoot ? p.rootLoglik : ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
-			p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
+			const HuPlaceOut none = {0, 0, 0, 0};
+			const HuPlaceOut& po = b->placesGiven ? none : b->hPlaceOut[c];
+			if(!b->placesGiven) {
+				p.rootLoglik = b->fixedRoot ? b->hRootLL[c] : NAN;
+				p.loglik = b->fixedRoot ? p.rootLoglik : ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
+				p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
+			}
 			p.qPlace = p.qTaxon = NAN;     /* --ML computes none */
 			b->places[c] = p;
 		}

@@ -810,9 +810,12 @@ __global__ __launch_bounds__(64) void k_viterbi_wave(HuDbDev db, const HuReadDes
 				if(reg_contains(g2, i, j)) later = true;
 				if(i >= g2.i0 - 1 && i <= g2.i1 && j >= g2.j0 - 1 && j <= g2.j1) near = true;
 			}
-			if(near && i >= g.ci0 && j >= g.cj0) {
-				const int64_t idx = (g.coff + (int64_t)(j - g.cj0) * (g.i1 - g.ci0 + 1) + (i - g.ci0)) * 3;
-				scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+			if(near) { /* the corner block's origin is read from LDS here, on the rare path, instead of living in four registers for the whole phase */
+				const HuRegion& gc = sreg[r];
+				if(i >= gc.ci0 && j >= gc.cj0) {
+					const int64_t idx = (gc.coff + (int64_t)(j - gc.cj0) * (gc.i1 - gc.ci0 + 1) + (i - gc.ci0)) * 3;
+					scr[idx] = M; scr[idx + 1] = I; scr[idx + 2] = D;
+				}
 			}
 			if(!later) {
 				const double ccv = __dmul_rn(tCC, (double)(L - i));

@@ -364,19 +364,6 @@ __device__ inline double fast_div(double a, double b) { /* a / b to ~1 ulp for f
 	return fma(fma(-b, q, a), y, q);
 }
 
-typedef double hu_double4 __attribute__((ext_vector_type(4)));
-/* sum over the 64 lanes on the matrix pipe, identical in every lane.  A[i][k] = x(lane i + 16 k), B = ones:
- * D[i][.] = sum_k A[i][k]; lane l holds D rows (l >> 4) + 4 r, r = 0..3; their sum T(l >> 4) is the next
- * A[i][k = l >> 4]: D' = sum_k T_k.  (Measured slower than the DPP butterfly in k_place_blk: the two dependent
- * f64 MFMAs cost more latency than the butterfly costs issue slots; kept for reference.) */
-__device__ inline double wave_sum_mfma(double x) {
-	const hu_double4 z = {0.0, 0.0, 0.0, 0.0};
-	hu_double4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(x, 1.0, z, 0, 0, 0);
-	const double t = (d[0] + d[1]) + (d[2] + d[3]);
-	d = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
-	return d[0];
-}
-
 /* exp / log as real calls: inlined, their ~20 polynomial coefficients are hoisted out of the candidate's outer loop
  * and sit in ~45 VGPRs for the whole kernel (64-bit literals cannot be VOP3 operands) — the difference between two
  * and four workgroups per CU.  They run a few times per EM call, never per site. */
@@ -384,7 +371,7 @@ __device__ __attribute__((noinline)) double hu_exp_call(double x) { return exp(x
 __device__ __attribute__((noinline)) double hu_log_call(double x) { return log(x); }
 
 /* EMV: Newton steps on v_rcp_f64 (2^-23 or better): 1 -> 2^-46 per term (a 1e-14 relative bias on the branch
- * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: 0 = DPP butterfly, 1 = MFMA.
+ * length, eight orders below the 1e-6 bar), 2 -> full double precision.  RED: unused (0).
  * Measured and not kept (round 2): s_memtime stamps put a step of the 12-site kernel at 680 ticks of arithmetic + 378 of wave reduction and
  * exchange + 200 of tail.  Shortening the second half — row sums only on the DPP network, the 4 NW row sums handed over through LDS as a
  * broadcast read, the tail's factors computed before the exchange — changed nothing (8.80 against 8.86 ms), nor did the stage-by-stage
@@ -457,7 +444,7 @@ __device__ inline double em_branch_blk(const double (&rho)[SPT], int nvalidWave,
 		}
 		if(st) { if(s == 1.2345e-300) st[7] = 1; }   /* wait for the arithmetic */
 		stamp(0);
-		s = RED ? wave_sum_mfma(s) : wave_sum_uniform(s);
+		s = wave_sum_uniform(s);       /* (RED = 1 once chose a wave sum on two v_mfma_f64_16x16x4: measured slower than the DPP butterfly, removed in round 3) */
 		stamp(1);
 		double* r = red + (phase & 1) * NW;
 		if(lane == 0) r[wave] = s;
@@ -730,297 +717,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 		tk[4] = (long long) __builtin_amdgcn_s_memtime() - t0; tk[5] = iter; tk[6] = emIters;
 		for(int i = 0; i < 8; ++i) dbg[(size_t) blockIdx.x * 8 + i] = tk[i];
 		for(int i = 0; i < 4; ++i) dbg[(size_t) gridDim.x * 8 + (size_t) blockIdx.x * 4 + i] = te[i];
-	}
-}
-
-/* ------------------------------------------------------------------------------------------------
- * k_place_w1: the same optimisation (one workgroup of two waves per candidate, messages register-resident, table-driven
- * sweeps) with the EM of a branch run by ONE wave.
- *
- * In k_place_blk every EM step ends in a dependency chain — DPP butterfly, LDS exchange between the two waves, s_barrier,
- * scalar tail — of about the length of the step's arithmetic, 36 times per candidate, and the co-resident workgroups
- * fall into step with each other (s_memtime stamps: 1.27 k ticks per step for ~290 cycles of issue per wave; VALU active
- * 34 % of the wave cycles).  An EM step needs nothing but the per-site ratios rho_j, one double per site: after a sweep the
- * partner wave hands its ratios over through LDS once (6 KB), and one wave iterates on all of the candidate's ratios with
- * no barrier and no LDS inside the loop; the other wave sleeps at the barrier behind the EM and costs its SIMD nothing.
- * The same wave then writes the exponentials and the 4x4 tables of the next sweep (they depend on the branch length it
- * has just found), so a phase has two workgroup barriers — ratios handed over, tables ready — instead of three for the
- * tables plus one per EM step.  Which wave serves alternates with the workgroup index, so that the workgroups sharing a
- * CU put their serial phases on different SIMDs.
- * Registers: the third components of both messages live in LDS (24 KB at 12 sites per thread), which pays for the 2 x SPT
- * ratios the serving wave holds.  Arithmetic per site and per step is that of k_place_blk (EMV = 3: one v_rcp_f64 + Newton
- * per four sites); only the order of the sums differs (one wave sum over 24 per-lane terms instead of two over 12). */
-template<int NR>
-__device__ inline double em_branch_wave(const double (&rho)[NR], double cnt, double w0, double maxL, int& emIters) {
-	static_assert(NR % 4 == 0, "ratios are taken four at a time");
-	double q0 = hu_exp_call(-w0), p0 = 1 - q0, p = p0, q = q0;
-	const double rc = 1.0 / cnt;
-	for(int it = 0; it < HU_MAX_ITER && p >= 0 && p <= 1; ++it) {
-		double s = 0;
-		const bool fast = q0 >= 1e-30 && p0 >= 1e-30; /* x = rho q0 + p0 in [1e-30, 1e60]; skipped sites add < 1e-30 */
-		if(fast) { /* 1/a + 1/b + 1/c + 1/d = ((a + b) cd + (c + d) ab) / (abcd): one reciprocal per four sites */
-			double s2 = 0;
-#pragma unroll
-			for(int t = 0; t < NR; t += 4) {
-				const double a = fma(rho[t], q0, p0), bb = fma(rho[t + 1], q0, p0), c = fma(rho[t + 2], q0, p0), d = fma(rho[t + 3], q0, p0);
-				const double ab = a * bb, cd = c * d, x = ab * cd;
-				const double num = fma(a + bb, cd, (c + d) * ab);
-				const double y = __builtin_amdgcn_rcp(x);
-				if(t & 4) s2 = fma(num * y, fma(-x, y, 2.0), s2); else s = fma(num * y, fma(-x, y, 2.0), s);
-			}
-			s += s2;
-		}
-		else { /* degenerate branch lengths (p0 = 0, q0 = 0): the reference's expression as written */
-#pragma unroll
-			for(int t = 0; t < NR; ++t) {
-				const double r = rho[t];
-				const double tt = p0 / fma(r, q0, p0);
-				s += r == HU_RHO_SKIP ? 0.0 : tt;
-			}
-		}
-		s = wave_sum_uniform(s);
-		if(fast) s *= p0;
-		p = s * rc; q = 1 - p;
-		++emIters;
-		if(q0 * HU_EXP_MEPS < q && q < q0 * HU_EXP_PEPS) break; /* |log q - log q0| < BRANCH_EPS */
-		p0 = p; q0 = q;
-	}
-	double w = -hu_log_call(q);
-	if(w > maxL) w = maxL;
-	return w;
-}
-
-/* DBG: diagnostic build, s_memtime ticks per wave into dbg[block][wave][8]: 0 load, 1 exps + tables, 2 sweeps, 3 EM loops,
- * 4 waiting at workgroup barriers, 5 hand-over copies, 6 total, 7 EM steps served */
-template<int SPT, int GS, int OCC = 2, bool DBG = false>
-__global__ __launch_bounds__(128, OCC) void k_place_w1(HuDbDev db, HuModelDev mdl, const int8_t* __restrict__ codes,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
-		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, const uint32_t* __restrict__ order,
-		const uint16_t* __restrict__ perm, const int32_t* __restrict__ permCnt, int xmap, long long* __restrict__ dbg = nullptr) {
-	constexpr int THREADS = 128;
-	long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, tl = 0;
-	auto stamp = [&](int slot) { if(DBG) { const long long t = (long long) __builtin_amdgcn_s_memtime(); tk[slot] += t - tl; tl = t; } };
-	if(DBG) { t0 = tl = (long long) __builtin_amdgcn_s_memtime(); }
-	__shared__ double cst[HU_PC_COUNT];
-	__shared__ double Etab[3 * HU_MAX_DGK * 4];          /* [which][k][m] = exp(lam_m len_which rate_k) */
-	__shared__ double Gtab[16];
-	__shared__ __attribute__((aligned(16))) double tabM[5 * HU_TP];
-	__shared__ __attribute__((aligned(16))) double tabD[6 * 4];             /* sweep (i): row 0 = G_mm; sweep (ii): row b = T^b_mm */
-	__shared__ double u2s[SPT * THREADS], v2s[SPT * THREADS];              /* third components of the normalised messages */
-	__shared__ double rhoX[SPT * 64];                                      /* the partner wave's ratios, handed over per phase */
-	__shared__ double pub[4];                                              /* [0] wnr, [1] wur, [2] the partner wave's site count */
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	/* the n-r branch (phase i) is served by one wave, the u-r branch (phase ii) by the other: whatever SIMDs the two waves sit
-	 * on, the serial work of a workgroup is split evenly between them (a fixed serving wave put the EMs of all the workgroups
-	 * of a CU on two of its four SIMDs: the workgroups of a CU have block indices of one parity) */
-	const bool serveI = wave == (int)(blockIdx.x >> 3 & 1u), serveII = !serveI;
-	const uint32_t ci = order ? order[hu_xcd_pos(blockIdx.x, gridDim.x, xmap)] : blockIdx.x;
-	const HuCand cd = cands[ci];
-	const int read = cd.read, un = cd.node;
-	const int start = rstart[read], end = rend[read], n = end - start + 1;
-	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
-	const double rKc = 1.0 / (double) Kc;
-	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;
-	const int64_t mOff = ((int64_t) un * db.winLen + (start - db.winStart)) * 4;
-	const double* __restrict__ Ub = db.up + mOff;
-	const double* __restrict__ Vb = db.down + mOff;
-	const int nGap = GS > 0 ? permCnt[2 * read] : 0, nBase = GS > 0 ? permCnt[2 * read + 1] : 0;
-	double u[SPT][2], v[SPT][2]; unsigned long long bop = 0, bop2 = 0;   /* base / gap code of slot t: 3 bits, slots 21.. in bop2 */
-	{
-		double aU[SPT][4], aV[SPT][4];
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			int jj;
-			if(GS > 0) { /* slot t of the site list: [0, GS x THREADS) gap sites, then the base sites */
-				const int i = t < GS ? tid + THREADS * t : tid + THREADS * (t - GS);
-				const bool val = i < (t < GS ? nGap : nBase);
-				jj = val ? (int) perm[(size_t) read * (SPT * THREADS) + (t < GS ? 0 : GS * THREADS) + i] : 0;
-			}
-			else { const int j = tid + THREADS * t; jj = j < n ? j : 0; }
-			load4(Ub + (size_t) jj * 4, aU[t]); load4(Vb + (size_t) jj * 4, aV[t]);
-			const int b = cdr[jj];
-			if(t < 21) bop |= (unsigned long long)(b >= 0 ? b : 4) << (3 * t);
-			else bop2 |= (unsigned long long)(b >= 0 ? b : 4) << (3 * (t - 21));
-		}
-#pragma unroll
-		for(int t = 0; t < SPT; ++t) {
-			const double iu = 1.0 / aU[t][0], iv = 1.0 / aV[t][0];
-			u[t][0] = aU[t][1] * iu; u[t][1] = aU[t][2] * iu; u2s[t * THREADS + tid] = aU[t][3] * iu;
-			v[t][0] = aV[t][1] * iv; v[t][1] = aV[t][2] * iv; v2s[t * THREADS + tid] = aV[t][3] * iv;
-		}
-	}
-	for(int i = tid; i < HU_PC_COUNT; i += THREADS) cst[i] = db.placeConst[i];
-	if(DBG) { double x = 0; for(int t = 0; t < SPT; ++t) x += u[t][0] + v[t][1]; if(x == 1.2345e-300) tk[7] = 1; } /* wait for the loads */
-	stamp(0);
-	lds_barrier();
-	stamp(4);
-	const double* clam = cst + HU_PC_LAM; const double* crate = cst + HU_PC_RATE; const double* cW = cst + HU_PC_W;
-	const double* cC = cst + HU_PC_C; const double* ccb = cst + HU_PC_CB;
-	const double w0 = db.blen[un];
-	double lenUR = w0 * cd.ratio0, lenVR = w0 * (1 - cd.ratio0), lenNR = cd.wnr0;
-	double wur0 = lenUR, wnr0 = lenNR;
-	const double w0j = lenUR + lenVR;
-	double wur = wur0, wnr = wnr0;
-	int iter = 0, emIters = 0;
-	double rho[SPT];
-	/* serving wave only: exponentials of one branch length, then the tables of a sweep (same expressions as k_place_blk) */
-	auto exps = [&](int which, double len) {
-		for(int e = lane; e < 4 * Kc; e += 64) Etab[(which * HU_MAX_DGK + (e >> 2)) * 4 + (e & 3)] = hu_exp_call(clam[e & 3] * (len * crate[e >> 2]));
-	};
-	auto tables_i = [&]() { /* G_mn = mean_k exp(lam_m w_ur r_k) exp(lam_n w_vr r_k); N^b_mn = W^b_mn G_mn */
-		lds_wave_sync();
-		if(lane < 16) {
-			const int m = lane >> 2, nn = lane & 3;
-			double g = 0;
-			for(int k = 0; k < Kc; ++k) g += Etab[k * 4 + m] * Etab[(HU_MAX_DGK + k) * 4 + nn];
-			Gtab[lane] = g * rKc;
-		}
-		lds_wave_sync();
-		for(int e = lane; e < 84; e += 64) {
-			if(e < 80) tabM[(e >> 4) * HU_TP + (e & 15)] = cW[e] * Gtab[e & 15];
-			else tabD[e - 80] = Gtab[(e - 80) * 5];
-		}
-	};
-	auto tables_ii = [&]() { /* G'_mn = mean_k exp(lam_m w_vr r_k) exp(lam_n w_nr r_k); T^b_mn = c^b_n G'_mn; Z^b_mk = sum_n T^b_mn C_mnk */
-		lds_wave_sync();
-		if(lane < 16) {
-			const int m = lane >> 2, nn = lane & 3;
-			double g = 0;
-			for(int k = 0; k < Kc; ++k) g += Etab[(HU_MAX_DGK + k) * 4 + m] * Etab[(2 * HU_MAX_DGK + k) * 4 + nn];
-			Gtab[lane] = g * rKc;
-		}
-		lds_wave_sync();
-		for(int e = lane; e < 100; e += 64) {
-			if(e < 80) {
-				const int b = e >> 4, m = (e >> 2) & 3, kk = e & 3;
-				double z = 0;
-#pragma unroll
-				for(int nn = 0; nn < 4; ++nn) z = fma(ccb[b * 4 + nn] * Gtab[m * 4 + nn], cC[(m * 4 + nn) * 4 + kk], z);
-				tabM[b * HU_TP + m * 4 + kk] = z;
-			}
-			else { const int b = (e - 80) >> 2, m = (e - 80) & 3; tabD[b * 4 + m] = ccb[b * 4 + m] * Gtab[m * 5]; }
-		}
-	};
-	/* hand the partner's ratios over; the serving wave returns all 2 x SPT of them and the site count */
-	auto hand_over = [&](int nv, bool isEm) {
-		if(!isEm) {
-#pragma unroll
-			for(int t = 0; t < SPT; ++t) rhoX[t * 64 + lane] = rho[t];
-			if(lane == 0) pub[2] = (double) nv;
-		}
-		stamp(5);
-		lds_barrier();
-		stamp(4);
-	};
-	if(serveII) { exps(0, lenUR); exps(1, lenVR); tables_i(); }
-	stamp(1);
-	lds_barrier();
-	stamp(4);
-	for(; iter < HU_MAX_ITER && 0 <= wur && wur <= w0j; ++iter) {
-		/* (i) message r->n from children u, v against the read's leaf message; EM on the n-r branch */
-		int nv = 0;
-		{
-			unsigned long long bq = bop, bq2 = bop2;
-			asm volatile("" : "+v"(bq), "+v"(bq2));  /* the per-site table addresses are recomputed per sweep, not kept live */
-			const double g0 = tabD[0], g1 = tabD[1], g2 = tabD[2], g3 = tabD[3];
-			double Mg[GS > 0 ? 16 : 1];
-			if(GS > 0) {
-#pragma unroll
-				for(int e = 0; e < 16; ++e) Mg[e] = tabM[4 * HU_TP + e];
-			}
-#pragma unroll
-			for(int t = 0; t < SPT; ++t) {
-				const double* M = (GS > 0 && t < GS) ? Mg : tabM + (unsigned)(((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21)))) & 7u) * HU_TP;
-				const double v0 = v[t][0], v1 = v[t][1], v2 = v2s[t * THREADS + tid];
-				const double u0 = u[t][0], u1 = u[t][1], u2 = u2s[t * THREADS + tid];
-				double num = fma(M[3], v2, fma(M[2], v1, fma(M[1], v0, M[0])));
-				{ const double tm = fma(M[7], v2, fma(M[6], v1, fma(M[5], v0, M[4]))); num = fma(tm, u0, num); }
-				{ const double tm = fma(M[11], v2, fma(M[10], v1, fma(M[9], v0, M[8]))); num = fma(tm, u1, num); }
-				{ const double tm = fma(M[15], v2, fma(M[14], v1, fma(M[13], v0, M[12]))); num = fma(tm, u2, num); }
-				const double den = fma(g3 * u2, v2, fma(g2 * u1, v1, fma(g1 * u0, v0, g0)));
-				const double r = fast_div(num, den);
-				const bool inr = GS > 0 ? (t < GS ? tid + THREADS * t < nGap : tid + THREADS * (t - GS) < nBase) : tid + THREADS * t < n;
-				const bool ok = inr && fabs(r) < HU_RHO_SKIP; /* false for NaN, inf */
-				rho[t] = ok ? r : HU_RHO_SKIP;
-				nv += __popcll(__ballot(ok));
-			}
-		}
-		stamp(2);
-		hand_over(nv, serveI);
-		if(serveI) {
-			double r2[2 * SPT];
-#pragma unroll
-			for(int t = 0; t < SPT; ++t) { r2[t] = rho[t]; r2[SPT + t] = rhoX[t * 64 + lane]; }
-			stamp(5);
-			wnr = em_branch_wave<2 * SPT>(r2, (double) nv + pub[2], lenNR, 1.0, emIters);
-			stamp(3);
-			exps(2, wnr); tables_ii();
-			if(lane == 0) pub[0] = wnr;
-			stamp(1);
-		}
-		lds_barrier();
-		stamp(4);
-		wnr = pub[0];
-		lenNR = wnr;
-		/* (ii) message r->u from children v, n against u's own message; EM on the u-r branch */
-		nv = 0;
-		{
-			unsigned long long bq = bop, bq2 = bop2;
-			asm volatile("" : "+v"(bq), "+v"(bq2));
-			double Mg[GS > 0 ? 16 : 1], Dg[GS > 0 ? 4 : 1];
-			if(GS > 0) {
-#pragma unroll
-				for(int e = 0; e < 16; ++e) Mg[e] = tabM[4 * HU_TP + e];
-#pragma unroll
-				for(int e = 0; e < 4; ++e) Dg[e] = tabD[4 * 4 + e];
-			}
-#pragma unroll
-			for(int t = 0; t < SPT; ++t) {
-				const unsigned bi = (unsigned)((t < 21 ? bq >> (3 * t) : bq2 >> (3 * (t - 21))) & 7u);
-				const double* M = (GS > 0 && t < GS) ? Mg : tabM + bi * HU_TP;
-				const double* D = (GS > 0 && t < GS) ? Dg : tabD + bi * 4;
-				const double v0 = v[t][0], v1 = v[t][1], v2 = v2s[t * THREADS + tid];
-				const double u0 = u[t][0], u1 = u[t][1], u2 = u2s[t * THREADS + tid];
-				double A = fma(M[3], u2, fma(M[2], u1, fma(M[1], u0, M[0])));
-				{ const double tm = fma(M[7], u2, fma(M[6], u1, fma(M[5], u0, M[4]))); A = fma(tm, v0, A); }
-				{ const double tm = fma(M[11], u2, fma(M[10], u1, fma(M[9], u0, M[8]))); A = fma(tm, v1, A); }
-				{ const double tm = fma(M[15], u2, fma(M[14], u1, fma(M[13], u0, M[12]))); A = fma(tm, v2, A); }
-				const double piX = fma(D[3], v2, fma(D[2], v1, fma(D[1], v0, D[0])));
-				const double r = fast_div(A, piX);
-				const bool inr = GS > 0 ? (t < GS ? tid + THREADS * t < nGap : tid + THREADS * (t - GS) < nBase) : tid + THREADS * t < n;
-				const bool ok = inr && fabs(r) < HU_RHO_SKIP;
-				rho[t] = ok ? r : HU_RHO_SKIP;
-				nv += __popcll(__ballot(ok));
-			}
-		}
-		stamp(2);
-		hand_over(nv, serveII);
-		if(serveII) {
-			double r2[2 * SPT];
-#pragma unroll
-			for(int t = 0; t < SPT; ++t) { r2[t] = rho[t]; r2[SPT + t] = rhoX[t * 64 + lane]; }
-			stamp(5);
-			wur = em_branch_wave<2 * SPT>(r2, (double) nv + pub[2], lenUR, w0j, emIters);
-			stamp(3);
-			exps(0, wur); exps(1, w0j - wur); tables_i();       /* for the next outer iteration, if there is one */
-			if(lane == 0) pub[1] = wur;
-			stamp(1);
-		}
-		lds_barrier();
-		stamp(4);
-		wur = pub[1];
-		lenUR = wur;
-		lenVR = w0j - wur;
-		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
-		wur0 = wur; wnr0 = wnr;
-	}
-	/* each wave counted the EM steps of the branch it served */
-	if(lane == 0) pub[2 + wave] = (double) emIters;
-	lds_barrier();
-	if(tid == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = (int)(pub[2] + pub[3]); out[ci] = o; }
-	if(DBG && lane == 0) {
-		tk[6] = (long long) __builtin_amdgcn_s_memtime() - t0; tk[7] = emIters;
-		for(int i = 0; i < 8; ++i) dbg[((size_t) blockIdx.x * 2 + wave) * 8 + i] = tk[i];
 	}
 }
 

@@ -48,80 +48,6 @@ __device__ inline uint32_t hu_pair_load(const void* pairs, size_t idx, int p16) 
 	return p16 ? HuPair<uint16_t>::canon(((const uint16_t*) pairs)[idx]) : ((const uint32_t*) pairs)[idx];
 }
 
-/* T reads x M node blocks per workgroup: a lane owns M nodes (node, node + 256, ...) and T reads, so every
- * scalar load of a read's planes (48 B) feeds 24 M vector operations.  With M = 1 the kernel sat at ~50 % of the
- * integer issue rate behind `s_load -> s_waitcnt lgkmcnt(0)` pairs: the scalar cache, shared by several
- * CUs, was the limiter.  Reads [t0, t0 + T) of the 16-read layout tile blockIdx.x / (16 / T). */
-template<int T, int M, bool NOCOUNT = false>
-__global__ __launch_bounds__(256) void k_seed_pdist(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ ins, uint32_t* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
-	constexpr int SPLIT = HU_READ_TILE / T;
-	const int tile = blockIdx.x / SPLIT, t0 = (blockIdx.x % SPLIT) * T;
-	const int node0 = blockIdx.y * (256 * M) + threadIdx.x;
-	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1); /* [0] = count, then the quads holding any base of the tile's reads */
-	const int nq = ql[0];
-	uint32_t d[M][T], N[M][T];
-#pragma unroll
-	for(int m = 0; m < M; ++m)
-#pragma unroll
-		for(int t = 0; t < T; ++t) { d[m][t] = 0; N[m][t] = 0; }
-	const size_t np = (size_t) db.nNodesPad;
-	for(int qi = 0; qi < nq; ++qi) {
-		const int q = ql[1 + qi];
-		uint4 n0[M], n1[M], nv[M];
-#pragma unroll
-		for(int m = 0; m < M; ++m) {
-			const int node = node0 + 256 * m < db.nNodesPad ? node0 + 256 * m : node0;
-			n0[m] = db.planes[((size_t) q * 3 + 0) * np + node];
-			n1[m] = db.planes[((size_t) q * 3 + 1) * np + node];
-			nv[m] = db.planes[((size_t) q * 3 + 2) * np + node];
-		}
-		const uint32_t* __restrict__ r = rp + (((size_t) tile * db.WQ + q) * HU_READ_TILE + t0) * 16;
-#pragma unroll
-		for(int t = 0; t < T; ++t) {
-			const uint32_t* rt = r + t * 16;
-#pragma unroll
-			for(int m = 0; m < M; ++m) {
-				uint32_t k, x;
-				k = nv[m].x & rt[8];  x = ((n0[m].x ^ rt[0]) | (n1[m].x ^ rt[4])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
-				k = nv[m].y & rt[9];  x = ((n0[m].y ^ rt[1]) | (n1[m].y ^ rt[5])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
-				k = nv[m].z & rt[10]; x = ((n0[m].z ^ rt[2]) | (n1[m].z ^ rt[6])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
-				k = nv[m].w & rt[11]; x = ((n0[m].w ^ rt[3]) | (n1[m].w ^ rt[7])) & k; d[m][t] += __popc(x); if(!NOCOUNT) N[m][t] += __popc(k);
-			}
-		}
-	}
-	/* the reads' bases in non-profile columns (alignment inserts): one node word per listed position */
-#pragma unroll
-	for(int t = 0; t < T; ++t) {
-		const int read = slotRead[tile * HU_READ_TILE + t0 + t];
-		if(read < 0) continue;
-		const int32_t* __restrict__ il = ins + (size_t) read * (HU_MAX_INS + 1);
-		const int cnt = il[0];
-		for(int e = 0; e < cnt; ++e) {
-			const int ent = il[1 + e], pos = ent >> 2, code = ent & 3;
-			const int q = pos >> 7, w = (pos >> 5) & 3, bit = pos & 31;
-#pragma unroll
-			for(int m = 0; m < M; ++m) {
-				const int node = node0 + 256 * m < db.nNodesPad ? node0 + 256 * m : node0;
-				const uint32_t* pw = reinterpret_cast<const uint32_t*>(db.planes + ((size_t) q * 3) * np + node) + w;
-				const uint32_t w0 = pw[0], w1 = pw[np * 4], wv = pw[np * 8];
-				const uint32_t valid = (wv >> bit) & 1u, nc = ((w0 >> bit) & 1u) | (((w1 >> bit) & 1u) << 1);
-				N[m][t] += valid; d[m][t] += valid & (nc != (uint32_t) code ? 1u : 0u);
-			}
-		}
-	}
-#pragma unroll
-	for(int m = 0; m < M; ++m) {
-		const int node = node0 + 256 * m;
-		if(node >= db.nNodesPad) continue;
-#pragma unroll
-		for(int t = 0; t < T; ++t) {
-			const int read = slotRead[tile * HU_READ_TILE + t0 + t];
-			if(read >= 0) pairs[(size_t) read * np + node] = (d[m][t] << 16) | N[m][t];
-		}
-	}
-}
-
 /* The scan with the inserts of a whole tile as ONE list (k_tile_lists): entries (read t << 24 | scan position << 2 |
  * base) read from the TRANSPOSED planes of the non-profile positions (HuDbDev::colPlanes: three wave-uniform
  * 8-byte words per insert instead of three 1-KB gathers that fetch a whole quad's lines for one bit per node) and added
@@ -245,53 +171,6 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
  * k_seed_dscan4 is the same with FOUR nodes per lane and the reads' planes broadcast from LDS into vector registers: every
  * operation then runs on vector registers alone (2 cycles) and a step costs 10 cycles instead of 16; the LDS serves 48 broadcast
  * reads of 16 B per wave and quad against 2,560 cycles of arithmetic. */
-template<class DT>
-__global__ __launch_bounds__(256, 8) void k_seed_dscan(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, DT* __restrict__ dm, const int32_t* __restrict__ slotRead, uint32_t* __restrict__ bminD, const uint2* __restrict__ tileSpan) {
-	constexpr int T = HU_READ_TILE;
-	constexpr uint32_t DMAX = (uint32_t)(DT) ~(DT) 0;
-	__shared__ __attribute__((aligned(16))) uint32_t acc[T][256];
-	const int tile = blockIdx.x, tid = threadIdx.x;
-	const int node = blockIdx.y * 256 + tid;
-	const int32_t* __restrict__ ql = tileQ + (size_t) tile * (db.WQ + 1);
-	const int nq = ql[0];
-	uint32_t d[T];
-#pragma unroll
-	for(int t = 0; t < T; ++t) d[t] = 0;
-	const size_t np = (size_t) db.nNodesPad;
-	for(int qi = 0; qi < nq; ++qi) {
-		const int q = ql[1 + qi];
-		const uint4 n0 = db.planes[((size_t) q * 3 + 0) * np + node], n1 = db.planes[((size_t) q * 3 + 1) * np + node], nv = db.planes[((size_t) q * 3 + 2) * np + node];
-		const uint32_t* __restrict__ r = rp + (((size_t) tile * db.WQ + q) * T) * 16;
-#pragma unroll
-		for(int t = 0; t < T; ++t) {
-			const uint32_t* rt = r + t * 16;
-#define HU_DSTEP(W, I) d[t] += __popc(__builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n0.W ^ rt[I], n1.W, rt[4 + I], 0xf6), nv.W, rt[8 + I], 0x80));
-			HU_DSTEP(x, 0) HU_DSTEP(y, 1) HU_DSTEP(z, 2) HU_DSTEP(w, 3)
-#undef HU_DSTEP
-		}
-	}
-	/* a node that shares no position with ANY read of the tile (N = 0 for all of them: d_scan = 0 without being near) stays out of the minima */
-	const uint32_t skip = node < db.nNodes && node != db.root && hu_cover_meets(db.nodeCover[node], tileSpan[tile]) ? 0u : 0xffffffffu;
-#pragma unroll
-	for(int t = 0; t < T; ++t) {
-		const int read = slotRead[tile * T + t];
-		const uint32_t v = min(d[t], DMAX);
-		if(read >= 0) dm[(size_t) read * np + node] = (DT) v;
-		acc[t][tid] = v | skip;                   /* own slot: nobody else has read or written it yet */
-	}
-	static_assert(T == 16, "sixteen lanes x sixteen values per read");
-	__syncthreads();
-	const int t = tid >> 4, sg = tid & 15;
-	const uint4* row = reinterpret_cast<const uint4*>(&acc[t][sg * 16]);
-	const uint4 a = row[0], b = row[1], c = row[2], e = row[3];
-	uint32_t m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
-	m = min(m, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(e.x, e.y), min(e.z, e.w))));
-	m = dpp_min_full<0xB1>(m); m = dpp_min_full<0x4E>(m); m = dpp_min_full<0x141>(m); m = dpp_min_full<0x140>(m);
-	const int read = slotRead[tile * T + t];
-	if(sg == 0 && read >= 0) bminD[(size_t) read * gridDim.y + blockIdx.y] = m;
-}
-
 /* Measured and not kept: two passes of eight reads per tile (32 counters per lane instead of 64: 128 VGPRs, four workgroups per CU, node planes
  * loaded twice): 2.52 ms against 2.20 — the second pass over the quads costs more than the fourth workgroup hides. */
 template<class DT>

@@ -1,7 +1,24 @@
-// Per-read adapters with the shape of the reference's free functions (src/HmmUFOtu_main.h:70-113)
-// over the batched C ABI: a batch of one.  POD mirrors replace HmmAlignment / PTLoc / PTPlacement
-// (node ids instead of shared_ptr<PTUNode>).  Header-only; link with -lhmmufotu_amd.
+// Per-read adapters with the shape of the reference's free functions (src/HmmUFOtu_main.h:70-113) and of the two PTUnrooted
+// members they call (src/PhyloTreeUnrooted.h:1128, 1158) over the batched C ABI: a batch of one.  POD mirrors replace
+// HmmAlignment / DigitalSeq / PTLoc / PTPlacement (node ids instead of shared_ptr<PTUNode>).  Header-only; link with -lhmmufotu_amd.
+//
+//   reference (src/HmmUFOtu_main.h)                                            here
+//   :71  alignSeq(hmm, csfm, read, seedLen, seedRegion, mode)                  Engine::alignSeq(read, seeds)   (after the CSFM lookup)
+//   :86  getSeed(ptu, seq, start, end, maxDiff, maxHeight) -> vector<PTLoc>    getSeed(eng, seq, start, end, maxDiff, maxHeight)
+//   :91  estimateSeq(ptu, seq, locs, method) -> vector<PTPlacement>            estimateSeq(eng, seq, locs, method)
+//   :100 filterPlacements(places, maxError)                                    filterPlacements(places, maxError)   (host: the same std::sort)
+//   :103 placeSeq(ptu, seq, places, maxHeight)                                 placeSeq(eng, seq, places, maxHeight)
+//   :107 calcQValues(places, type)                                             calcQValues(eng, places, type)
+//   PTUnrooted::estimateSeq(seq, loc, method) / placeSeq(seq, place, maxHeight)  Engine::estimateSeq / Engine::placeSeq
+//
+// Every stage takes and returns vectors like the reference's: the caller may truncate the seeds (src/hmmufotu.cpp:646-647), drop or
+// reorder placements between the stages, and sorts the final vector itself (src/hmmufotu.cpp:726, 730) with compareByLoglik /
+// compareByQPlace below.  Not the fast path (use hu_assign_batch for throughput): every call here is a batch of ONE read.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -17,25 +34,57 @@ struct HmmAlignment { /* src/BandedHMMP7.h:74-130 */
 	bool isValid() const { return status == HU_READ_OK; }
 };
 struct ViterbiAlignPath { int start, end, from, to, nIns, nDel; }; /* src/BandedHMMP7.h:229-248 */
+/* DigitalSeq(abc, name, str) (src/DigitalSeq.cpp:41-48) over IUPACNucl (src/IUPACNucl.cpp:33-50): upper-cased, characters outside the
+ * alphabet dropped, A C G T -> 0..3, degenerate codes -> their first expansion, gaps "-._" -> -2 */
+struct DigitalSeq {
+	std::vector<int8_t> codes;
+	DigitalSeq() {}
+	explicit DigitalSeq(const std::string& str) {
+		for(char ch : str) {
+			const char c = (char) ::toupper((unsigned char) ch);
+			int8_t b;
+			switch(c) {
+			case 'A': case 'M': case 'R': case 'W': case 'V': case 'H': case 'D': case 'N': b = 0; break;
+			case 'C': case 'S': case 'Y': case 'B': b = 1; break;
+			case 'G': case 'K': b = 2; break;
+			case 'T': case 'U': b = 3; break;
+			case '-': case '.': case '_': b = -2; break;
+			default: continue;
+			}
+			codes.push_back(b);
+		}
+	}
+	size_t length() const { return codes.size(); }
+};
 struct PTLoc { int start, end; long id; double dist; };             /* src/PhyloTreeUnrooted.h:390-405 */
+inline bool operator<(const PTLoc& l, const PTLoc& r) { return l.dist < r.dist; }   /* :1623-1625 */
 struct PTPlacement {                                                /* src/PhyloTreeUnrooted.h:410-510 */
 	int start = 0, end = 0; long cNode = -1, pNode = -1, aNode = -1;
 	double wuv = 0, ratio = 0, wnr = 0, loglik = 0, height = 0, qPlace = 0, qTaxon = 0;
+	double annoDist = 0;          /* getAnnoDist(): aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr */
+	double estLoglik = 0;         /* the loglik estimateSeq wrote (placeSeq overwrites loglik) */
+	long getTaxonId() const { return aNode; }
 };
+inline bool compareByLoglik(const PTPlacement& l, const PTPlacement& r) { return l.loglik < r.loglik; }   /* src/PhyloTreeUnrooted.h:1627-1629 */
+inline bool compareByQPlace(const PTPlacement& l, const PTPlacement& r) { return l.qPlace < r.qPlace; }   /* :1631-1633 */
+enum PRIOR_TYPE { UNIFORM = HU_PRIOR_UNIFORM, HEIGHT = HU_PRIOR_HEIGHT };
 
 inline void check(int rc) { if(rc != HU_OK) throw std::runtime_error(hu_last_error()); }
 
-/* One read at a time through one hu_batch: the same call order as the task body of
- * src/hmmufotu.cpp:621-733.  Not the fast path (use hu_assign_batch for throughput). */
-class PerRead {
+/* the loaded database + one batch of one read: stands where the reference passes `const PTUnrooted& ptu` (and `hmm`) */
+class Engine {
 public:
-	PerRead(hu_db* db, const hu_opts& o) : db_(db), opts_(o) {
+	Engine(hu_db* db, const hu_opts& o) : db_(db), opts_(o) {
 		check(hu_batch_create(db, 1, &b_));
 		check(hu_db_info(db, &K_, &L_, nullptr, nullptr, nullptr));
 	}
-	~PerRead() { hu_batch_destroy(b_); }
+	~Engine() { hu_batch_destroy(b_); }
+	Engine(const Engine&) = delete;
+	Engine& operator=(const Engine&) = delete;
+	int getCSLen() const { return L_; }
+	hu_opts& opts() { return opts_; }
 
-	/* alignSeq(hmm, csfm, read, seedLen, seedRegion, mode) after the CSFM lookup */
+	/* alignSeq(hmm, csfm, read, seedLen, seedRegion, mode) after the CSFM lookup (src/HmmUFOtu_main.cpp:86-104) */
 	HmmAlignment alignSeq(const std::string& read, const std::vector<ViterbiAlignPath>& seeds) {
 		int64_t offs[2] = {0, (int64_t) read.size()};
 		int32_t vp[12] = {0};
@@ -47,34 +96,150 @@ public:
 		HmmAlignment a;
 		a.K = K_; a.L = L_; a.seqStart = rec.seq_start; a.seqEnd = rec.seq_end; a.hmmStart = rec.hmm_start; a.hmmEnd = rec.hmm_end;
 		a.csStart = rec.cs_start; a.csEnd = rec.cs_end; a.cost = rec.cost; a.align = row; a.status = rec.status;
+		have_ = false;
 		return a;
 	}
-	/* getSeed(ptu, seq, start, end, maxDiff, maxHeight) + truncation to max_nseed */
-	std::vector<PTLoc> getSeed() {
-		check(hu_seed_batch(b_, &opts_));
-		int32_t n = 0, ids[64], d[64], N[64];
+
+	/* PTUnrooted::estimateSeq(seq, loc, method) (src/PhyloTreeUnrooted.h:1128, .cpp:849-877) */
+	PTPlacement estimateSeq(const DigitalSeq& seq, const PTLoc& loc, const std::string& method) {
+		std::vector<PTLoc> one(1, loc);
+		return estimateMany(seq, one, method)[0];
+	}
+	/* PTUnrooted::placeSeq(seq, place, maxHeight) const (src/PhyloTreeUnrooted.h:1158, .cpp:925-954) */
+	PTPlacement& placeSeq(const DigitalSeq& seq, PTPlacement& place, double maxHeight) {
+		std::vector<PTPlacement> one(1, place);
+		placeMany(seq, one, maxHeight);
+		place = one[0];
+		return place;
+	}
+
+	/* ---- the vector forms the free functions below forward to: ONE pass of the kernels over all seeds / candidates of the read */
+	std::vector<PTLoc> seedMany(const DigitalSeq& seq, int start, int end, double maxDiff, double maxHeight) {
+		load(seq, start, end);
+		hu_opts o = opts_; o.max_diff = maxDiff; o.max_height = maxHeight; o.max_nseed = HU_MAX_SEEDS;   /* the caller truncates (src/hmmufotu.cpp:646-647) */
+		check(hu_seed_batch(b_, &o));
+		int32_t n = 0, ids[HU_MAX_SEEDS], d[HU_MAX_SEEDS], N[HU_MAX_SEEDS];
 		check(hu_batch_get_seeds(b_, &n, ids, d, N));
-		hu_align_rec rec; check(hu_batch_get_alignments(b_, &rec, nullptr, nullptr, 0));
 		std::vector<PTLoc> locs;
-		for(int i = 0; i < n; ++i) locs.push_back(PTLoc{rec.cs_start - 1, rec.cs_end - 1, ids[i], (double) d[i] / N[i]});
+		for(int i = 0; i < n; ++i) locs.push_back(PTLoc{start, end, ids[i], (double) d[i] / N[i]});
 		return locs;
 	}
-	/* estimateSeq + filterPlacements + placeSeq + calcQValues; returns the best placement like
-	 * `bestPlace = places[0]` (src/hmmufotu.cpp:733) */
-	PTPlacement place() {
-		check(hu_estimate_batch(b_, &opts_));
-		check(hu_filter_batch(b_, &opts_));
-		check(hu_place_batch(b_, &opts_));
-		check(hu_finish_batch(b_, &opts_));
-		hu_place_rec r; check(hu_batch_get_placements(b_, &r));
-		hu_align_rec rec; check(hu_batch_get_alignments(b_, &rec, nullptr, nullptr, 0));
-		PTPlacement p;
-		p.start = rec.cs_start - 1; p.end = rec.cs_end - 1; p.cNode = r.c_node; p.pNode = r.p_node; p.aNode = r.a_node;
-		p.wuv = r.wuv; p.ratio = r.ratio; p.wnr = r.wnr; p.loglik = r.loglik; p.height = r.height; p.qPlace = r.q_place; p.qTaxon = r.q_taxon;
-		return p;
+	std::vector<PTPlacement> estimateMany(const DigitalSeq& seq, const std::vector<PTLoc>& locs, const std::string& method) {
+		if(method != "unweighted" && method != "weighted") throw std::invalid_argument("Unknown branch length estimating method '" + method + "'");   /* src/PhyloTreeUnrooted.cpp:1010-1016 */
+		std::vector<PTPlacement> places;
+		if(locs.empty()) return places;
+		if(locs.size() > HU_MAX_SEEDS) throw std::invalid_argument("estimateSeq: more than HU_MAX_SEEDS locations in one call");
+		for(const PTLoc& l : locs) if(l.start != locs[0].start || l.end != locs[0].end) throw std::invalid_argument("estimateSeq: the locations of one call share one region");
+		load(seq, locs[0].start, locs[0].end);
+		int32_t cnt = (int32_t) locs.size(), ids[HU_MAX_SEEDS];
+		for(size_t i = 0; i < locs.size(); ++i) ids[i] = (int32_t) locs[i].id;
+		check(hu_seed_batch_given(b_, &cnt, ids, nullptr, HU_MAX_SEEDS));
+		{ /* PTLoc::dist is what estimateSeq takes as cDist (src/PhyloTreeUnrooted.cpp:854-856); the device measures it itself over the region:
+		   * a location whose dist is NOT that distance (never the case for the output of getSeed) cannot be honoured */
+			int32_t n = 0, gi[HU_MAX_SEEDS], d[HU_MAX_SEEDS], N[HU_MAX_SEEDS];
+			check(hu_batch_get_seeds(b_, &n, gi, d, N));
+			for(int i = 0; i < n; ++i) {
+				const double dist = (double) d[i] / N[i];
+				if(!(dist == locs[i].dist || (std::isnan(dist) && std::isnan(locs[i].dist))))
+					throw std::invalid_argument("estimateSeq: PTLoc.dist is not the p-distance of the read to the node over [start, end]");
+			}
+		}
+		hu_opts o = opts_; o.weighted = method == "weighted";
+		check(hu_estimate_batch(b_, &o));
+		double ratio[HU_MAX_SEEDS], wnr[HU_MAX_SEEDS], ll[HU_MAX_SEEDS];
+		check(hu_batch_get_estimates(b_, ratio, wnr, ll));
+		std::vector<int32_t> par(nNodes()); std::vector<double> bl(nNodes());
+		tree(par, bl);
+		for(size_t i = 0; i < locs.size(); ++i) {
+			PTPlacement p;
+			p.start = locs[i].start; p.end = locs[i].end; p.cNode = locs[i].id; p.pNode = par[locs[i].id]; p.wuv = bl[locs[i].id];
+			p.ratio = ratio[i]; p.wnr = wnr[i]; p.loglik = p.estLoglik = ll[i];
+			p.aNode = p.ratio <= 0.5 ? p.cNode : p.pNode;                       /* src/PhyloTreeUnrooted.cpp:876 */
+			p.annoDist = p.aNode == p.cNode ? p.wuv * p.ratio + p.wnr : (1 - p.ratio) * p.wuv + p.wnr;
+			places.push_back(p);
+		}
+		return places;
 	}
+	std::vector<PTPlacement>& placeMany(const DigitalSeq& seq, std::vector<PTPlacement>& places, double maxHeight) {
+		if(places.empty()) return places;
+		load(seq, places[0].start, places[0].end);
+		give(places, 0);
+		hu_opts o = opts_; o.max_height = maxHeight;
+		check(hu_place_batch(b_, &o));
+		check(hu_finish_batch(b_, &o));                                          /* the per-candidate records (height, aNode, the F4 loglik) are assembled there */
+		take(places, false);
+		return places;
+	}
+	void qValues(std::vector<PTPlacement>& places, PRIOR_TYPE type) {
+		if(places.empty()) return;
+		if(!have_) throw std::logic_error("calcQValues: no read is loaded (call getSeed / estimateSeq / placeSeq on it first)");
+		give(places, 1);
+		hu_opts o = opts_; o.prior = (int32_t) type; o.only_ml = 0;
+		check(hu_finish_batch(b_, &o));
+		take(places, true);
+	}
+
 private:
+	int nNodes() { int32_t n = 0; check(hu_db_info(db_, nullptr, nullptr, &n, nullptr, nullptr)); return n; }
+	void tree(std::vector<int32_t>& par, std::vector<double>& bl) { check(hu_db_get_tree(db_, par.data(), bl.data(), nullptr, nullptr)); }
+	/* the aligned read as getSeed / estimateSeq / placeSeq receive it (src/hmmufotu.cpp:641-645): uploaded once per (seq, region) */
+	void load(const DigitalSeq& seq, int start, int end) {
+		if((int) seq.length() != L_) throw std::invalid_argument("DigitalSeq length differs from the consensus length");
+		if(have_ && start == start_ && end == end_ && seq.codes == codes_) return;
+		int32_t s = start, e = end;
+		check(hu_batch_set_aligned(b_, 1, seq.codes.data(), &s, &e));
+		codes_ = seq.codes; start_ = start; end_ = end; have_ = true;
+	}
+	void give(const std::vector<PTPlacement>& places, int placed) {
+		if(places.size() > HU_MAX_SEEDS) throw std::invalid_argument("more than HU_MAX_SEEDS placements in one call");
+		std::vector<hu_place_rec> recs(places.size());
+		for(size_t i = 0; i < places.size(); ++i) {
+			const PTPlacement& p = places[i]; hu_place_rec& r = recs[i];
+			memset(&r, 0, sizeof(r));
+			r.c_node = (int32_t) p.cNode; r.p_node = (int32_t) p.pNode; r.a_node = (int32_t) p.aNode; r.ratio = p.ratio; r.wnr = p.wnr;
+			r.est_loglik = p.estLoglik; r.loglik = p.loglik; r.height = p.height; r.wuv = p.wuv; r.root_loglik = std::numeric_limits<double>::quiet_NaN();
+		}
+		int64_t offs[2] = {0, (int64_t) places.size()};
+		check(hu_batch_set_candidates(b_, offs, recs.data(), placed));
+	}
+	void take(std::vector<PTPlacement>& places, bool qOnly) {
+		std::vector<hu_place_rec> recs(places.size());
+		check(hu_batch_get_candidate_places(b_, recs.data()));
+		for(size_t i = 0; i < places.size(); ++i) {
+			PTPlacement& p = places[i]; const hu_place_rec& r = recs[i];
+			if(!qOnly) { p.aNode = r.a_node; p.ratio = r.ratio; p.wnr = r.wnr; p.loglik = r.loglik; p.height = r.height; p.annoDist = r.anno_dist; }
+			p.qPlace = r.q_place; p.qTaxon = r.q_taxon;
+		}
+	}
 	hu_db* db_; hu_batch* b_ = nullptr; hu_opts opts_; int32_t K_ = 0, L_ = 0;
+	std::vector<int8_t> codes_; int start_ = 0, end_ = -1; bool have_ = false;
 };
+typedef Engine PerRead;   /* the name of rounds 1-2 */
+
+/* ---- the free functions of src/HmmUFOtu_main.h, `Engine&` standing for `const PTUnrooted&` ---- */
+/* :86 — every seed the engine holds for the read (<= HU_MAX_SEEDS, ascending by (dist, node id)); the caller truncates to maxNSeed */
+inline std::vector<PTLoc> getSeed(Engine& ptu, const DigitalSeq& seq, int start, int end, double maxDiff, double maxHeight) {
+	return ptu.seedMany(seq, start, end, maxDiff, maxHeight);
+}
+/* :91 */
+inline std::vector<PTPlacement> estimateSeq(Engine& ptu, const DigitalSeq& seq, const std::vector<PTLoc>& locs, const std::string& method) {
+	return ptu.estimateMany(seq, locs, method);
+}
+/* :100 — host: literally the reference's body (src/HmmUFOtu_main.cpp:162-173), the same std::sort call on the same sequence */
+inline std::vector<PTPlacement>& filterPlacements(std::vector<PTPlacement>& places, double maxError) {
+	if(places.empty() || !(maxError >= 0)) throw std::invalid_argument("filterPlacements: no placement, or a negative maxError");   /* the reference asserts */
+	std::sort(places.rbegin(), places.rend(), compareByLoglik);
+	const double bestEstLoglik = places[0].loglik;
+	std::vector<PTPlacement>::iterator goodPlace;
+	for(goodPlace = places.begin(); goodPlace != places.end(); ++goodPlace) if(bestEstLoglik - goodPlace->loglik > maxError) break;
+	places.erase(goodPlace, places.end());
+	return places;
+}
+/* :103 */
+inline std::vector<PTPlacement>& placeSeq(Engine& ptu, const DigitalSeq& seq, std::vector<PTPlacement>& places, double maxHeight) {
+	return ptu.placeMany(seq, places, maxHeight);
+}
+/* :107 — the reference's PTPlacement carries node pointers (taxon names, heights); here the database is named explicitly */
+inline void calcQValues(Engine& ptu, std::vector<PTPlacement>& places, PRIOR_TYPE type) { ptu.qValues(places, type); }
 
 } // namespace hmmufotu_amd

@@ -501,6 +501,13 @@ class Batch:
         _chk(load_library().hu_batch_get_candidate_places(self.h, out.ctypes.data_as(C.c_void_p)))
         return offs, out
 
+    def set_candidates(self, offs, recs, placed=False):
+        """hu_batch_set_candidates: the candidates of every read given by the caller (records of PLACE_DTYPE in the order the later stages
+        are to see them); placed: they carry placeSeq's results and calc_q_values may follow, else place_seq may follow"""
+        offs = np.ascontiguousarray(offs, np.int64); recs = np.ascontiguousarray(recs, PLACE_DTYPE)
+        assert len(offs) == self.n + 1 and offs[-1] == len(recs)
+        _chk(load_library().hu_batch_set_candidates(self.h, _p(offs, C.c_int64), recs.ctypes.data_as(C.c_void_p), C.c_int(int(placed))))
+
     def get_seed_given(self, n_seeds, ids, dist_ids=None):
         """Segment form of the seed stage: given node ids, distances over the current regions (src/hmmufotu.cpp:662-665)."""
         n_seeds = np.ascontiguousarray(n_seeds, np.int32); ids = np.ascontiguousarray(ids, np.int32)

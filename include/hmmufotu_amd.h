@@ -256,6 +256,14 @@ int hu_estimate_batch(hu_batch* b, const hu_opts* o);
 int hu_filter_batch(hu_batch* b, const hu_opts* o);
 /* placeSeq over the survivors (src/HmmUFOtu_main.cpp:175-180, src/PhyloTreeUnrooted.cpp:879-954) */
 int hu_place_batch(hu_batch* b, const hu_opts* o);
+/* The candidates of every read GIVEN by the caller instead of produced by hu_filter_batch — for callers that keep the reference's
+ * per-stage functions (estimateSeq -> filterPlacements -> placeSeq -> calcQValues on a vector<PTPlacement>, src/HmmUFOtu_main.h:91-107)
+ * and may drop, reorder or edit placements between the stages (hmmufotu_amd/csrc/hu_reference_api.hpp does).  offs [n + 1]; recs
+ * [offs[n]] in the order the later stages are to see them, at most HU_MAX_SEEDS per read, none for a read that is not HU_READ_OK.
+ * Read from a record: c_node (a non-root node), ratio, wnr, est_loglik; with placed != 0 also loglik, height, a_node — records as
+ * hu_batch_get_candidate_places returns them — and the batch then counts as placed (hu_finish_batch may follow); with placed == 0 it
+ * counts as filtered (hu_place_batch may follow).  The batch must be aligned (hu_align_batch or hu_batch_set_aligned). */
+int hu_batch_set_candidates(hu_batch* b, const int64_t* offs, const hu_place_rec* recs, int placed);
 /* calcQValues + final sort + bestPlace (src/HmmUFOtu_main.cpp:182-216, src/hmmufotu.cpp:725-733) */
 int hu_finish_batch(hu_batch* b, const hu_opts* o);
 /* the whole per-read task body for the batch (src/hmmufotu.cpp:621-733) */

@@ -36,6 +36,7 @@ def test_single_rank_line_has_the_contract_fields_and_zero_unexplained_differenc
     r = j["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = j["cpu_baseline"]
+    assert c["value"] is not None, c
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
     assert c["unexplained_best_branch_diffs"] == 0 and c["candidate_order"]["swaps_unexplained"] == 0 and c["candidate_order"]["candidate_set_differs"] == 0
     # numbers at the tolerance of the north star, iteration counts equal, and the tie-mode report is there
@@ -47,4 +48,5 @@ def test_single_rank_line_has_the_contract_fields_and_zero_unexplained_differenc
     assert t["reads"] == 96 and t["seed_set_diffs_all_exact_cutoff_ties"] and t["final_pick_differs"] == t["final_pick_diffs_traced_to_a_cutoff_tie"]
     assert r["bound"] == "valu_fp64_issue" and "hbm_roof" in r and "valu_roof" in r and len(r["kernel_source_hash"]) == 16
     e = j["end_to_end"]
+    assert "failed" not in e, e
     assert e["reads"] == 500 and e["value"] > 0 and e["placed"] > 400 and e["tsv_mb"] > 0.5
