@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--uniform-starts", action="store_true", help="read starts uniform over the resident window (SURVEY §8d second run)")
     ap.add_argument("--partial-frac", type=float, default=0.0, help="fraction of the leaves that lose a prefix or suffix (partial reference sequences)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 15 s worth)")
+    ap.add_argument("--seed-order", choices=["stable", "reference"], default="stable",
+                    help="hu_opts.seed_order: 'stable' = (dist, node id), selected on the device [default]; 'reference' = the first max_nseed of libstdc++'s "
+                         "std::sort on dist alone (HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, reproduced on the host)")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("HU_BENCH_E2E_READS", 1 << 20)),
                     help="distinct reads of the end-to-end block (host seed lookup + upload + engine + TSV formatting, measured after the timed region; 0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
@@ -249,7 +252,7 @@ def main():
                                win_start=db.win[0], win_len=db.win[1] if win else 0, device=local, msgs_on_device=True)
     log("database resident: %.1f GB in HBM, K=%d, nodes=%d, build %.0fs" % (D.hbm_bytes / 1e9, D.K, D.n_nodes, time.time() - t0))
     batches = []
-    opts = E.default_opts()
+    opts = E.default_opts(seed_order=1 if args.seed_order == "reference" else 0)
     for i in range(nb):
         B = E.Batch(D, args.batch)
         if args.paired:
@@ -410,7 +413,9 @@ def main():
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="%s synthetic DB (%d nodes x %d CS columns, K=%d), GTR%s, %s %s reads, "
                                     "batch %d reads/step/GPU, %d batches in flight" % ("SILVA-scale" if args.leaves >= 150000 else "gg_97_otus-scale" if args.leaves >= 90000 else "reduced-scale", D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
-                                                                                         shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb),
+                                                                                         shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb) +
+                                    (", seeds in the reference's std::sort order (host)" if args.seed_order == "reference" else ""),
+                           seed_order=args.seed_order,
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world,
                            hbm_in_use_gb=(total_b - free_b) / 1e9, hbm_total_gb=total_b / 1e9),
                timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
@@ -497,7 +502,7 @@ def main():
             reads, mates, mv = cpu["reads"], cpu["mates"], cpu["mv"]
             tc = time.perf_counter()
             r1 = O.pipeline_batch(cpu["H"], T_b, reads[:ns], all_vps[0][:ns], mates=mates[:ns] if mates else None, mvpaths=mv[:ns] if mates else None,
-                                  threads=cores, want_cands=True, mode=2, seeds=(p1["seed_cnt"], p1["seed_ids"]))
+                                  threads=cores, want_cands=True, mode=2, seeds=(p1["seed_cnt"], p1["lib_ids"] if args.seed_order == "reference" else p1["seed_ids"]))
             dB = time.perf_counter() - tc
             per = []
             for i in range(ns):
@@ -538,6 +543,7 @@ def main():
                                               "the messages (%.1f s), estimate / filter / place / q-values after the GPU run on the gathered rows of the seed nodes (%.1f s)" % (ns, cpu["dA"], dB),
                                        stage_cpu_sec=dict(zip(["align", "seed", "estimate", "place"],
                                                               [round(float(x), 2) for x in (p1["stage_sec"][0], p1["stage_sec"][1], r1["stage_sec"][2], r1["stage_sec"][3])])),
+                                       oracle_seed_order="TIE_LIBSTDCXX (literal std::sort)" if args.seed_order == "reference" else "TIE_STABLE (dist, node id)",
                                        best_branch_agreement_with_gpu=agree,
                                        best_branch_diffs=tot["best_differs"], unexplained_best_branch_diffs=tot["best_unexplained"],
                                        candidate_order=dict(swaps_explained_near_tie=tot["swaps_explained"], swaps_unexplained=tot["swaps_unexplained"],

@@ -49,7 +49,10 @@ static void usage(const char* p) {
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
 		"            --inflight INT [3] batches in flight per device  -v  --version  -h|--help\n"
-		"            -S|--seed INT and -p|--process INT are accepted and have no effect (seed hits are deterministic; host threads follow the batches in flight)\n";
+		"            --seed-order stable|reference  which of the nodes tying at the cut-off distance become seeds: (dist, node id) [stable, default],\n"
+		"                             or the reference binary's own choice — the first -N of libstdc++'s std::sort on dist alone (slower: sorted on the host)\n"
+		"            -S|--seed INT    a seed hit drawn from all its occurrences (CSFMIndex::locateOne) with this seed; without it the first occurrence\n"
+		"                             (locateFirst).  A run repeats at any thread count.  -p|--process INT is accepted and has no effect\n";
 }
 #define CHK(call) do { if((call) != HU_OK) { std::cerr << "Error: " << hu_last_error() << std::endl; return EXIT_FAILURE; } } while(0)
 
@@ -61,10 +64,18 @@ struct Packed { std::string bases; std::vector<int64_t> offs{0}; std::vector<int
  * worker thread drives batch k through the engine and writes its lines (output stays in read order) */
 struct Slot { Packed f, r; std::vector<std::string> ids, descs; };
 
+/* the seed scans of one packed batch: first occurrence, or (-S) a drawn one; stream 0 = forward reads, 1 = mates, 2 / 3 = the strand test */
+static int seed_lookup(const hu_seed_index* ix, Packed& p, int seedRegion, int mode, bool random, uint64_t seed, int stream, int64_t firstRead) {
+	p.vp.assign((size_t) p.n() * 12, 0);
+	if(!random) return hu_seed_index_lookup(ix, p.n(), p.bases.data(), p.offs.data(), seedRegion, mode, p.vp.data());
+	return hu_seed_index_lookup_random(ix, p.n(), p.bases.data(), p.offs.data(), seedRegion, mode, seed + 0x9e3779b97f4a7c15ull * (uint64_t) stream, firstRead, p.vp.data());
+}
+
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
 	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0;
-	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false, noCsfm = false;
+	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false, noCsfm = false, randomHits = false;
+	uint64_t hitSeed = 0; std::string seedOrder = "stable";
 	std::string alnFn;
 	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
 	hu_opts o; hu_default_opts(&o);
@@ -105,7 +116,9 @@ int main(int argc, char** argv) {
 		else if(a == "--gpus") nGpus = atoi(val());
 		else if(a == "--inflight") inflight = atoi(val());
 		else if(a == "-v") verbose++;
-		else if(a == "-S" || a == "--seed" || a == "-p" || a == "--process") (void) val(); /* accepted, no effect: lookups are deterministic */
+		else if(a == "-S" || a == "--seed") { hitSeed = (uint64_t) strtoull(val(), nullptr, 10); randomHits = true; }   /* src/hmmufotu.cpp:262-266 */
+		else if(a == "--seed-order") seedOrder = val();
+		else if(a == "-p" || a == "--process") (void) val(); /* accepted, no effect: host threads follow the batches in flight */
 		else if(a[0] == '-' && a.size() > 1) { std::cerr << "Error: unknown option " << a << std::endl; usage(argv[0]); return EXIT_FAILURE; }
 		else pos.push_back(a);
 	}
@@ -117,6 +130,8 @@ int main(int argc, char** argv) {
 	if(o.max_nseed < 1 || o.max_nseed > 64) { std::cerr << "-N must be in range [1, 64]" << std::endl; return EXIT_FAILURE; }
 	if(!(o.max_error >= 0)) { std::cerr << "-e|--err must be non-negative" << std::endl; return EXIT_FAILURE; }
 	if(method != "unweighted" && method != "weighted") { std::cerr << "-m|--method must be either 'unweighted' or 'weighted'" << std::endl; return EXIT_FAILURE; }
+	if(seedOrder != "stable" && seedOrder != "reference") { std::cerr << "--seed-order must be either 'stable' or 'reference'" << std::endl; return EXIT_FAILURE; }
+	o.seed_order = seedOrder == "reference" ? HU_SEED_ORDER_LIBSTDCXX : HU_SEED_ORDER_STABLE;
 	if(prior != "uniform" && prior != "height") { std::cerr << "--prior must be either 'uniform' or 'height'" << std::endl; return EXIT_FAILURE; }
 	/* the chimera options only count with -C (src/hmmufotu.cpp:248-260); checks of :325-340 */
 	if(!checkChimera) { chimeraInfo = false; chiOutFn.clear(); numSeg = 2; chimeraErr = NAN; chimeraLod = 0; }
@@ -175,9 +190,8 @@ int main(int argc, char** argv) {
 		double fwdScore = 0, revScore = 0;
 		std::vector<hu_align_rec> af(f.n()), ar(f.n());
 		if(f.n() > 0) {
-			f.vp.resize((size_t) f.n() * 12); r.vp.resize((size_t) f.n() * 12);
-			CHK(hu_seed_index_lookup(ix, f.n(), f.bases.data(), f.offs.data(), seedRegion, o.align_mode, f.vp.data()));
-			CHK(hu_seed_index_lookup(ix, r.n(), r.bases.data(), r.offs.data(), seedRegion, o.align_mode, r.vp.data()));
+			CHK(seed_lookup(ix, f, seedRegion, o.align_mode, randomHits, hitSeed, 2, 0));
+			CHK(seed_lookup(ix, r, seedRegion, o.align_mode, randomHits, hitSeed, 3, 0));
 			CHK(hu_batch_set_reads(gb, f.n(), f.bases.data(), f.offs.data(), f.vp.data(), nullptr, nullptr, nullptr));
 			CHK(hu_align_batch(gb, &o)); CHK(hu_batch_get_alignments(gb, af.data(), nullptr, nullptr, 0));
 			CHK(hu_batch_set_reads(gb, r.n(), r.bases.data(), r.offs.data(), r.vp.data(), nullptr, nullptr, nullptr));
@@ -296,9 +310,9 @@ int main(int argc, char** argv) {
 			P.cv.notify_all();
 			Slot& sl = *job.second; const int n = sl.f.n();
 			auto tS = std::chrono::steady_clock::now();
-			sl.f.vp.assign((size_t) n * 12, 0);
-			int rc = hu_seed_index_lookup(ix, n, sl.f.bases.data(), sl.f.offs.data(), seedRegion, o.align_mode, sl.f.vp.data());
-			if(rc == HU_OK && paired) { sl.r.vp.assign((size_t) n * 12, 0); rc = hu_seed_index_lookup(ix, n, sl.r.bases.data(), sl.r.offs.data(), seedRegion, o.align_mode, sl.r.vp.data()); }
+			(void) n;
+			int rc = seed_lookup(ix, sl.f, seedRegion, o.align_mode, randomHits, hitSeed, 0, (int64_t) job.first * batch);
+			if(rc == HU_OK && paired) rc = seed_lookup(ix, sl.r, seedRegion, o.align_mode, randomHits, hitSeed, 1, (int64_t) job.first * batch);
 			usSeed += usSince(tS);
 			if(rc != HU_OK) { P.fail(rc, hu_last_error()); continue; }
 			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || P.seeded.size() < depth; }); P.seeded.push_back(std::move(job)); }

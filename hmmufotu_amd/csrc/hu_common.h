@@ -115,6 +115,8 @@ void hu_set_error(const char* fmt, ...);
  * out-of-bounds access of a kernel ends the process from inside the HIP runtime): those are kept out by validating every index a
  * kernel forms from caller data before the launch. */
 int hu_catch_all(const char* fn) noexcept;
+/* the first k places of std::sort (libstdc++) on packed (key << 24 | index) elements compared on the key alone (hu_host.cpp) */
+void hu_sort_prefix_packed(uint64_t* a, size_t n, size_t k);
 
 /* model constants of the table-driven placement kernel (k_place_blk), one buffer of doubles per database */
 #define HU_PC_LAM 0              /* [4]      eigenvalues                                                      */

@@ -1272,6 +1272,77 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 __global__ void k_seed_drop_empty(int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int32_t* __restrict__ seedCnt);
 static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{b->dRp.p, b->dRq.p, b->dIns.p, b->dReadSlot.p, (const uint2*) b->dRSpan.p}; }
 
+/* HU_SEED_ORDER_LIBSTDCXX: getSeed's std::sort + the caller's truncation as the reference runs them (src/HmmUFOtu_main.cpp:139,
+ * src/hmmufotu.cpp:646-647), on the host, from the pair matrix the scan has just left on the device.  The rows come over in chunks through
+ * two page-locked buffers (the copy of one chunk runs under the host work on the previous one); per read the (d, N) of every eligible node
+ * become order-isomorphic integer keys in node order, and hu_sort_prefix_packed leaves in the first max_nseed places what libstdc++'s
+ * introsort would.  A read with a NaN distance (a node sharing no base with it: 0 / 0) takes the (dist, node id) order with NaN last —
+ * std::sort is undefined there and the oracle falls back the same way.  Seeds, their (d, N) and their parents' go back to the device. */
+static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
+	const hu_db* db = b->db;
+	const HuDbDev& d = db->dev;
+	const size_t n = (size_t) b->n, np = (size_t) d.nNodesPad, K = (size_t) o->max_nseed;
+	const size_t rowBytes = np * (b->pair16 ? 2 : 4);
+	const size_t CH = std::max<size_t>(1, std::min<size_t>(n, (192u << 20) / rowBytes));
+	b->hSeedCnt.assign(n, 0); b->hSeedId.assign(n * HU_MAX_SEEDS, 0); b->hSeedDN.assign(n * HU_MAX_SEEDS, 0);
+	PinnedVec<uint32_t> hPar(n * HU_MAX_SEEDS, 0);
+	PinnedVec<uint8_t> buf[2];
+	buf[0].resize(CH * rowBytes); buf[1].resize(CH * rowBytes);
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	HuScope guard([&] { for(int i = 0; i < 2; ++i) if(ev[i]) (void) hipEventDestroy(ev[i]); });
+	for(int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+	auto copy = [&](size_t c) -> int { /* chunk c into buffer c & 1 */
+		const size_t r0 = c * CH, cnt = std::min(CH, n - r0);
+		HIPCHK(hipMemcpyAsync(buf[c & 1].data(), (const uint8_t*) b->dPairs.p + r0 * rowBytes, cnt * rowBytes, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipEventRecord(ev[c & 1], b->stream));
+		return HU_OK;
+	};
+	const size_t nChunks = (n + CH - 1) / CH;
+	const double maxH = o->max_height;
+	const bool p16 = b->pair16;
+	int rc;
+	if(nChunks && (rc = copy(0)) != HU_OK) return rc;
+	for(size_t c = 0; c < nChunks; ++c) {
+		HIPCHK(hipEventSynchronize(ev[c & 1]));
+		if(c + 1 < nChunks && (rc = copy(c + 1)) != HU_OK) return rc;
+		const size_t r0 = c * CH, cnt = std::min(CH, n - r0);
+		const uint8_t* rows = buf[c & 1].data();
+		parallel_for(cnt, [&](size_t k) {
+			const size_t r = r0 + k;
+			if(b->hAlns[r].status != HU_READ_OK || b->hEnd[r] < b->hStart[r]) return;
+			static thread_local std::vector<uint64_t> a;
+			a.clear();
+			const uint16_t* q16 = (const uint16_t*)(rows + k * rowBytes); const uint32_t* q32 = (const uint32_t*)(rows + k * rowBytes);
+			auto pairOf = [&](int i) -> uint32_t { return p16 ? (((uint32_t)(q16[i] >> 8) << 16) | (q16[i] & 0xffu)) : q32[i]; };
+			bool nan = false;
+			for(int i = 0; i < d.nNodes; ++i) {
+				if(i == d.root || !(db->height[i] <= maxH)) continue;
+				const uint32_t pr = pairOf(i); const uint64_t dd = pr >> 16, N = pr & 0xffffu;
+				if(N == 0) { nan = true; a.push_back((((uint64_t) 1 << 39) + 1) << 24 | (uint64_t) i); continue; }    /* beyond every d / N <= 1 */
+				a.push_back(((dd << 39) / N) << 24 | (uint64_t) i);
+			}
+			const size_t keep = std::min(K, a.size());
+			if(!nan) hu_sort_prefix_packed(a.data(), a.size(), K);
+			else std::partial_sort(a.begin(), a.begin() + keep, a.end());        /* (dist, node id), NaN last */
+			b->hSeedCnt[r] = (int32_t) keep;
+			for(size_t s = 0; s < keep; ++s) {
+				const int id = (int)(a[s] & 0xffffffu);
+				b->hSeedId[r * HU_MAX_SEEDS + s] = id;
+				b->hSeedDN[r * HU_MAX_SEEDS + s] = pairOf(id);
+				hPar[r * HU_MAX_SEEDS + s] = pairOf(db->parent[id]);
+			}
+		});
+	}
+	if(n) {
+		HIPCHK(hipMemcpyAsync(b->dSeedCnt.p, b->hSeedCnt.data(), n * 4, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipMemcpyAsync(b->dSeedId.p, b->hSeedId.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipMemcpyAsync(b->dSeedDN.p, b->hSeedDN.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipMemcpyAsync(b->dParDN.p, hPar.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));      /* hPar is a local */
+	}
+	return HU_OK;
+}
+
 extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("hu_seed_batch: reads are not aligned"); return HU_ERR_STATE; }
@@ -1287,7 +1358,9 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 	 * more than 2 % of the reference sequences are partial (measured at gg_97 scale with 40 % of the leaves cut: 264 k reads/s on the
 	 * distance-only path, whose top-k then wades through thousands of barely overlapping candidates per read, 378 k on the pair matrix) */
 	const bool manyPartial = b->db->partialFrac > 0.02 && b->knob.scan_pairs != -1;
-	const bool dOnly = b->knob.scan_pairs != 1 && !manyPartial && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
+	if(o->seed_order != HU_SEED_ORDER_STABLE && o->seed_order != HU_SEED_ORDER_LIBSTDCXX) { hu_set_error("seed_order must be HU_SEED_ORDER_STABLE or HU_SEED_ORDER_LIBSTDCXX"); return HU_ERR_ARG; }
+	const bool refOrder = o->seed_order == HU_SEED_ORDER_LIBSTDCXX;      /* needs every node's (d, N): the pair matrix */
+	const bool dOnly = !refOrder && b->knob.scan_pairs != 1 && !manyPartial && o->max_height == INFINITY && nBlk >= 2 * o->max_nseed && nBlk <= 2048 && d.nNodes - 1 >= o->max_nseed;
 	const bool narrow = !b->knob.pairs32 && b->maxBases <= 255;      /* 8-bit distances / 16-bit pairs */
 	b->pair16 = !dOnly && narrow;
 	b->pairsKind = dOnly ? 0 : (b->pair16 ? 16 : 32);
@@ -1327,6 +1400,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 				else { k_seed_topk_straight<uint16_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t), b->knob.topk_general); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
 				#undef TOPK_ARGS
 			}
+			else if(refOrder) { if((rc = seed_order_libstdcxx(b, o)) != HU_OK) return rc; }
 			else {
 				if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
 				else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);

@@ -9,6 +9,7 @@
 #include <limits>
 #include <map>
 #include <sstream>
+#include <algorithm>
 #include <new>
 #include <stdexcept>
 #include "hu_common.h"
@@ -31,6 +32,88 @@ int hu_catch_all(const char* fn) noexcept {
 	catch(...) { hu_set_error("%s: unknown exception", fn); return HU_ERR_STATE; }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The first k places of std::sort, for HU_SEED_ORDER_LIBSTDCXX.
+ *
+ * The reference keeps the first maxNSeed elements of std::sort(locs.begin(), locs.end()) with operator< on dist alone
+ * (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647; operator< src/PhyloTreeUnrooted.h:1623-1625): which of the nodes tying at the
+ * cut-off distance are kept, and the order of equal distances inside the list, is the permutation libstdc++'s introsort leaves — a
+ * deterministic function of the sequence of comparison results, hence of the keys in node order.  Restated here from the published
+ * algorithm of libstdc++'s <bits/stl_algo.h> (std::__sort, GCC 4.9 - 13; the reference's distribution builds with the system's g++):
+ *   introsort loop on [first, last) while it holds more than 16 elements: depth limit 2 floor(lg n), decremented per partition — at 0 the
+ *   range is heap-sorted (make_heap + sort_heap); pivot = median of first + 1, first + (last - first) / 2, last - 1 swapped into *first;
+ *   unguarded Hoare partition of [first + 1, last) against *first (both scans stop on elements EQUAL to the pivot, which are swapped);
+ *   recursion into [cut, last), loop on [first, cut); then ONE insertion sort over everything (strict comparisons: stable on what the
+ *   partitions left).
+ * Only what can reach the first k places is executed: a range that starts at or beyond place k is never partitioned (its elements are
+ * >= everything left of it and the strict insertion sort cannot carry them across its start), so the cost is ~2n element visits
+ * instead of n lg n.  tests/test_seed_order.py checks it against the literal std::sort of the oracle on tie-heavy inputs of every size.
+ * Elements are (key << 24 | index) with key an order-isomorphic integer image of dist; comparisons look at the key alone. */
+namespace {
+struct PrefixSort {
+	uint64_t* a; size_t k;
+	static bool less(uint64_t x, uint64_t y) { return (x >> 24) < (y >> 24); }
+	void median_to_first(uint64_t* result, uint64_t* x, uint64_t* y, uint64_t* z) {
+		if(less(*x, *y)) { if(less(*y, *z)) std::swap(*result, *y); else if(less(*x, *z)) std::swap(*result, *z); else std::swap(*result, *x); }
+		else if(less(*x, *z)) std::swap(*result, *x);
+		else if(less(*y, *z)) std::swap(*result, *z);
+		else std::swap(*result, *y);
+	}
+	uint64_t* partition(uint64_t* first, uint64_t* last, const uint64_t* pivot) {
+		for(;;) {
+			while(less(*first, *pivot)) ++first;
+			--last;
+			while(less(*pivot, *last)) --last;
+			if(!(first < last)) return first;
+			std::swap(*first, *last);
+			++first;
+		}
+	}
+	void loop(uint64_t* first, uint64_t* last, long depth) {
+		while(last - first > 16) {
+			if(depth == 0) { std::make_heap(first, last, less); std::sort_heap(first, last, less); return; }    /* __partial_sort(first, last, last) */
+			--depth;
+			uint64_t* mid = first + (last - first) / 2;
+			median_to_first(first, first + 1, mid, last - 1);
+			uint64_t* cut = partition(first + 1, last, first);
+			if(cut < a + k) loop(cut, last, depth);       /* a range beyond the first k places cannot change them */
+			last = cut;
+		}
+	}
+	void run(size_t n) {
+		if(n == 0) return;
+		long lg = 0; for(size_t m = n; m > 1; m >>= 1) ++lg;
+		loop(a, a + n, 2 * lg);
+		/* __final_insertion_sort over the part whose blocks are final: everything up to the end of the block that holds place k - 1.
+		 * The first unpartitioned range starts at or beyond k; blocks of <= 16 elements lie before it.  Sorting a few elements more
+		 * than needed is harmless, fewer would not be: take [0, min(n, k + 16)) — a block reaching across k ends within 16 of it...
+		 * unless it is a heap-sorted or skipped range, whose elements an insertion sort leaves where they are relative to [0, k). */
+		const size_t e = std::min(n, k + 16);
+		for(size_t i = 1; i < e; ++i) {
+			const uint64_t v = a[i]; size_t j = i;
+			while(j > 0 && less(v, a[j - 1])) { a[j] = a[j - 1]; --j; }
+			a[j] = v;
+		}
+	}
+};
+}
+/* a [n] packed (key << 24 | index); on return a[0 .. min(k, n)) are the first places of std::sort on the keys */
+void hu_sort_prefix_packed(uint64_t* a, size_t n, size_t k) { PrefixSort s{a, k}; s.run(n); }
+
+extern "C" int hu_sort_prefix_libstdcxx(const double* dist, int64_t n, int64_t k, int32_t* out_idx) try {
+	if(n < 0 || k < 0 || (n > 0 && (!dist || !out_idx)) || n >= (1ll << 24)) { hu_set_error("hu_sort_prefix_libstdcxx: bad argument"); return HU_ERR_ARG; }
+	/* order-isomorphic integer keys: the rank of each distinct value (40 bits are plenty for < 2^24 elements) */
+	std::vector<double> vals(dist, dist + n);
+	for(int64_t i = 0; i < n; ++i) if(std::isnan(vals[i])) { hu_set_error("hu_sort_prefix_libstdcxx: NaN distance (std::sort is undefined on it)"); return HU_ERR_ARG; }
+	std::sort(vals.begin(), vals.end());
+	vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+	std::vector<uint64_t> a((size_t) n);
+	for(int64_t i = 0; i < n; ++i) a[i] = ((uint64_t)(std::lower_bound(vals.begin(), vals.end(), dist[i]) - vals.begin()) << 24) | (uint64_t) i;
+	hu_sort_prefix_packed(a.data(), (size_t) n, (size_t) k);
+	for(int64_t i = 0; i < std::min(n, k); ++i) out_idx[i] = (int32_t)(a[i] & 0xffffffu);
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_sort_prefix_libstdcxx"); }
+
 extern "C" void hu_default_opts(hu_opts* o) {
 	o->align_mode = HU_MODE_GLOBAL;
 	o->max_nseed = 50;
@@ -41,7 +124,7 @@ extern "C" void hu_default_opts(hu_opts* o) {
 	o->only_ml = 0;
 	o->prior = HU_PRIOR_UNIFORM;
 	o->fix_root_loglik = 0;
-	o->reserved0 = 0;
+	o->seed_order = HU_SEED_ORDER_STABLE;
 	o->ignore_orient = 0;
 }
 

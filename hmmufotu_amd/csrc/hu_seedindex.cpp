@@ -394,7 +394,10 @@ extern "C" int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positio
 
 /* locateFirst + buildAlignPath for the k-mer read[from0 .. from0+seedLen): returns 1 and fills out6 when
  * the k-mer occurs and yields a valid path, else 0 */
-static int lookup_one(const hu_seed_index* ix, const char* read, int from0, int32_t* out6) {
+/* rnd != 0: CSFMIndex::locateOne instead (src/CSFMIndex.cpp:121-147): a member of the seed's hit range drawn with the 64-bit number rnd
+ * (start + rnd % count, as the reference draws with rand()).  The reference takes rand() from one global stream that its tasks race on
+ * (SURVEY.md F7); here the number is a hash of (user seed, read number, seed position), so a run is reproducible at any thread count. */
+static int lookup_one(const hu_seed_index* ix, const char* read, int from0, int32_t* out6, uint64_t rnd = 0) {
 	const int k = ix->seedLen;
 	uint64_t key = 0;
 	for(int i = 0; i < k; ++i) { const int8_t c = sym_code(read[from0 + i]); if(c < 0) return 0; key |= (uint64_t) c << (62 - 2 * i); }
@@ -405,6 +408,11 @@ static int lookup_one(const hu_seed_index* ix, const char* read, int from0, int3
 		if(keep_top(window32(ix->text, ix->sa[mid]), k) < key) lo = mid + 1; else hi = mid;
 	}
 	if(lo >= ix->dir[b + 1] || keep_top(window32(ix->text, ix->sa[lo]), k) != key) return 0;
+	if(rnd) { /* the end of the hit range, then one of its members */
+		size_t l2 = lo, h2 = ix->dir[b + 1];
+		while(l2 < h2) { const size_t mid = (l2 + h2) >> 1; if(keep_top(window32(ix->text, ix->sa[mid]), k) <= key) l2 = mid + 1; else h2 = mid; }
+		lo += (size_t)(rnd % (uint64_t)(l2 - lo));
+	}
 	const uint16_t* cols = &ix->cols[ix->sa[lo]];
 	/* CSLoc: 1-based start/end, CS string with '-' wherever the hit sequence has no residue (extractCS); walked
 	 * exactly like buildAlignPath does (i over the read, j over CS columns) */
@@ -478,10 +486,22 @@ extern "C" int hu_seed_index_locate_first(const hu_seed_index* ix, const char* k
 } catch(...) { return hu_catch_all("hu_seed_index_locate_first"); }
 
 /* the two seed scans of alignSeq (src/HmmUFOtu_main.cpp:50-84) for n reads; vpaths [n][2][6] */
+static inline uint64_t hu_mix64(uint64_t x) { x += 0x9e3779b97f4a7c15ull; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31); }
+static int lookup_impl(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region, int align_mode, int32_t* vpaths,
+		bool random, uint64_t seed, int64_t firstRead);
 extern "C" int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
 		int align_mode, int32_t* vpaths) try {
+	return lookup_impl(ix, n, bases, offs, seed_region, align_mode, vpaths, false, 0, 0);
+} catch(...) { return hu_catch_all("hu_seed_index_lookup"); }
+extern "C" int hu_seed_index_lookup_random(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
+		int align_mode, uint64_t seed, int64_t first_read, int32_t* vpaths) try {
+	return lookup_impl(ix, n, bases, offs, seed_region, align_mode, vpaths, true, seed, first_read);
+} catch(...) { return hu_catch_all("hu_seed_index_lookup_random"); }
+static int lookup_impl(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region, int align_mode, int32_t* vpaths,
+		bool random, uint64_t seed, int64_t firstRead) {
 	if(!ix || n < 0 || (n && (!bases || !offs || !vpaths))) { hu_set_error("hu_seed_index_lookup: bad argument"); return HU_ERR_ARG; }
 	const int seedLen = ix->seedLen;
+	auto rnd = [&](int r, int pos) -> uint64_t { return random ? (hu_mix64(hu_mix64(seed ^ 0x5851f42d4c957f2dull) + (uint64_t)(firstRead + r) * 0x2545f4914f6cdd1dull + (uint64_t) pos) | (1ull << 63)) : 0; };
 	auto one = [&](int r) {
 		const char* read = bases + offs[r];
 		const int len = (int)(offs[r + 1] - offs[r]);
@@ -490,10 +510,10 @@ extern "C" int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* 
 		int k = 0;
 		const int regionLen = seed_region < len ? seed_region : len;
 		for(int seedFrom = 0; seedFrom + seedLen - 1 < regionLen; ++seedFrom)
-			if(lookup_one(ix, read, seedFrom, vp + 6 * k)) { ++k; break; }
+			if(lookup_one(ix, read, seedFrom, vp + 6 * k, rnd(r, seedFrom))) { ++k; break; }
 		if(align_mode == HU_MODE_GLOBAL && (k == 0 || len >= 2 * regionLen))
 			for(int seedTo = len - 1; seedTo - seedLen + 1 >= len - regionLen && seedTo - seedLen + 1 >= 0; --seedTo)
-				if(lookup_one(ix, read, seedTo - seedLen + 1, vp + 6 * k)) { ++k; break; }
+				if(lookup_one(ix, read, seedTo - seedLen + 1, vp + 6 * k, rnd(r, seedTo - seedLen + 1))) { ++k; break; }
 	};
 	unsigned nt = std::thread::hardware_concurrency();
 	if(nt > 16) nt = 16;
@@ -501,4 +521,4 @@ extern "C" int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* 
 	std::atomic<int> next{0};
 	hu_run_threads(nt, [&] { for(;;) { int a = next.fetch_add(256); if(a >= n) break; int e = std::min(n, a + 256); for(int r = a; r < e; ++r) one(r); } });
 	return HU_OK;
-} catch(...) { return hu_catch_all("hu_seed_index_lookup"); }
+}

@@ -46,7 +46,7 @@ class TreeDesc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("align_mode", C.c_int32), ("max_nseed", C.c_int32), ("max_diff", C.c_double), ("max_height", C.c_double),
                 ("max_error", C.c_double), ("weighted", C.c_int32), ("only_ml", C.c_int32), ("prior", C.c_int32),
-                ("ignore_orient", C.c_int32), ("fix_root_loglik", C.c_int32), ("reserved0", C.c_int32)]
+                ("ignore_orient", C.c_int32), ("fix_root_loglik", C.c_int32), ("seed_order", C.c_int32)]
 
 
 class AlignRec(C.Structure):
@@ -254,6 +254,17 @@ class SeedIndex:
         vp = np.zeros((n, 2, 6), np.int32)
         _chk(load_library().hu_seed_index_lookup(self.h, C.c_int(n), cat, _p(offs, C.c_int64), C.c_int(seed_region), C.c_int(align_mode),
                                                  _p(vp, C.c_int32)))
+        return vp
+
+    def lookup_random(self, reads, seed, first_read=0, seed_region=50, align_mode=0):
+        """CSFMIndex::locateOne's hit choice (hu_seed_index_lookup_random): a member of each seed's hit range drawn from a hash of
+        (seed, number of the read = first_read + index, seed position)"""
+        n = len(reads)
+        cat = "".join(reads).encode("latin1")
+        offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
+        vp = np.zeros((n, 2, 6), np.int32)
+        _chk(load_library().hu_seed_index_lookup_random(self.h, C.c_int(n), cat, _p(offs, C.c_int64), C.c_int(seed_region), C.c_int(align_mode),
+                                                        C.c_uint64(seed), C.c_int64(first_read), _p(vp, C.c_int32)))
         return vp
 
     def lookup_packed(self, cat, offs, seed_region=50, align_mode=0):

@@ -116,8 +116,14 @@ typedef struct {
 	                           * intended, sum_j log pi . exp(loglik(r, j)) at the optimised branch lengths; candidates are then
 	                           * ranked by it (q-values, --ML sort, chimera log-odds all become informative).  A documented
 	                           * deviation from the reference, off by default                                          */
-	int32_t reserved0;
+	int32_t seed_order;       /* which of the nodes that TIE at the cut-off distance getSeed keeps, and in which order the seeds reach estimateSeq:
+	                           * HU_SEED_ORDER_STABLE (0, default): ascending (dist, node id) — deterministic, selected on the device;
+	                           * HU_SEED_ORDER_LIBSTDCXX (1): the reference's own — the first max_nseed elements of std::sort(locs) on dist ALONE
+	                           * (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647), i.e. the tie permutation of libstdc++'s introsort over
+	                           * all ~n_nodes PTLocs in node order, reproduced on the host from the device's (d, N) of every node (a mode for
+	                           * exact agreement with the reference binary: several times slower than the default) */
 } hu_opts;
+enum { HU_SEED_ORDER_STABLE = 0, HU_SEED_ORDER_LIBSTDCXX = 1 };
 
 /* BandedHMMP7::HmmAlignment minus the string (src/BandedHMMP7.h:74-130) */
 typedef struct {
@@ -220,9 +226,21 @@ int64_t hu_seed_index_bytes(const hu_seed_index* ix, int64_t* positions /* index
 /* CSFMIndex::locateFirst + count for one seed of the index's length: 1-based CS columns of the first hit's first and last base */
 int hu_seed_index_locate_first(const hu_seed_index* ix, const char* kmer, int32_t* cs_start, int32_t* cs_end, int64_t* count);
 int64_t hu_seed_index_occurrences(const hu_seed_index* ix, const char* kmer, int32_t* seq_no, int32_t* offset, int32_t* cs_col, int64_t cap);
+/* Host only, no device: what std::sort (libstdc++: introsort — median-of-3 Hoare partitions down to 16 elements, heap sort past a depth of
+ * 2 lg n, one final insertion sort) leaves in the first k places of n PTLocs compared on dist alone, given in node order — the computation
+ * behind HU_SEED_ORDER_LIBSTDCXX, exposed for its parity test.  dist must hold no NaN (std::sort is undefined on them).  out_idx [min(k, n)]:
+ * indices into dist. */
+int hu_sort_prefix_libstdcxx(const double* dist, int64_t n, int64_t k, int32_t* out_idx);
 /* the 5' and (GLOBAL mode) 3' seed scans for n reads -> vpaths [n][2][6] for hu_batch_set_reads */
 int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
 		int align_mode, int32_t* vpaths);
+
+/* The same with CSFMIndex::locateOne's hit choice (src/CSFMIndex.cpp:121-147; `hmmufotu -S <seed>`): each seed takes a pseudo-random member
+ * of its hit range instead of the first.  The reference draws with rand() from ONE global stream, seeded by -S (default: the time) and
+ * raced on by its OpenMP tasks, so its own runs only repeat with -p 1; here the draw is a hash of (seed, number of the read
+ * in the input = first_read + its index, seed position): the same reads get the same hits whatever the batching or thread count. */
+int hu_seed_index_lookup_random(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
+		int align_mode, uint64_t seed, int64_t first_read, int32_t* vpaths);
 
 /* ---- batch ------------------------------------------------------------------------------ */
 int hu_batch_create(hu_db* db, int max_reads, hu_batch** out);

@@ -324,6 +324,33 @@ void orc_pipeline_batch(void* hmm, void* tr, int nReads, const char* reads, cons
 }
 
 
+/* literal std::sort of n PTLocs (id = index) on dist alone, first k ids: the checker of the product's restatement of libstdc++'s introsort
+ * (hu_sort_prefix_libstdcxx, HU_SEED_ORDER_LIBSTDCXX) */
+void orc_std_sort_prefix(const double* dist, long n, long k, int* outIdx) {
+	std::vector<PTLoc> locs((size_t) n);
+	for(long i = 0; i < n; ++i) { locs[i].start = locs[i].end = 0; locs[i].id = i; locs[i].dist = dist[i]; locs[i].d = locs[i].N = 0; }
+	std::sort(locs.begin(), locs.end());
+	for(long i = 0; i < k && i < n; ++i) outIdx[i] = (int) locs[i].id;
+}
+
+/* McIlroy's adversary ("A Killer Adversary for Quicksort", 1999) run against std::sort itself: values are decided while the sort compares
+ * them, so that every pivot turns out to be among the smallest of its range.  The values it ends with, given again as plain numbers, walk
+ * std::sort through the same comparisons: partitions of depth > 2 lg n, i.e. introsort's heap-sort branch — the input of the test of that
+ * branch in the product's restatement. */
+void orc_antiqsort(long n, double* out) {
+	std::vector<long> val((size_t) n); const long gas = n - 1; long nsolid = 0, candidate = 0;
+	for(long i = 0; i < n; ++i) val[i] = gas;
+	std::vector<long> ptr((size_t) n);
+	for(long i = 0; i < n; ++i) ptr[i] = i;
+	auto cmp = [&](long x, long y) {
+		if(val[x] == gas && val[y] == gas) { if(x == candidate) val[x] = nsolid++; else val[y] = nsolid++; }
+		if(val[x] == gas) candidate = x; else if(val[y] == gas) candidate = y;
+		return val[x] < val[y];
+	};
+	std::sort(ptr.begin(), ptr.end(), cmp);
+	for(long i = 0; i < n; ++i) out[i] = (double) val[i] / (double) n;
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }
 
 } // extern "C"

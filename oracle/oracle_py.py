@@ -313,5 +313,20 @@ def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, op
                 picks=picks, via_cutoff_seed=via_tie, phase1=p1), summ
 
 
+def std_sort_prefix(dist, k):
+    """first k indices of a literal std::sort of PTLocs on dist alone (orc_std_sort_prefix)"""
+    dist = np.ascontiguousarray(dist, np.float64); n = len(dist)
+    out = np.zeros(min(n, k), np.int32)
+    lib().orc_std_sort_prefix(_p(dist, C.c_double), C.c_long(n), C.c_long(k), _p(out, C.c_int))
+    return out
+
+
+def antiqsort(n):
+    """an input that drives std::sort into its heap-sort branch (orc_antiqsort)"""
+    out = np.zeros(n)
+    lib().orc_antiqsort(C.c_long(n), _p(out, C.c_double))
+    return out
+
+
 def max_threads():
     return lib().orc_max_threads()

@@ -710,6 +710,20 @@ def test_cli_end_to_end(tmp_path):
         outn = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--no-csfm"], capture_output=True, text=True, timeout=300)
         assert outn.returncode == 0 and "seed index built" in outn.stderr
         os.remove(pre + ".csfm")
+    # -S <seed>: seed hits drawn from all occurrences (CSFMIndex::locateOne) — reproducible, whatever the batching; same lines as the ABI
+    # driven from Python with the same draws
+    outs = [subprocess.run([cli, pre, fa, "-s", "1", "-S", "7", "--batch", bs], capture_output=True, text=True, timeout=300) for bs in ("16", "5")]
+    assert all(o_.returncode == 0 for o_ in outs), outs[0].stderr
+    ls = [[l for l in o_.stdout.split("\n") if l and not l.startswith("#")][1:] for o_ in outs]
+    B.set_reads(reads, ix.lookup_random(reads, 7, 0, 50, 0)); B.assign(E.default_opts())
+    assert ls[0] == ls[1] == B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
+    # --seed-order reference: the seeds under libstdc++'s std::sort on dist alone (hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX)
+    outr = subprocess.run([cli, pre, fa, "-s", "1", "--seed-order", "reference"], capture_output=True, text=True, timeout=300)
+    assert outr.returncode == 0, outr.stderr
+    B.set_reads(reads, ix.lookup(reads, 50, 0)); B.assign(E.default_opts(seed_order=1))
+    assert [l for l in outr.stdout.split("\n") if l and not l.startswith("#")][1:] == \
+        B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
+    assert subprocess.run([cli, pre, fa, "--seed-order", "x"], capture_output=True).returncode != 0
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
     import gzip
     fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")

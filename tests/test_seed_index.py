@@ -102,6 +102,48 @@ def test_lookup_builds_the_path_of_the_first_hit():
     assert found >= 20
 
 
+def test_random_hit_choice_is_a_member_of_the_hit_set_and_repeats():
+    """hmmufotu -S <seed> (CSFMIndex::locateOne, src/CSFMIndex.cpp:121-147): a seed takes one of its occurrences at random.  Every path
+    the seeded lookup returns must be the path of SOME occurrence of that seed; the draw depends on (seed, number of the read in the input,
+    seed position) only — the same reads in other batches get the same hits; another seed gives other hits; and the first-hit lookup is
+    one of the possibilities."""
+    from hmmufotu_amd import engine as E
+    db = get_db(120, 700, "GTR", dg_k=4)
+    _, H, _ = oracle_objects(db)
+    rows = _leaf_rows(db)
+    ix = E.SeedIndex(db.parent, db.seq, db.hmm, 20)
+    rng = np.random.default_rng(11)
+    seqs = []
+    for i in range(60):                                            # exact leaf substrings: seeds are found, many of them in several leaves
+        cols, s = rows[int(rng.integers(len(rows)))]
+        a = int(rng.integers(0, len(s) - 110)); seqs.append(s[a:a + 110])
+
+    def paths_of(read, sf):
+        out = set()
+        for h in _brute_hits(rows, read[sf:sf + 20]):
+            cols, s = rows[h[1]]
+            cc = cols[h[2]:h[2] + 20]
+            cs = ["-"] * (int(cc[-1]) - int(cc[0]) + 1)
+            for j, c in enumerate(cc):
+                cs[int(c) - int(cc[0])] = read[sf + j]
+            out.add(tuple(int(x) for x in H.build_align_path(int(cc[0]) + 1, int(cc[-1]) + 1, "".join(cs), sf + 1, sf + 20)))
+        return out
+    first = ix.lookup(seqs, 50, 0)
+    a = ix.lookup_random(seqs, 7, 0); b = ix.lookup_random(seqs, 7, 0); c = ix.lookup_random(seqs, 8, 0)
+    assert (a == b).all() and (a != c).any() and (a != first).any()
+    # batching does not matter: the second half alone, numbered from 30
+    assert (ix.lookup_random(seqs[30:], 7, 30) == a[30:]).all()
+    multi = 0
+    for r, read in enumerate(seqs):
+        v5 = tuple(int(x) for x in a[r, 0])
+        assert v5[0] > 0                                           # an exact leaf substring always has a 5' seed
+        sf = v5[2] - 1
+        ps = paths_of(read, sf)
+        assert v5 in ps and tuple(int(x) for x in first[r, 0]) in paths_of(read, int(first[r, 0, 2]) - 1)
+        multi += len(ps) > 1
+    assert multi > 10
+
+
 def test_bad_arguments():
     from hmmufotu_amd import engine as E
     db = get_db(120, 700, "GTR", dg_k=4)

@@ -1,0 +1,131 @@
+"""HU_SEED_ORDER_LIBSTDCXX (hu_opts.seed_order = 1): the seeds getSeed keeps under the reference's own order — the first max_nseed elements of
+std::sort(locs) on dist ALONE (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647), i.e. the tie permutation of libstdc++'s introsort.
+
+CPU part: the product's restatement of that algorithm restricted to the first k places (hu_sort_prefix_libstdcxx, hu_host.cpp) against the
+LITERAL std::sort of the oracle (orc_std_sort_prefix) on tie-heavy inputs of every size class.  GPU part: the engine in that mode against the
+oracle's TIE_LIBSTDCXX task on config 1, where the two orders give different final branches for 19 of 1,000 reads."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _prefix(dist, k):
+    from hmmufotu_amd import engine as E
+    lib = E.load_library()
+    dist = np.ascontiguousarray(dist, np.float64)
+    out = np.zeros(min(len(dist), k), np.int32)
+    rc = lib.hu_sort_prefix_libstdcxx(dist.ctypes.data_as(C.c_void_p), C.c_int64(len(dist)), C.c_int64(k), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return out
+
+
+def _cases():
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 50, 51, 64, 65, 100, 257, 1000, 4099, 30011):
+        yield "distinct-%d" % n, rng.permutation(n) / max(n, 1)
+        yield "two-values-%d" % n, rng.integers(0, 2, n) * 0.5
+        yield "ties-%d" % n, rng.integers(0, max(2, n // 7), n) / 251.0
+        yield "all-equal-%d" % n, np.full(n, 0.25)
+        yield "ascending-%d" % n, np.sort(rng.integers(0, max(2, n // 3), n) / 250.0)
+        yield "descending-%d" % n, np.sort(rng.integers(0, max(2, n // 3), n) / 250.0)[::-1]
+        a = np.arange(n) / 250.0
+        yield "organ-pipe-%d" % n, np.minimum(a, a[::-1])
+        # the shape of a real distance row: d / N with N = the read's bases for the inferred ancestors, a little less for leaves
+        N = np.where(rng.random(n) < 0.5, 250, 250 - rng.integers(0, 6, n)); d = np.minimum(N, rng.binomial(250, 0.08, n))
+        yield "d-over-N-%d" % n, d / N
+    # median-of-3 killer (Musser): drives the partitions towards the depth limit, past which the range is heap-sorted
+    for n in (2048, 20000):
+        k = n // 2; a = np.zeros(n)
+        for i in range(1, k + 1):
+            if i % 2:
+                a[i - 1] = i; a[i] = k + i
+            a[k + i - 1] = 2 * i
+        yield "musser-%d" % n, a / n
+    n = 200000
+    N = np.where(rng.random(n) < 0.5, 250, 250 - rng.integers(0, 6, n)); d = np.minimum(N, rng.binomial(250, 0.08, n))
+    yield "gg97-scale-row", d / N
+    yield "gg97-scale-few-values", rng.integers(0, 40, n) / 250.0
+
+
+def test_prefix_of_libstdcxx_sort_against_the_literal_std_sort():
+    from oracle import oracle_py as O
+    worst = 0
+    for name, dist in _cases():
+        for k in (1, 10, 50, 64, len(dist)):
+            if k > 64 and len(dist) > 5000:
+                continue
+            got = _prefix(dist, k); want = O.std_sort_prefix(dist, k)
+            assert np.array_equal(got, want), (name, k, got[:20], want[:20])
+        # and the orders really differ from a stable sort on such inputs (else the test would prove nothing)
+        st = np.argsort(dist, kind="stable")[:50]
+        worst += int(not np.array_equal(st, O.std_sort_prefix(dist, 50)))
+    assert worst > 20
+
+
+def test_heap_sort_branch_of_introsort():
+    """past a partition depth of 2 lg n introsort heap-sorts the range: reached with McIlroy's adversary run against std::sort itself"""
+    from oracle import oracle_py as O
+    for n in (40, 500, 5000, 60000):
+        dist = O.antiqsort(n)
+        assert len(np.unique(dist)) > n // 2
+        for k in (1, 17, 50, n):
+            assert np.array_equal(_prefix(dist, k), O.std_sort_prefix(dist, k)), (n, k)
+        # ties on top of it: the adversarial values quantised
+        q = np.floor(dist * 97) / 97
+        for k in (50, n):
+            assert np.array_equal(_prefix(q, k), O.std_sort_prefix(q, k)), (n, k, "quantised")
+
+
+def test_nan_is_refused():
+    from hmmufotu_amd import engine as E
+    lib = E.load_library()
+    d = np.array([0.1, np.nan, 0.2]); out = np.zeros(3, np.int32)
+    assert lib.hu_sort_prefix_libstdcxx(d.ctypes.data_as(C.c_void_p), C.c_int64(3), C.c_int64(3), out.ctypes.data_as(C.c_void_p)) == -1
+
+
+@pytest.mark.gpu
+def test_engine_in_reference_seed_order_on_config_1():
+    """all 1,000 reads of config 1 (the reference's 70_otus fixture) with hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX against the oracle's
+    task under TIE_LIBSTDCXX (literal std::sort): the seed lists are identical id by id, in order; candidates and final branches identical
+    or a documented near-tie; and the default order differs from it on this fixture (19 final branches), so the mode does something"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_cfg1_golden as G
+    from hmmufotu_amd import engine as E
+    from oracle import oracle_py as O, parity
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    db, reads, vps = G.cfg1_inputs()
+    D = E.Database.from_synth(db)
+    B = E.Batch(D, len(reads))
+    rd = [r.seq for r in reads]
+    B.set_reads(rd, vps)
+    B.assign(E.default_opts())
+    stable = B.placements().copy()
+    opts = E.default_opts(seed_order=1)
+    B.assign(opts)
+    cnt, ids, sd, sN = B.seeds(); best = B.placements(); cand = B.candidates()
+    m = O.Model(db.model.type_id, db.model.pi, db.model.par)
+    H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
+    T = O.Tree(db.parent, db.blen, db.seq, db.up, db.down, db.height, m, None, db.anno_id)
+    p1 = O.pipeline_batch(H, T, rd, vps, mode=1, want_lib=True)
+    assert (cnt == p1["seed_cnt"]).all()
+    for i in range(len(reads)):
+        assert (ids[i, :cnt[i]] == p1["lib_ids"][i, :cnt[i]]).all(), i                 # the reference's list, in the reference's order
+    res = O.pipeline_batch(H, T, rd, vps, want_cands=True, mode=2, seeds=(p1["seed_cnt"], p1["lib_ids"]))
+    per = []
+    for i in range(len(reads)):
+        k = int(res["n_cand"][i]); a, b = int(cand["offs"][i]), int(cand["offs"][i + 1])
+        per.append(parity.classify_read(res["cand_node"][i, :k], res["cand_est"][i, :k], res["cand_ratio0"][i, :k], cand["c_node"][a:b], db.parent,
+                                        pos=int(res["best_pos"][i])))
+    tot = parity.summarize(per)
+    assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
+    same = best["c_node"] == res["best_nodes"][:, 0]
+    assert same.sum() == len(reads) - tot["best_differs"]
+    assert (best["a_node"][same] == res["best_nodes"][same, 2]).all()
+    ndiff = int((stable["c_node"] != best["c_node"]).sum())
+    print("config 1: final branches that differ between the two seed orders:", ndiff, "| near-tie swaps:", tot)
+    assert ndiff == 19
+    # 70_otus leaves have gaps: some reads have nodes with N = 0 ... none on this fixture (tie report: reads_with_nan_dist == 0)
+    B.close(); D.close()
