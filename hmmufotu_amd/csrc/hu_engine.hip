@@ -1300,6 +1300,12 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
 	const size_t nChunks = (n + CH - 1) / CH;
 	const double maxH = o->max_height;
 	const bool p16 = b->pair16;
+	const uint64_t nanKey = ((uint64_t) 1 << 39) + 1;
+	static const std::vector<uint64_t> key16 = [] { /* [d << 8 | N] -> floor(d 2^39 / N); N = 0 -> beyond every distance */
+		std::vector<uint64_t> t(65536);
+		for(uint32_t v = 0; v < 65536; ++v) { const uint64_t dd = v >> 8, N = v & 0xffu; t[v] = N ? (dd << 39) / N : ((uint64_t) 1 << 39) + 1; }
+		return t;
+	}();
 	int rc;
 	if(nChunks && (rc = copy(0)) != HU_OK) return rc;
 	for(size_t c = 0; c < nChunks; ++c) {
@@ -1307,7 +1313,11 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
 		if(c + 1 < nChunks && (rc = copy(c + 1)) != HU_OK) return rc;
 		const size_t r0 = c * CH, cnt = std::min(CH, n - r0);
 		const uint8_t* rows = buf[c & 1].data();
-		parallel_for(cnt, [&](size_t k) {
+		/* ~0.5 ms of host work per read (2 x 10^5 keys, ~4 x 10^5 element visits of the partitions): spread over up to HU_SORT_THREADS (default 32)
+		 * threads per batch in flight — the per-batch pool of the <= 50-record stages (8 threads, and serial below 512 items) is too small for it */
+		static const unsigned sortThreads = [] { const char* e = getenv("HU_SORT_THREADS"); int v = e ? atoi(e) : 32; unsigned hw = std::thread::hardware_concurrency(); if(hw < 1) hw = 1; return (unsigned) std::min<int>(std::max(v, 1), (int) hw); }();
+		std::atomic<size_t> next{0};
+		auto oneRead = [&](size_t k) {
 			const size_t r = r0 + k;
 			if(b->hAlns[r].status != HU_READ_OK || b->hEnd[r] < b->hStart[r]) return;
 			static thread_local std::vector<uint64_t> a;
@@ -1317,8 +1327,14 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
 			bool nan = false;
 			for(int i = 0; i < d.nNodes; ++i) {
 				if(i == d.root || !(db->height[i] <= maxH)) continue;
-				const uint32_t pr = pairOf(i); const uint64_t dd = pr >> 16, N = pr & 0xffffu;
-				if(N == 0) { nan = true; a.push_back((((uint64_t) 1 << 39) + 1) << 24 | (uint64_t) i); continue; }    /* beyond every d / N <= 1 */
+				if(p16) { /* d, N <= 255: the key of every (d, N) from a table (a 64-bit division per node costs as much as the partitions) */
+					const uint64_t kk = key16[q16[i]];
+					nan |= kk == nanKey;
+					a.push_back(kk << 24 | (uint64_t) i);
+					continue;
+				}
+				const uint32_t pr = q32[i]; const uint64_t dd = pr >> 16, N = pr & 0xffffu;
+				if(N == 0) { nan = true; a.push_back(nanKey << 24 | (uint64_t) i); continue; }    /* beyond every d / N <= 1 */
 				a.push_back(((dd << 39) / N) << 24 | (uint64_t) i);
 			}
 			const size_t keep = std::min(K, a.size());
@@ -1331,7 +1347,8 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
 				b->hSeedDN[r * HU_MAX_SEEDS + s] = pairOf(id);
 				hPar[r * HU_MAX_SEEDS + s] = pairOf(db->parent[id]);
 			}
-		});
+		};
+		hu_run_threads(std::min<unsigned>(sortThreads, (unsigned) cnt), [&] { for(;;) { const size_t k = next.fetch_add(4); if(k >= cnt) break; for(size_t q = k; q < std::min(cnt, k + 4); ++q) oneRead(q); } });
 	}
 	if(n) {
 		HIPCHK(hipMemcpyAsync(b->dSeedCnt.p, b->hSeedCnt.data(), n * 4, hipMemcpyHostToDevice, b->stream));
