@@ -9,6 +9,7 @@
 #include <limits>
 #include <map>
 #include <sstream>
+#include <memory>
 #include <algorithm>
 #include <new>
 #include <stdexcept>
@@ -536,4 +537,39 @@ int hu_read_ptu_sink(const char* path, HuTreeHost& t, const std::function<int(bo
 		t.annoId[i] = it->second;
 	}
 	return HU_OK;
+}
+
+/* ---- hu_tree_info: the tree of a .ptu without its messages (include/hmmufotu_amd.h) ---- */
+struct hu_tree_info { HuTreeHost t; std::vector<std::vector<int32_t>> children; };
+extern "C" int hu_tree_info_load(const char* ptu_path, hu_tree_info** out) try {
+	if(!ptu_path || !out) { hu_set_error("hu_tree_info_load: null argument"); return HU_ERR_ARG; }
+	*out = nullptr;
+	std::unique_ptr<hu_tree_info> ti(new hu_tree_info);
+	std::vector<int32_t> order;           /* children in the order their parent -> child edges stand in the file */
+	const std::function<int(bool, int64_t, const double*)> sink = [&](bool isDown, int64_t node, const double*) -> int { if(isDown) order.push_back((int32_t) node); return HU_OK; };
+	int rc = hu_read_ptu_sink(ptu_path, ti->t, &sink);
+	if(rc != HU_OK) return rc;
+	ti->children.assign((size_t) ti->t.n, std::vector<int32_t>());
+	for(int32_t c : order) { const int32_t p = c >= 0 && c < ti->t.n ? ti->t.parent[c] : -1; if(p >= 0 && p < ti->t.n) ti->children[p].push_back(c); }
+	*out = ti.release();
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_tree_info_load"); }
+extern "C" void hu_tree_info_free(hu_tree_info* t) { delete t; }
+extern "C" int hu_tree_info_get(const hu_tree_info* t, int32_t* n_nodes, int32_t* cs_len, int32_t* root, hu_model_desc* model) {
+	if(!t) return HU_ERR_ARG;
+	if(n_nodes) *n_nodes = t->t.n; if(cs_len) *cs_len = t->t.csLen; if(root) *root = t->t.root; if(model) *model = t->t.model;
+	return HU_OK;
+}
+extern "C" int hu_tree_info_node(const hu_tree_info* t, int32_t i, int32_t* parent, double* blen, double* anno_dist, int32_t* is_leaf,
+		const char** name, const char** anno) {
+	if(!t || i < 0 || i >= t->t.n) return HU_ERR_ARG;
+	if(parent) *parent = t->t.parent[i]; if(blen) *blen = t->t.blen[i]; if(anno_dist) *anno_dist = t->t.annoDist[i];
+	if(is_leaf) *is_leaf = t->children[i].empty();
+	if(name) *name = t->t.names[i].c_str(); if(anno) *anno = t->t.annos[i].c_str();
+	return HU_OK;
+}
+extern "C" int hu_tree_info_children(const hu_tree_info* t, int32_t i, const int32_t** children) {
+	if(!t || i < 0 || i >= t->t.n) return 0;
+	if(children) *children = t->children[i].data();
+	return (int) t->children[i].size();
 }

@@ -199,6 +199,20 @@ int hu_tree_evaluate(int32_t n_nodes, int32_t cs_len, const int32_t* parent, con
 int hu_ptu_write(const char* path, const hu_tree_desc* tree, const char* const* names, const char* const* annos, const hu_model_desc* model,
 		const char* model_text, double dg_alpha, const double* dg_breaks);
 
+/* ---- the tree of a .ptu without its messages (host only, no device): what the consumers of an assignment file need of the database —
+ * hmmufotu-sum the nodes' taxon annotations (src/hmmufotu-sum.cpp:378-383), hmmufotu-jplace the topology, branch lengths and the order of
+ * every node's children as PTUnrooted::load leaves it (src/hmmufotu-jplace.cpp:197, src/PhyloTreeUnrooted.cpp:1135-1157).  The 4 x csLen
+ * doubles of every directed edge are read past, never kept. */
+typedef struct hu_tree_info hu_tree_info;
+int hu_tree_info_load(const char* ptu_path, hu_tree_info** out);
+void hu_tree_info_free(hu_tree_info* t);
+int hu_tree_info_get(const hu_tree_info* t, int32_t* n_nodes, int32_t* cs_len, int32_t* root, hu_model_desc* model);
+/* node i: parent (-1: root), length of the branch to it, annotation distance, leaf flag; the strings live as long as t */
+int hu_tree_info_node(const hu_tree_info* t, int32_t i, int32_t* parent, double* blen, double* anno_dist, int32_t* is_leaf,
+		const char** name, const char** anno);
+/* children of node i in the order of PTUNode::neighbors (the order their parent -> child edges stand in the file); returns the count */
+int hu_tree_info_children(const hu_tree_info* t, int32_t i, const int32_t** children);
+
 /* BandedHMMP7::buildAlignPath (src/BandedHMMP7.cpp:894-941): the CSLoc of a CSFM hit (1-based CS
  * start/end + the gapped CS string, src/CSLoc.h) and the seed's 1-based read range -> the
  * ViterbiAlignPath row {start,end,from,to,nIns,nDel} hu_batch_set_reads takes.  Host only. */
