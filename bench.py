@@ -426,6 +426,37 @@ def main():
                kernel_ms={k: round(v, 3) for k, v in acc.items()}, kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},
                host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
+    # ---- the same task with the seeds in the REFERENCE's own order (hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX: the first max_nseed of libstdc++'s
+    # std::sort on dist alone, reproduced on the device by k_seed_refsort) — measured here, after the timed region, on the same resident batches, because
+    # that order is what the reference binary's output follows wherever nodes tie at the cut-off distance (cpu_baseline.tie_mode counts how often)
+    best_ref = None
+    if rank == 0 and world == 1 and args.seed_order == "stable":
+        try:
+            opts_ref = E.default_opts(seed_order=1)
+            nbr = min(nb, 4); steps_ref = 4 * nbr
+            for i in range(nbr):
+                batches[i].assign(opts_ref)                     # setup: the mode's buffers (pair matrix, sort scratch) exist before the clock starts
+            def ref_steps(i):
+                for _ in range(steps_ref // nbr):
+                    batches[i].assign(opts_ref)
+                    batches[i].placements()
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            list(pool.map(ref_steps, range(nbr)))
+            torch.cuda.synchronize()
+            dtr = time.perf_counter() - tr0
+            best_ref = batches[0].placements().copy()
+            tms = batches[0].timings()
+            out["seed_order_reference"] = dict(value=args.batch * steps_ref / dtr, unit=out["unit"], ms_per_step=dtr / steps_ref * 1e3, steps=steps_ref, batches_in_flight=nbr,
+                                               seed_stage_ms=round(tms["seed_pdist"] + tms["seed_topk"], 2),
+                                               what="hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX: full (d, N) pair scan + k_seed_refsort (libstdc++'s introsort restricted to the first "
+                                                    "max_nseed places, as data-parallel Hoare partitions) instead of the distance-only scan + top-k; everything else as in the timed region")
+            log("reference seed order: %.0f %s (%.1f ms/step, %d batches in flight)" % (args.batch * steps_ref / dtr, out["unit"], dtr / steps_ref * 1e3, nbr))
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            out["seed_order_reference"] = dict(value=None, failed=repr(ex))
+
     # ---- end to end in this process: host seed lookup (hu_seed_index_lookup over the leaf rows' own index) -> read upload -> engine -> TSV lines,
     # over the pool of distinct reads drawn before the database was packed; one worker thread per batch object, chunks dealt in order of completion
     if e2e_pool is not None:
@@ -554,6 +585,10 @@ def main():
                                                     note="relative to max(|oracle|, 1e-3), every candidate of every sampled read matched by branch; est_loglik = estimateSeq's, "
                                                          "ratio / wnr / height = placeSeq's; iterations = outer loops of the joint optimisation and passes of the 2-node EM"),
                                        tie_mode=tsum)
+            if best_ref is not None:    # the engine in the reference's seed order against the oracle under the literal std::sort, read by read
+                want_c = np.where(tper["order_differs"][:ns], tper["picks"][:ns, 1, 0], r1["best_nodes"][:ns, 0])
+                out["seed_order_reference"]["final_branch_differs_from_oracle_std_sort"] = int((best_ref["c_node"][:ns] != want_c).sum())
+                out["seed_order_reference"]["reads_compared"] = int(ns)
         except Exception as ex:                             # the baseline must never sink the measurement
             import traceback
             traceback.print_exc()

@@ -23,6 +23,7 @@
 #include "hu_kern_align.h"
 #include "hu_kern_tree.h"
 #include "hu_kern_blk.h"
+#include "hu_kern_refsort.h"
 #include <hipcub/hipcub.hpp>
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
@@ -738,6 +739,7 @@ struct HuKnobs {
 	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
 	int scan_lds_pad = 0;        /* the same for the distance-only scan                                               */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
+	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
 	                              * host pool, 2 = std::length_error on the calling thread of the finish stage, 3 = std::runtime_error in a pool worker
 	                              * of the TSV formatter.  Never set by the product */
@@ -749,7 +751,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
-	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault},
+	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -796,6 +798,9 @@ struct hu_batch {
 	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin, dRSpan, dTileSpan;     /* dRSpan / dTileSpan: uint2 per read / tile */
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
+	DBuf<unsigned long long> dRefScratch;      /* k_seed_refsort: two arrays of 64-bit elements per resident workgroup */
+	DBuf<int32_t> dBail;
+	int nRefBail = 0;                            /* reads of the last seed stage that the device sort left to the host */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
 	DBuf<uint32_t> dSortK, dSortV;
 	DBuf<uint8_t> dSortTmp;
@@ -1278,10 +1283,141 @@ static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{
  * become order-isomorphic integer keys in node order, and hu_sort_prefix_packed leaves in the first max_nseed places what libstdc++'s
  * introsort would.  A read with a NaN distance (a node sharing no base with it: 0 / 0) takes the (dist, node id) order with NaN last —
  * std::sort is undefined there and the oracle falls back the same way.  Seeds, their (d, N) and their parents' go back to the device. */
-static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o) {
+extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt) try {
+	if(!pairs || rows < 1 || n < 1 || n >= (1 << 24) - 1 || k < 1 || k > HU_MAX_SEEDS || !out_idx || !out_cnt) { hu_set_error("hu_sort_prefix_device: bad argument"); return HU_ERR_ARG; }
+	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
+	HIPCHK(hipSetDevice(device));
+	/* a tree of n + 1 nodes whose LAST node is the root: position p of the sort is node p */
+	HuDbDev d; memset(&d, 0, sizeof(d));
+	d.nNodes = (int32_t) n + 1; d.nNodesPad = (d.nNodes + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD; d.root = (int32_t) n;
+	int idBits = 1; while((1 << idBits) < d.nNodes) ++idBits;
+	if((!pair16 && idBits > 19) || hu_refsort_lds(d.nNodes) > 150 * 1024) { hu_set_error("hu_sort_prefix_device: %lld elements are more than the kernel takes", (long long) n); return HU_ERR_ARG; }
+	const size_t np = (size_t) d.nNodesPad;
+	DBuf<int32_t> dPar, dSt, dEn, dCnt, dId, dBail; DBuf<uint32_t> dDN, dPN, dP32; DBuf<uint16_t> dP16; DBuf<unsigned long long> scr;
+	int rc;
+	if((rc = dPar.ensure(np)) != HU_OK || (rc = dSt.ensure(rows)) != HU_OK || (rc = dEn.ensure(rows)) != HU_OK || (rc = dCnt.ensure(rows)) != HU_OK ||
+			(rc = dId.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK || (rc = dDN.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK || (rc = dPN.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK ||
+			(rc = dBail.ensure((size_t) rows + 1)) != HU_OK) return rc;
+	HIPCHK(hipMemset(dPar.p, 0, np * 4)); HIPCHK(hipMemset(dSt.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dEn.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dBail.p, 0, 4));
+	d.parent = dPar.p;
+	std::vector<uint32_t> h32; std::vector<uint16_t> h16;
+	if(pair16) {
+		h16.assign((size_t) rows * np, 0x0001);
+		for(int r = 0; r < rows; ++r) for(int64_t i = 0; i < n; ++i) { const uint32_t v = pairs[(size_t) r * n + i]; h16[(size_t) r * np + i] = (uint16_t)(((v >> 16) << 8) | (v & 0xffu)); }
+		if((rc = dP16.ensure(h16.size())) != HU_OK) return rc;
+		HIPCHK(hipMemcpy(dP16.p, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+	}
+	else {
+		h32.assign((size_t) rows * np, 1);
+		for(int r = 0; r < rows; ++r) memcpy(&h32[(size_t) r * np], pairs + (size_t) r * n, (size_t) n * 4);
+		if((rc = dP32.ensure(h32.size())) != HU_OK) return rc;
+		HIPCHK(hipMemcpy(dP32.p, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
+	}
+	const size_t m0 = (size_t) n, rsOff = (m0 + 63) & ~(size_t) 63, cap = rsOff + m0 / 2 + 64, lds = hu_refsort_lds(d.nNodes);
+	const int G = std::min(rows, getenv("HU_RS_GRID") ? atoi(getenv("HU_RS_GRID")) : 256);
+	if((rc = scr.ensure((size_t) G * 2 * cap)) != HU_OK) return rc;
+	(void) hipGetLastError();
+	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+	HuScope evg([&] { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); });
+	HIPCHK(hipEventRecord(e0, nullptr));
+	if(pair16) {
+		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds>>>(d, dP16.p, rows, dSt.p, dEn.p, k, idBits, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+	}
+	else {
+		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds>>>(d, dP32.p, rows, dSt.p, dEn.p, k, idBits, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(e1, nullptr));
+	HIPCHK(hipDeviceSynchronize());
+	if(getenv("HU_RS_TIMING")) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d rows x %lld elements, grid %d: %.3f ms\n", rows, (long long) n, G, ms); }
+	std::vector<int32_t> cnt(rows), ids((size_t) rows * HU_MAX_SEEDS), hb((size_t) rows + 1);
+	HIPCHK(hipMemcpy(cnt.data(), dCnt.p, (size_t) rows * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(ids.data(), dId.p, ids.size() * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(hb.data(), dBail.p, hb.size() * 4, hipMemcpyDeviceToHost));
+	for(int r = 0; r < rows; ++r) { out_cnt[r] = cnt[r]; for(int s = 0; s < k; ++s) out_idx[(size_t) r * k + s] = s < cnt[r] ? ids[(size_t) r * HU_MAX_SEEDS + s] : -1; }
+	for(int i = 0; i < hb[0]; ++i) out_cnt[hb[1 + i]] = -1;
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_sort_prefix_device"); }
+
+static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector<int32_t>* only = nullptr);
+
+/* the same on the device (k_seed_refsort: data-parallel Hoare partitions, hu_kern_refsort.h); the reads it lists — a NaN distance, the
+ * heap-sort branch of introsort — are finished by the host function */
+static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
+	const HuDbDev& d = b->db->dev;
+	const int n = b->n;
+	int idBits = 1; while((1 << idBits) < d.nNodes) ++idBits;
+	if(b->knob.refsort_host || o->max_height != INFINITY || (!b->pair16 && idBits > 19) || idBits > 24 || d.nNodes < 3) return seed_order_libstdcxx(b, o);
+	const size_t m0 = (size_t) d.nNodes - 1;
+	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = rsOff + m0 / 2 + 64;
+	const size_t lds = hu_refsort_lds(d.nNodes);
+	if(lds > 150 * 1024) return seed_order_libstdcxx(b, o);
+	int G = std::min(n, 1024);
+	{ const size_t budget = (size_t) 5 << 30; const size_t perWg = 2 * cap * 8; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / perWg)); }
+	int rc;
+	if((rc = b->dRefScratch.ensure((size_t) G * 2 * cap)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 1)) != HU_OK) return rc;
+	HIPCHK(hipMemsetAsync(b->dBail.p, 0, 4, b->stream));
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	HuScope evg([&] { if(e0) (void) hipEventDestroy(e0); if(e1) (void) hipEventDestroy(e1); });
+	if(b->knob.trace) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, b->stream)); }
+	if(b->pair16) {
+		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed, idBits,
+				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+	}
+	else {
+		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed, idBits,
+				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+	}
+	HIPCHK(hipGetLastError());
+	if(e1) HIPCHK(hipEventRecord(e1, b->stream));
+	std::vector<int32_t> hb((size_t) n + 1);
+	HIPCHK(hipMemcpyAsync(hb.data(), b->dBail.p, ((size_t) n + 1) * 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	b->nRefBail = hb[0];
+	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", ms, hb[0]); }
+	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 1, hb.begin() + 1 + hb[0]); std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
+	return HU_OK;
+}
+
+static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector<int32_t>* only) {
 	const hu_db* db = b->db;
 	const HuDbDev& d = db->dev;
 	const size_t n = (size_t) b->n, np = (size_t) d.nNodesPad, K = (size_t) o->max_nseed;
+	if(only) { /* a few reads the device left over: their rows one by one */
+		const size_t rowB = np * (b->pair16 ? 2 : 4);
+		std::vector<uint8_t> rowBuf(rowB);
+		std::vector<uint64_t> a;
+		const bool p16 = b->pair16;
+		for(int32_t r : *only) {
+			HIPCHK(hipMemcpyAsync(rowBuf.data(), (const uint8_t*) b->dPairs.p + (size_t) r * rowB, rowB, hipMemcpyDeviceToHost, b->stream));
+			HIPCHK(hipStreamSynchronize(b->stream));
+			const uint16_t* q16 = (const uint16_t*) rowBuf.data(); const uint32_t* q32 = (const uint32_t*) rowBuf.data();
+			auto pairOf = [&](int i) -> uint32_t { return p16 ? (((uint32_t)(q16[i] >> 8) << 16) | (q16[i] & 0xffu)) : q32[i]; };
+			a.clear();
+			bool nan = false;
+			for(int i = 0; i < d.nNodes; ++i) {
+				if(i == d.root || !(db->height[i] <= o->max_height)) continue;
+				const uint32_t pr = pairOf(i); const uint64_t dd = pr >> 16, N = pr & 0xffffu;
+				if(N == 0) { nan = true; a.push_back((((uint64_t) 1 << 39) + 1) << 24 | (uint64_t) i); continue; }
+				a.push_back(((dd << 39) / N) << 24 | (uint64_t) i);
+			}
+			const size_t keep = std::min(K, a.size());
+			if(!nan) hu_sort_prefix_packed(a.data(), a.size(), K); else std::partial_sort(a.begin(), a.begin() + keep, a.end());
+			int32_t cnt = (b->hAlns[r].status == HU_READ_OK && b->hEnd[r] >= b->hStart[r]) ? (int32_t) keep : 0;
+			int32_t ids[HU_MAX_SEEDS]; uint32_t dn[HU_MAX_SEEDS], pn[HU_MAX_SEEDS];
+			for(size_t s = 0; s < keep; ++s) { const int id = (int)(a[s] & 0xffffffu); ids[s] = id; dn[s] = pairOf(id); pn[s] = pairOf(db->parent[id]); }
+			HIPCHK(hipMemcpyAsync(b->dSeedCnt.p + r, &cnt, 4, hipMemcpyHostToDevice, b->stream));
+			HIPCHK(hipMemcpyAsync(b->dSeedId.p + (size_t) r * HU_MAX_SEEDS, ids, keep * 4, hipMemcpyHostToDevice, b->stream));
+			HIPCHK(hipMemcpyAsync(b->dSeedDN.p + (size_t) r * HU_MAX_SEEDS, dn, keep * 4, hipMemcpyHostToDevice, b->stream));
+			HIPCHK(hipMemcpyAsync(b->dParDN.p + (size_t) r * HU_MAX_SEEDS, pn, keep * 4, hipMemcpyHostToDevice, b->stream));
+			HIPCHK(hipStreamSynchronize(b->stream));      /* the staging arrays are locals */
+		}
+		return HU_OK;
+	}
 	const size_t rowBytes = np * (b->pair16 ? 2 : 4);
 	const size_t CH = std::max<size_t>(1, std::min<size_t>(n, (192u << 20) / rowBytes));
 	b->hSeedCnt.assign(n, 0); b->hSeedId.assign(n * HU_MAX_SEEDS, 0); b->hSeedDN.assign(n * HU_MAX_SEEDS, 0);
@@ -1417,7 +1553,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 				else { k_seed_topk_straight<uint16_t><<<b->n, 256, 0, b->stream>>>(TOPK_ARGS(uint16_t), b->knob.topk_general); k_seed_topk_d<uint16_t, true><<<std::min(b->n, 1024), 256, 0, b->stream>>>(TOPK_ARGS(uint16_t)); }
 				#undef TOPK_ARGS
 			}
-			else if(refOrder) { if((rc = seed_order_libstdcxx(b, o)) != HU_OK) return rc; }
+			else if(refOrder) { if((rc = seed_order_libstdcxx_device(b, o)) != HU_OK) return rc; }
 			else {
 				if(b->pair16) k_seed_topk<uint16_t><<<b->n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);
 				else k_seed_topk<uint32_t><<<b->n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->knob.topk_fast_min);

@@ -1,0 +1,332 @@
+// HU_SEED_ORDER_LIBSTDCXX on the device: the first max_nseed places of std::sort(locs) — libstdc++'s introsort on dist ALONE over all
+// ~n_nodes PTLocs in node order (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647) — from the (d, N) pair row the scan left.
+// The algorithm restated (hu_host.cpp has the sequential restatement and the note on its source):
+//   introsort loop on [first, last) while it holds more than 16 elements: pivot = median of first + 1, mid, last - 1 swapped into *first;
+//   unguarded Hoare partition of [first + 1, last) against it; recursion into [cut, last), loop on [first, cut); depth limit 2 lg n;
+//   one final insertion sort.  Only ranges that reach into the first K places matter.
+//
+// One workgroup per read.  A Hoare partition is a deterministic pairing: with the LEFT STOPPERS (elements >= pivot) numbered from the
+// left, i_1 < i_2 < ..., and the RIGHT STOPPERS (elements <= pivot) numbered from the right, j_1 > j_2 > ..., the sequential scans swap
+// exactly the pairs (i_k, j_k) with i_k < j_k, k = 1 .. m, and return cut = min(i_(m+1), j_m) (the left scan of the last round stops at
+// the next original left stopper or at the swapped-in element at j_m, whichever comes first; cut = i_1 when nothing is swapped).  Ranks
+// are prefix counts, so a partition is two data-parallel passes: count the stoppers per 64-element subtile (ballots), scan the counts,
+// locate cut and m, copy the right stoppers j_1 .. j_m out by rank, and write the left part [first, cut) of the next level with the left
+// stoppers replaced by them.  Only the left part is written: the right part matters only when cut falls inside the first K places —
+// then the (tiny) left part is set aside and the right part is written instead.  Ranges of at most HU_RS_SMALL elements are finished
+// by one thread in LDS with the literal sequential algorithm.  Reads the device does not finish (a NaN distance, the heap-sort branch of
+// introsort, keys that do not fit) are listed for the host path.
+//
+// Elements are 64-bit words (key << idBits | node): key = the leading bits of the double d / N, order-isomorphic to dist for d <= N < 2^16
+// while idBits <= 19 (33 mantissa bits: two different fractions differ by more than 2^-32 relative) or N <= 255 (any idBits <= 24).
+#pragma once
+#include "hu_common.h"
+#include "hu_kern_sep.h"
+
+#define HU_RS_SMALL 512
+#define HU_RS_THREADS 512
+#define HU_RS_U 4                 /* elements per thread and loop trip of the streaming passes: their loads are in flight together */
+#define HU_RS_FIN (HU_RS_SMALL + 96)        /* LDS array of the sequential finisher: the set-aside prefix (< 64 places) + the last range */
+
+struct HuRsRange { int lo, hi, depth; };
+
+__device__ inline uint64_t rs_lane_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+__device__ inline uint64_t rs_lane_ge(int lane) { return ~0ull << lane; }
+
+/* element of position p of the level-0 array: node order without the root */
+template<class PT>
+__device__ __attribute__((noinline)) uint64_t rs_elem0(const PT* __restrict__ row, int root, int p, int idBits, bool& nan) {
+	const int node = p < root ? p : p + 1;
+	const uint32_t pr = HuPair<PT>::canon(row[node]);
+	const uint32_t d = pr >> 16, N = pr & 0xffffu;
+	if(N == 0) { nan = true; return (~0ull << idBits) | (uint64_t) node; }
+	const unsigned long long bits = (unsigned long long) __double_as_longlong((double) d / (double) N);
+	return ((bits >> idBits) << idBits) | (uint64_t) node;
+}
+
+/* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
+static inline size_t hu_refsort_lds(int nNodes) { const size_t NT = ((size_t) nNodes - 1 + 63) / 64; return (HU_RS_FIN + 64) * 8 + 2 * (NT + 2) * 4; }
+
+/* the literal sequential algorithm on an LDS array, for one thread: introsort loop restricted to ranges that start before place K */
+__device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* LDS [72] */, int first, int last, int depth, int K, int idBits) {
+	/* explicit stack of (first, last, depth): the recursion into [cut, last) happens only when cut < K */
+	int* sf = stk; int* sl = stk + 24; int* sd = stk + 48; int sp = 0;
+	sf[0] = first; sl[0] = last; sd[0] = depth; sp = 1;
+	while(sp > 0) {
+		--sp;
+		int f = sf[sp], l = sl[sp], dp = sd[sp];
+		while(l - f > 16) {
+			if(dp == 0) return false;          /* heap-sort branch: left to the host */
+			--dp;
+			const int mid = f + (l - f) / 2;
+			{ /* __move_median_to_first(f, f + 1, mid, l - 1) */
+				const uint64_t x = a[f + 1] >> idBits, y = a[mid] >> idBits, z = a[l - 1] >> idBits;
+				int w;
+				if(x < y) { if(y < z) w = mid; else if(x < z) w = l - 1; else w = f + 1; }
+				else if(x < z) w = f + 1;
+				else if(y < z) w = l - 1;
+				else w = mid;
+				const uint64_t t = a[f]; a[f] = a[w]; a[w] = t;
+			}
+			const uint64_t pk = a[f] >> idBits;
+			int i = f + 1, j = l;
+			for(;;) {
+				while((a[i] >> idBits) < pk) ++i;
+				--j;
+				while(pk < (a[j] >> idBits)) --j;
+				if(!(i < j)) break;
+				const uint64_t t = a[i]; a[i] = a[j]; a[j] = t;
+				++i;
+			}
+			if(i < K) { if(sp >= 24) return false; sf[sp] = i; sl[sp] = l; sd[sp] = dp; ++sp; }
+			l = i;
+		}
+	}
+	return true;
+}
+
+template<class PT>
+__global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K, int idBits,
+		unsigned long long* __restrict__ scratch, size_t cap, int rsOff,
+		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
+		int32_t* __restrict__ bail) {
+	extern __shared__ unsigned char rs_smem[];
+	const int m0 = db.nNodes - 1;
+	const int NT = (m0 + 63) >> 6;
+	uint64_t* fin = reinterpret_cast<uint64_t*>(rs_smem);                  /* [HU_RS_FIN]: the sequential finisher's array, by absolute position */
+	uint64_t* lsb = fin + HU_RS_FIN;                                       /* [64]: left stoppers of a tiny left part */
+	uint32_t* preL = reinterpret_cast<uint32_t*>(lsb + 64);                /* [NT + 2] */
+	uint32_t* sufR = preL + (NT + 2);                                      /* [NT + 2] */
+	__shared__ uint32_t part[HU_RS_THREADS];
+	__shared__ uint64_t shE[4];              /* pivot element, patch values */
+	__shared__ int shI[12];                  /* broadcast slots */
+	__shared__ HuRsRange stash[12];
+	__shared__ int seqStack[72];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for(int read = blockIdx.x; read < nReads; read += gridDim.x) {
+		__syncthreads();
+		if(rend[read] < rstart[read] || m0 < 1) { if(tid == 0) seedCnt[read] = 0; continue; }
+		const PT* __restrict__ row = pairs + (size_t) read * db.nNodesPad;
+		unsigned long long* bufA = scratch + (size_t) blockIdx.x * 2 * cap;
+		unsigned long long* bufB = bufA + cap;
+		const unsigned long long* src = nullptr;        /* nullptr: the implicit level-0 array */
+		unsigned long long* dst = bufA;
+		int lo = 0, hi = m0, depth = 0, nStash = 0;
+		for(int x = m0; x > 1; x >>= 1) ++depth;
+		depth *= 2;
+		int pA = -1, pB = -1; uint64_t vA = 0, vB = 0;   /* level 0: the one swap of the pivot selection, kept as two patches */
+		bool failed = false, nan = false;
+		auto E = [&](int p) -> uint64_t {
+			if(src) return src[p];
+			if(p == pA) return vA;
+			if(p == pB) return vB;
+			return rs_elem0(row, db.root, p, idBits, nan);
+		};
+		while(hi - lo > HU_RS_SMALL) {
+			if(depth == 0) { failed = true; break; }
+			--depth;
+			/* ---- pivot: median of lo + 1, mid, hi - 1 swapped into lo */
+			if(tid == 0) {
+				const int mid = lo + (hi - lo) / 2;
+				const uint64_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
+				const uint64_t x = ea >> idBits, y = eb >> idBits, z = ec >> idBits;
+				int w; uint64_t ew;
+				if(x < y) { if(y < z) { w = mid; ew = eb; } else if(x < z) { w = hi - 1; ew = ec; } else { w = lo + 1; ew = ea; } }
+				else if(x < z) { w = lo + 1; ew = ea; }
+				else if(y < z) { w = hi - 1; ew = ec; }
+				else { w = mid; ew = eb; }
+				shE[0] = ew; shE[1] = ef; shI[0] = w;
+				if(src) { const_cast<unsigned long long*>(src)[lo] = ew; const_cast<unsigned long long*>(src)[w] = ef; }
+			}
+			__threadfence_block();
+			__syncthreads();
+			const uint64_t pivE = shE[0];
+			if(!src) { pA = lo; vA = pivE; pB = shI[0]; vB = shE[1]; }
+			const uint64_t pk = pivE >> idBits;
+			const int M = hi - lo - 1, NTl = (M + 63) >> 6;
+			/* ---- pass A: stoppers per subtile of 64 positions q = p - (lo + 1) */
+			for(int base = 0; base < M; base += HU_RS_THREADS * HU_RS_U) {
+				uint64_t ev[HU_RS_U];
+#pragma unroll
+				for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < M ? E(lo + 1 + q) : 0; }
+#pragma unroll
+				for(int u = 0; u < HU_RS_U; ++u) {
+					const int qb = base + u * HU_RS_THREADS, q = qb + tid;
+					const bool valid = q < M;
+					const uint64_t k = ev[u] >> idBits;
+					const unsigned long long mL = __ballot(valid && !(k < pk)), mR = __ballot(valid && !(pk < k));
+					if(lane == 0 && qb + wave * 64 < M) { preL[(qb >> 6) + wave] = (uint32_t) __popcll(mL); sufR[(qb >> 6) + wave] = (uint32_t) __popcll(mR); }
+				}
+			}
+			if(__syncthreads_or(nan ? 1 : 0)) { failed = true; break; }
+			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
+			{
+				const int per = (NTl + HU_RS_THREADS - 1) / HU_RS_THREADS, a0 = tid * per, a1 = min(NTl, a0 + per);
+				uint32_t sL = 0, sR = 0;
+				for(int t = a0; t < a1; ++t) { sL += preL[t]; sR += sufR[t]; }
+				part[tid] = sL;
+				__syncthreads();
+				if(tid == 0) { uint32_t acc = 0; for(int i = 0; i < HU_RS_THREADS; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } shI[1] = (int) acc; }
+				__syncthreads();
+				uint32_t accL = part[tid];
+				__syncthreads();
+				part[tid] = sR;
+				__syncthreads();
+				if(tid == 0) { uint32_t acc = 0; for(int i = HU_RS_THREADS - 1; i >= 0; --i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } }
+				__syncthreads();
+				uint32_t accR = part[tid];     /* right stoppers in the chunks after this thread's */
+				for(int t = a0; t < a1; ++t) { const uint32_t v = preL[t]; preL[t] = accL; accL += v; }
+				for(int t = a1 - 1; t >= a0; --t) { accR += sufR[t]; sufR[t] = accR; }
+				if(tid == 0) { preL[NTl] = (uint32_t) shI[1]; sufR[NTl] = 0; }
+				__syncthreads();
+			}
+			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
+			 * the swapped pairs are the left stoppers with g < 0; c0 = the first position with g >= 0 */
+			if(wave == 0) {
+				/* first subtile t0 with preL[t0 + 1] >= sufR[t0 + 1] (positions of earlier subtiles all have g < 0) */
+				int t0;
+				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
+				auto masks = [&](int t, unsigned long long& mL, unsigned long long& mR) {
+					const int q = t * 64 + lane; const bool valid = q < M;
+					const uint64_t k = valid ? (E(lo + 1 + q) >> idBits) : 0;
+					mL = __ballot(valid && !(k < pk)); mR = __ballot(valid && !(pk < k));
+				};
+				unsigned long long mL, mR;
+				masks(t0, mL, mR);
+				int c0;
+				{
+					const int Lq = (int) preL[t0] + __popcll(mL & rs_lane_lt(lane));
+					const int Rq = (int) sufR[t0 + 1] + __popcll(mR & rs_lane_ge(lane) & ~(1ull << lane));
+					const unsigned long long ok = __ballot(t0 * 64 + lane < M && Lq - Rq >= 0);
+					c0 = ok ? t0 * 64 + (__ffsll((long long) ok) - 1) : (t0 + 1) * 64;
+				}
+				int tc = c0 >> 6, m, iNext = -1;                     /* iNext: i_(m+1), the first left stopper at or after c0 (-1: none) */
+				if(tc < NTl) {
+					if(tc != t0) masks(tc, mL, mR);
+					m = (int) preL[tc] + __popcll(mL & rs_lane_lt(c0 & 63));
+					unsigned long long cand = mL & rs_lane_ge(c0 & 63);
+					int t = tc;
+					while(!cand && ++t < NTl) { if(preL[t + 1] > preL[t]) { unsigned long long x, y; masks(t, x, y); cand = x; } }
+					if(cand) iNext = t * 64 + (__ffsll((long long) cand) - 1);
+				}
+				else m = (int) preL[NTl];
+				int jm = -1;                                         /* j_m: the m-th right stopper from the right */
+				if(m >= 1) {
+					int a = 0, b = NTl - 1;                           /* last subtile t with sufR[t] >= m */
+					while(a < b) { const int md = (a + b + 1) >> 1; if((int) sufR[md] >= m) a = md; else b = md - 1; }
+					unsigned long long x, y; masks(a, x, y);
+					const int want = m - (int) sufR[a + 1];
+					const unsigned long long hit = __ballot(((y >> lane) & 1ull) && __popcll(y & rs_lane_ge(lane)) == want);
+					jm = a * 64 + (__ffsll((long long) hit) - 1);
+				}
+				const int cutq = (m >= 1 && (iNext < 0 || iNext > jm)) ? jm : iNext;
+				if(lane == 0) { shI[2] = cutq; shI[3] = m; shI[4] = jm; }
+			}
+			__syncthreads();
+			const int cutq = shI[2], m = shI[3], jm = shI[4];
+			if(cutq < 0) { failed = true; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
+			const int cutAbs = lo + 1 + cutq;
+			unsigned long long* RS = dst + rsOff;                    /* right stoppers by rank, beyond the positions */
+			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
+			if(m >= 1) {
+				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_THREADS * HU_RS_U) {
+					uint64_t ev[HU_RS_U];
+#pragma unroll
+					for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < M ? E(lo + 1 + q) : 0; }
+#pragma unroll
+					for(int u = 0; u < HU_RS_U; ++u) {
+						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
+						const bool rs = q < M && !(pk < (ev[u] >> idBits));
+						const unsigned long long mR = __ballot(rs);
+						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) RS[rk - 1] = ev[u]; }
+					}
+				}
+			}
+			__threadfence_block();
+			__syncthreads();
+			const bool tiny = cutAbs < K;        /* the left part ends inside the first K places: the right part is needed too */
+			if(!tiny) {
+				/* ---- pass B2: the left part [lo, cut) of the next level */
+				if(tid == 0) dst[lo] = pivE;
+				for(int base = 0; base < cutq; base += HU_RS_THREADS * HU_RS_U) {
+					uint64_t ev[HU_RS_U];
+#pragma unroll
+					for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < cutq ? E(lo + 1 + q) : 0; }
+#pragma unroll
+					for(int u = 0; u < HU_RS_U; ++u) {
+						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
+						const bool valid = q < cutq;
+						const bool ls = valid && !((ev[u] >> idBits) < pk);
+						const unsigned long long mL = __ballot(ls);
+						if(valid) dst[lo + 1 + q] = ls ? RS[(int) preL[t] + __popcll(mL & rs_lane_lt(lane))] : ev[u];
+					}
+				}
+				hi = cutAbs;
+			}
+			else {
+				/* the tiny left part goes to the finisher's array as it is after this partition; its left stoppers are kept for the right part */
+				if(tid < 64) {
+					const int q = tid; const bool valid = q < cutq;
+					const uint64_t e = valid ? E(lo + 1 + q) : 0;
+					const bool ls = valid && !((e >> idBits) < pk);
+					const unsigned long long mL = __ballot(ls);
+					const int k = __popcll(mL & rs_lane_lt(lane));
+					if(ls) lsb[k] = e;
+					if(valid) fin[lo + 1 + q] = ls ? RS[k] : e;
+					if(tid == 0) { fin[lo] = pivE; if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
+				}
+				__syncthreads();
+				if(nStash >= 12) { failed = true; break; }
+				++nStash;
+				/* the right part [cut, hi): a right stopper of rank k <= m receives the k-th left stopper (the element that sat at i_k) */
+				for(int base = cutq / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_THREADS) {
+					const int q = base + tid, t = q >> 6;
+					const bool valid = q < M;
+					const uint64_t e = valid ? E(lo + 1 + q) : 0;
+					const bool rs = valid && !(pk < (e >> idBits));
+					const unsigned long long mR = __ballot(rs);
+					if(valid && q >= cutq) {
+						const int rk = rs ? (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)) : 0;
+						dst[lo + 1 + q] = (rs && rk <= m) ? lsb[rk - 1] : e;
+					}
+				}
+				lo = cutAbs;
+			}
+			__threadfence_block();
+			__syncthreads();
+			src = dst; dst = (dst == bufA) ? bufB : bufA;
+			pA = pB = -1;
+		}
+		if(__syncthreads_or((failed || nan) ? 1 : 0)) { /* the host path finishes this read */
+			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; }
+			continue;
+		}
+		/* ---- the last range into LDS beside the set-aside prefix; one thread finishes with the literal algorithm */
+		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) fin[p] = E(p);
+		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; } continue; }
+		if(tid == 0) {
+			bool ok = true;
+			for(int s = 0; s < nStash && ok; ++s) ok = rs_seq_loop(fin, seqStack, stash[s].lo, stash[s].hi, stash[s].depth, K, idBits);
+			if(ok) ok = rs_seq_loop(fin, seqStack, lo, hi, depth, K, idBits);
+			if(ok) { /* __final_insertion_sort over the blocks that hold the first K places */
+				const int e = min(hi, K + 16);
+				for(int i = 1; i < e; ++i) {
+					const uint64_t v = fin[i]; int j = i;
+					while(j > 0 && (v >> idBits) < (fin[j - 1] >> idBits)) { fin[j] = fin[j - 1]; --j; }
+					fin[j] = v;
+				}
+			}
+			shI[5] = ok ? 1 : 0;
+		}
+		__syncthreads();
+		if(!shI[5]) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; } continue; }
+		const int keep = min(K, hi);
+		if(tid == 0) seedCnt[read] = keep;
+		if(tid < keep) {
+			const int node = (int)(fin[tid] & ((1ull << idBits) - 1));
+			seedId[(size_t) read * HU_MAX_SEEDS + tid] = node;
+			seedDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[node]);
+			parDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[db.parent[node]]);
+		}
+	}
+}

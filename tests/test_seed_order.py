@@ -85,6 +85,59 @@ def test_nan_is_refused():
 
 
 @pytest.mark.gpu
+def test_device_sort_prefix_against_the_host_restatement():
+    """k_seed_refsort (data-parallel Hoare partitions + a sequential finisher in LDS) on rows of (d, N) pairs of every shape of the CPU test —
+    sizes below and above the finisher's range, heavy ties, sorted / reversed / organ-pipe rows, a row shaped like a real distance row at
+    gg_97 scale — against hu_sort_prefix_libstdcxx (itself checked against the literal std::sort above): identical ids in identical order,
+    or the row is handed back (count -1) when it needs introsort's heap-sort branch."""
+    from hmmufotu_amd import engine as E
+    lib = E.load_library()
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    rng = np.random.default_rng(17)
+
+    def run(dm, Nm, k, p16):
+        rows, n = dm.shape
+        pairs = np.ascontiguousarray((dm.astype(np.uint32) << 16) | Nm.astype(np.uint32))
+        out = np.zeros((rows, k), np.int32); cnt = np.zeros(rows, np.int32)
+        rc = lib.hu_sort_prefix_device(C.c_int(0), pairs.ctypes.data_as(C.c_void_p), C.c_int(rows), C.c_int64(n), C.c_int(k), C.c_int(int(p16)),
+                                       out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+        assert rc == 0, lib.hu_last_error()
+        return out, cnt
+    handed_back = 0
+    for n in (1, 2, 17, 40, 300, 512, 513, 600, 1025, 2000, 5000, 33333, 198642):
+        rows = 6 if n > 50000 else 24
+        for shape in ("row", "few", "equal", "asc", "desc", "pipe", "wideN"):
+            p16 = shape != "wideN"
+            if shape == "wideN":
+                Nm = rng.integers(300, 600, (rows, n)); dm = np.minimum(Nm, rng.binomial(500, 0.1, (rows, n)))
+            else:
+                Nm = np.where(rng.random((rows, n)) < 0.5, 250, 250 - rng.integers(0, 6, (rows, n)))
+                dm = {"row": lambda: rng.binomial(250, 0.08, (rows, n)), "few": lambda: rng.integers(0, 4, (rows, n)), "equal": lambda: np.full((rows, n), 7),
+                      "asc": lambda: np.sort(rng.integers(0, 200, (rows, n)), 1), "desc": lambda: np.sort(rng.integers(0, 200, (rows, n)), 1)[:, ::-1],
+                      "pipe": lambda: np.minimum(np.arange(n), np.arange(n)[::-1])[None, :].repeat(rows, 0) % 200}[shape]()
+                dm = np.minimum(dm, Nm)
+                if shape in ("asc", "desc", "pipe", "equal"):
+                    Nm = np.full((rows, n), 250)
+            for k in (50, 1, 64):
+                got, cnt = run(dm, Nm, k, p16)
+                for r in range(rows):
+                    if cnt[r] < 0:
+                        handed_back += 1; continue
+                    want = _prefix(dm[r] / Nm[r], k)
+                    assert cnt[r] == len(want) and np.array_equal(got[r, :cnt[r]], want), (n, shape, k, r, got[r, :12], want[:12])
+    print("rows handed back to the host path:", handed_back)
+    assert handed_back == 0
+    # the adversarial input reaches the depth limit: the kernel must hand the row back, not answer wrongly
+    from oracle import oracle_py as O
+    a = O.antiqsort(60000)
+    dm = np.round(a * 60000).astype(np.int64)[None, :]; Nm = np.full_like(dm, 65000)
+    got, cnt = run(dm, Nm, 50, False)
+    want = _prefix(dm[0] / Nm[0], 50)
+    assert cnt[0] == -1 or np.array_equal(got[0], want)
+
+
+@pytest.mark.gpu
 def test_engine_in_reference_seed_order_on_config_1():
     """all 1,000 reads of config 1 (the reference's 70_otus fixture) with hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX against the oracle's
     task under TIE_LIBSTDCXX (literal std::sort): the seed lists are identical id by id, in order; candidates and final branches identical
