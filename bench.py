@@ -445,7 +445,7 @@ def main():
             list(pool.map(ref_steps, range(nbr)))
             torch.cuda.synchronize()
             dtr = time.perf_counter() - tr0
-            best_ref = batches[0].placements().copy()
+            best_ref = batches[0].placements().copy(); cand_ref = batches[0].candidates()
             tms = batches[0].timings()
             out["seed_order_reference"] = dict(value=args.batch * steps_ref / dtr, unit=out["unit"], ms_per_step=dtr / steps_ref * 1e3, steps=steps_ref, batches_in_flight=nbr,
                                                seed_stage_ms=round(tms["seed_pdist"] + tms["seed_topk"], 2),
@@ -587,8 +587,17 @@ def main():
                                        tie_mode=tsum)
             if best_ref is not None:    # the engine in the reference's seed order against the oracle under the literal std::sort, read by read
                 want_c = np.where(tper["order_differs"][:ns], tper["picks"][:ns, 1, 0], r1["best_nodes"][:ns, 0])
-                out["seed_order_reference"]["final_branch_differs_from_oracle_std_sort"] = int((best_ref["c_node"][:ns] != want_c).sum())
-                out["seed_order_reference"]["reads_compared"] = int(ns)
+                row_of = {int(i): k for k, i in enumerate(tper["lib_idx"])}; rl = tper["lib_run"]
+                perr = []
+                for i in range(ns):                           # the same classification as for the default order, against the oracle's std::sort run
+                    src_, k_ = (rl, row_of[i]) if i in row_of else (r1, i)
+                    kc = int(src_["n_cand"][k_]); a, b = int(cand_ref["offs"][i]), int(cand_ref["offs"][i + 1])
+                    perr.append(parity.classify_read(src_["cand_node"][k_, :kc], src_["cand_est"][k_, :kc], src_["cand_ratio0"][k_, :kc],
+                                                     cand_ref["c_node"][a:b], db.parent, pos=int(src_["best_pos"][k_]) if kc else None))
+                totr = parity.summarize(perr)
+                out["seed_order_reference"].update(reads_compared=int(ns), final_branch_differs_from_oracle_std_sort=int((best_ref["c_node"][:ns] != want_c).sum()),
+                                                   best_branch_diffs_explained_near_tie=totr["best_differs"] - totr["best_unexplained"], unexplained_best_branch_diffs=totr["best_unexplained"],
+                                                   candidate_set_differs=totr["set_differs"], swaps_unexplained=totr["swaps_unexplained"])
         except Exception as ex:                             # the baseline must never sink the measurement
             import traceback
             traceback.print_exc()

@@ -280,6 +280,7 @@ def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, op
     idx = np.nonzero(order_diff)[0]
     pick_mask = np.zeros(n, np.int32); filt_diff = np.zeros(n, bool); via_tie = np.zeros(n, bool)
     picks = np.full((n, 2, 3), -1, np.int32)
+    rl = None
     if len(idx):
         t2 = tree2 if tree2 is not None else tree
         sub = lambda x: None if x is None else [x[i] for i in idx]
@@ -310,7 +311,7 @@ def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, op
                 final_a_node_differs=int(((pick_mask & 4) != 0).sum()), final_pick_differs=int(pick.sum()),
                 final_pick_diffs_traced_to_a_cutoff_tie=int(via_tie[pick].sum()))
     return dict(order_differs=order_diff, seeds_only_in_libstdcxx=only_lib, filtered_set_differs=filt_diff, pick_mask=pick_mask,
-                picks=picks, via_cutoff_seed=via_tie, phase1=p1), summ
+                picks=picks, via_cutoff_seed=via_tie, phase1=p1, lib_idx=idx, lib_run=rl), summ
 
 
 def std_sort_prefix(dist, k):

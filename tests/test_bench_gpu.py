@@ -48,7 +48,7 @@ def test_single_rank_line_has_the_contract_fields_and_zero_unexplained_differenc
     assert t["reads"] == 96 and t["seed_set_diffs_all_exact_cutoff_ties"] and t["final_pick_differs"] == t["final_pick_diffs_traced_to_a_cutoff_tie"]
     assert r["bound"] == "valu_fp64_issue" and "hbm_roof" in r and "valu_roof" in r and len(r["kernel_source_hash"]) == 16
     sr = j["seed_order_reference"]
-    assert sr["value"] > 0 and sr["reads_compared"] == 96 and sr["final_branch_differs_from_oracle_std_sort"] == 0, sr
+    assert sr["value"] > 0 and sr["reads_compared"] == 96 and sr["unexplained_best_branch_diffs"] == 0 and sr["candidate_set_differs"] == 0 and sr["swaps_unexplained"] == 0, sr
     e = j["end_to_end"]
     assert "failed" not in e, e
     assert e["reads"] == 500 and e["value"] > 0 and e["placed"] > 400 and e["tsv_mb"] > 0.5
