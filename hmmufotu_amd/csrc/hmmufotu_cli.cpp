@@ -379,6 +379,9 @@ int main(int argc, char** argv) {
 		{ std::lock_guard<std::mutex> lk(P.mu); P.readerDone = true; }
 		P.cv.notify_all();
 	}
+	/* hu_last_error() is per thread; the library leaves a failing call's message in the CALLING thread's slot (a host-pool worker that throws is
+	 * carried to the caller: hu_catch_all), and every stage above reads it on the thread that made the call, right after the call.
+	 * The -v counters (reads in total, placed, flagged) are plain variables of the writer thread: read only below, after writer.join(). */
 	seeder.join();
 	for(auto& t : workers) t.join();
 	writer.join();
