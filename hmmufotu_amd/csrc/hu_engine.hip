@@ -24,6 +24,7 @@
 #include "hu_kern_tree.h"
 #include "hu_kern_blk.h"
 #include "hu_kern_refsort.h"
+#include "hu_kern_rank.h"
 #include <hipcub/hipcub.hpp>
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
@@ -155,6 +156,8 @@ struct hu_db {
 	std::vector<std::string> annos, names;   /* only when loaded from a .ptu */
 	std::vector<void*> allocs;
 	int64_t hbmBytes = 0;
+	int32_t* dAnnoId = nullptr;    /* [nNodes] class of the node's taxon annotation (calcQValues sums by taxon name) */
+	double* dLlTab = nullptr;      /* [csLen + 1] the final loglik placeSeq returns for a region of k columns: k sequential additions of log(sum_i pi_i e) */
 };
 
 template<class X> static int dev_alloc(hu_db* db, X** p, size_t n) {
@@ -357,6 +360,14 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 		double pc[HU_PC_COUNT];
 		hu_place_consts(db->mdl, pc);
 		if((rc = dev_upload(db, &q, pc, (size_t) HU_PC_COUNT)) != HU_OK) return fail(rc); d.placeConst = q;
+	}
+	{ /* what the finish stage reads on the device */
+		if((rc = dev_upload(db, &db->dAnnoId, db->annoId.data(), (size_t) n)) != HU_OK) return fail(rc);
+		const double e1 = std::exp(1.0);
+		const double siteLL = std::log((db->mdl.pi[0] * e1 + db->mdl.pi[2] * e1) + (db->mdl.pi[1] * e1 + db->mdl.pi[3] * e1));   /* dot_product_scaled(pi, ones): SSE2 association (e0 + e2) + (e1 + e3) */
+		std::vector<double> tab((size_t) L + 1, 0.0);
+		for(int k = 1; k <= L; ++k) tab[k] = tab[k - 1] + siteLL;
+		if((rc = dev_upload(db, &db->dLlTab, tab.data(), tab.size())) != HU_OK) return fail(rc);
 	}
 	if((rc = init_sym_map()) != HU_OK) return fail(rc);
 	built = true;
@@ -708,11 +719,7 @@ extern "C" int hu_tree_evaluate(int32_t n, int32_t cs_len, const int32_t* parent
 
 /* ------------------------------------------------------------------------------ batch */
 
-struct HostPlace {
-	int32_t seedIdx, cNode, pNode, aNode, iters;
-	double wuv, ratio, wnr, loglik, height, qPlace, qTaxon, estLoglik, rootLoglik;
-	double annoDist() const { return aNode == cNode ? wuv * ratio + wnr : (1 - ratio) * wuv + wnr; }
-};
+typedef HuPlaceRec HostPlace;     /* a candidate's PTPlacement: the same record on the device (hu_kern_rank.h) and in the host mirror */
 
 /* Kernel-selection and diagnostic knobs of a batch.  Defaults come from the environment ONCE, when the batch is created
  * (HU_<NAME>, e.g. HU_XCD_MAP=0; a variable that is set but not a number counts as 1); hu_batch_set_knob changes one
@@ -807,6 +814,15 @@ struct hu_batch {
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
+	/* the <= 64-record stages on the device (hu_kern_rank.h): candidates per read, their offsets, the seed slots in filter order, every
+	 * candidate's PTPlacement, the best one per read; meta = {candidates, largest gap-site count, largest base-site count} */
+	DBuf<int32_t> dCandCnt, dCandOff, dMeta;
+	DBuf<uint8_t> dFiltSlot;
+	DBuf<HuPlaceRec> dPlaces;
+	DBuf<hu_place_rec> dBest;
+	size_t nc = 0;                 /* candidates of the batch (after the filter stage / hu_batch_set_candidates) */
+	int maxGapSites = 0, maxBaseSites = 0;
+	bool hostCands = false;        /* candOffs / places below mirror the device's (filled on demand: getters, the chimera check) */
 	DBuf<double> dRootLL;
 	PinnedVec<double> hRootLL;
 	/* host */
@@ -1283,6 +1299,22 @@ static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{
  * become order-isomorphic integer keys in node order, and hu_sort_prefix_packed leaves in the first max_nseed places what libstdc++'s
  * introsort would.  A read with a NaN distance (a node sharing no base with it: 0 / 0) takes the (dist, node id) order with NaN last —
  * std::sort is undefined there and the oracle falls back the same way.  Seeds, their (d, N) and their parents' go back to the device. */
+extern "C" int hu_sort_desc_device(int device, const double* keys, int rows, int n, int32_t* order) try {
+	if(!keys || !order || rows < 1 || n < 0 || n > HU_MAX_SEEDS) { hu_set_error("hu_sort_desc_device: bad argument"); return HU_ERR_ARG; }
+	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
+	HIPCHK(hipSetDevice(device));
+	if(n == 0) return HU_OK;
+	DBuf<double> dk; DBuf<int32_t> dor;
+	int rc;
+	if((rc = dk.ensure((size_t) rows * n)) != HU_OK || (rc = dor.ensure((size_t) rows * n)) != HU_OK) return rc;
+	HIPCHK(hipMemcpy(dk.p, keys, (size_t) rows * n * 8, hipMemcpyHostToDevice));
+	(void) hipGetLastError();
+	k_sort_desc_test<<<(rows + 63) / 64, 64>>>(rows, n, dk.p, dor.p);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(order, dor.p, (size_t) rows * n * 4, hipMemcpyDeviceToHost));
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_sort_desc_device"); }
+
 extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt) try {
 	if(!pairs || rows < 1 || n < 1 || n >= (1 << 24) - 1 || k < 1 || k > HU_MAX_SEEDS || !out_idx || !out_cnt) { hu_set_error("hu_sort_prefix_device: bad argument"); return HU_ERR_ARG; }
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
@@ -1719,64 +1751,56 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) try {
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_estimate_batch"); }
 
-static bool cmpLoglik(const HostPlace& l, const HostPlace& r) { return l.loglik < r.loglik; }
-static bool cmpQPlace(const HostPlace& l, const HostPlace& r) { return l.qPlace < r.qPlace; }
+
+/* the host mirror of the device's candidate list (offsets + every candidate's PTPlacement), filled on demand */
+static int sync_host_cands(hu_batch* b) {
+	if(b->hostCands) return HU_OK;
+	const size_t n = (size_t) b->n;
+	std::vector<int32_t> off(n + 1, 0);
+	b->places.resize(b->nc);
+	HIPCHK(hipSetDevice(b->db->device));
+	if(n) HIPCHK(hipMemcpyAsync(off.data(), b->dCandOff.p, (n + 1) * 4, hipMemcpyDeviceToHost, b->stream));
+	if(b->nc) HIPCHK(hipMemcpyAsync(b->places.data(), b->dPlaces.p, b->nc * sizeof(HuPlaceRec), hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	b->candOffs.assign(off.begin(), off.end());      /* [n + 1], all zero for an empty batch */
+	b->hostCands = true;
+	return HU_OK;
+}
+/* offsets, candidate count and the site-count maxima of the batch from the per-read candidate counts on the device */
+static int scan_cands(hu_batch* b, bool withPerm) {
+	int rc;
+	if((rc = b->dCandOff.ensure((size_t) b->n + 1)) != HU_OK || (rc = b->dMeta.ensure(4)) != HU_OK) return rc;
+	k_cand_scan<<<1, 1024, 0, b->stream>>>(b->n, b->dCandCnt.p, b->dCandOff.p, withPerm ? b->dPermCnt.p : nullptr, b->dStart.p, b->dEnd.p, b->dMeta.p);
+	HIPCHK(hipGetLastError());
+	int32_t meta[4] = {0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(meta, b->dMeta.p, 12, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	b->nc = (size_t) meta[0]; b->maxGapSites = meta[1]; b->maxBaseSites = meta[2];
+	return HU_OK;
+}
 
 extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_ESTIMATED) { hu_set_error("hu_filter_batch: no estimates"); return HU_ERR_STATE; }
 	if(!(o->max_error >= 0)) { hu_set_error("max_error must be >= 0"); return HU_ERR_ARG; }
 	HIPCHK(hipSetDevice(b->db->device));
-	const hu_db* db = b->db;
 	const size_t n = (size_t) b->n;
-	b->hSeedCnt.resize(n); b->hSeedId.resize(n * HU_MAX_SEEDS); b->hSeedDN.resize(n * HU_MAX_SEEDS); b->hEst.resize(n * HU_MAX_SEEDS);
-	b->hPermCnt.resize(n * 2);
+	if(b->knob.inject_fault == 1) parallel_for(std::max<size_t>(n, 600), [&](size_t r) { if(r + 1 == std::max<size_t>(n, 600)) throw std::bad_alloc(); });   /* fault injection: a worker of the host pool throws */
+	int rc;
+	if((rc = b->dCandCnt.ensure(std::max<size_t>(n, 1))) != HU_OK || (rc = b->dFiltSlot.ensure(std::max<size_t>(n, 1) * HU_MAX_SEEDS)) != HU_OK) return rc;
+	(void) hipGetLastError();
+	b->nc = 0; b->maxGapSites = b->maxBaseSites = 0;
 	if(n) {
-		HIPCHK(hipMemcpyAsync(b->hSeedCnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipMemcpyAsync(b->hSeedId.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipMemcpyAsync(b->hSeedDN.data(), b->dSeedDN.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipMemcpyAsync(b->hEst.data(), b->dEst.p, n * HU_MAX_SEEDS * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipMemcpyAsync(b->hPermCnt.data(), b->dPermCnt.p, n * 8, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		/* filterPlacements (src/HmmUFOtu_main.cpp:162-173) per read on the device: libstdc++'s std::sort(rbegin, rend, compareByLoglik) restated (hu_kern_rank.h).
+		 * A read that is not placed has no seeds (k_seed_drop_empty), hence no candidates */
+		k_filter<<<(unsigned)((n + 63) / 64), 64, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dEst.p, o->max_error, b->dCandCnt.p, b->dFiltSlot.p, 0);
+		HIPCHK(hipGetLastError());
+		if((rc = scan_cands(b, true)) != HU_OK) return rc;
+		if((rc = b->dCands.ensure(std::max<size_t>(b->nc, 1))) != HU_OK || (rc = b->dPlaces.ensure(std::max<size_t>(b->nc, 1))) != HU_OK) return rc;
+		k_build_cands<<<(unsigned)((n * HU_MAX_SEEDS + 255) / 256), 256, 0, b->stream>>>(b->db->dev, b->n, b->dCandCnt.p, b->dCandOff.p, b->dFiltSlot.p, b->dSeedId.p, b->dEst.p, b->dCands.p, b->dPlaces.p);
+		HIPCHK(hipGetLastError());
 	}
-	b->candOffs.assign(n + 1, 0);
-	b->tmpPlaces.resize(n * HU_MAX_SEEDS);       /* per read: its <= 64 estimates, sorted in place; the first candOffs-many are kept */
-	const double maxError = o->max_error;
-	const int fault = b->knob.inject_fault;
-	parallel_for(n, [&](size_t r) {
-		if(fault == 1 && r + 1 == n) throw std::bad_alloc();
-		HostPlace* pl = b->tmpPlaces.data() + r * HU_MAX_SEEDS;
-		const int cnt = b->hAlns[r].status == HU_READ_OK ? b->hSeedCnt[r] : 0;
-		for(int s = 0; s < cnt; ++s) {
-			const HuEstOut& e = b->hEst[r * HU_MAX_SEEDS + s];
-			HostPlace p;
-			memset(&p, 0, sizeof(p));
-			p.seedIdx = s; p.cNode = b->hSeedId[r * HU_MAX_SEEDS + s]; p.pNode = db->parent[p.cNode];
-			p.ratio = e.ratio; p.wnr = e.wnr; p.loglik = e.loglik; p.estLoglik = e.loglik; p.wuv = db->blen[p.cNode];
-			p.aNode = p.ratio <= 0.5 ? p.cNode : p.pNode;
-			pl[s] = p;
-		}
-		size_t g = 0;
-		if(cnt > 0) { /* filterPlacements (src/HmmUFOtu_main.cpp:162-173): the same std::sort call on the same sequence */
-			std::sort(std::reverse_iterator<HostPlace*>(pl + cnt), std::reverse_iterator<HostPlace*>(pl), cmpLoglik);
-			const double bestLL = pl[0].loglik;
-			for(; g < (size_t) cnt; ++g) if(bestLL - pl[g].loglik > maxError) break;
-		}
-		b->candOffs[r + 1] = (int64_t) g;
-	});
-	for(size_t r = 0; r < n; ++r) b->candOffs[r + 1] += b->candOffs[r];
-	b->places.resize((size_t) b->candOffs[n]); b->hCands.resize((size_t) b->candOffs[n]);
-	parallel_for(n, [&](size_t r) {
-		size_t at = (size_t) b->candOffs[r];
-		const HostPlace* pl = b->tmpPlaces.data() + r * HU_MAX_SEEDS;
-		const size_t cnt = (size_t)(b->candOffs[r + 1] - b->candOffs[r]);
-		for(size_t k = 0; k < cnt; ++k) {
-			const HostPlace& p = pl[k];
-			b->places[at] = p;
-			HuCand c; c.read = (int32_t) r; c.node = p.cNode; c.ratio0 = p.ratio; c.wnr0 = p.wnr;
-			b->hCands[at++] = c;
-		}
-	});
+	b->hostCands = false; b->placesGiven = false;
 	b->state = ST_FILTERED;
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_filter_batch"); }
@@ -1801,6 +1825,8 @@ extern "C" int hu_batch_set_candidates(hu_batch* b, const int64_t* offs, const h
 	b->candOffs.assign(offs, offs + n + 1);
 	const size_t nc = (size_t) offs[n];
 	b->places.resize(nc); b->hCands.resize(nc);
+	std::vector<int32_t> hCnt(std::max<size_t>(n, 1), 0);
+	for(size_t r = 0; r < n; ++r) hCnt[r] = (int32_t)(offs[r + 1] - offs[r]);
 	for(size_t r = 0; r < n; ++r) for(int64_t c = offs[r]; c < offs[r + 1]; ++c) {
 		const hu_place_rec& q = recs[c];
 		HostPlace p;
@@ -1813,16 +1839,25 @@ extern "C" int hu_batch_set_candidates(hu_batch* b, const int64_t* offs, const h
 		HuCand cd; cd.read = (int32_t) r; cd.node = p.cNode; cd.ratio0 = p.ratio; cd.wnr0 = p.wnr;
 		b->hCands[c] = cd;
 	}
-	if(!placed && n) { /* gap / base site counts of the regions for the split placement kernel (the estimate stage may not have run on this batch) */
+	{ /* the list goes to the device, where the later stages read it */
 		int rc;
-		if((rc = b->dPermCnt.ensure(n * 2)) != HU_OK) return rc;
-		b->hPermCnt.resize(n * 2);
+		if((rc = b->dCandCnt.ensure(std::max<size_t>(n, 1))) != HU_OK || (rc = b->dCands.ensure(std::max<size_t>(nc, 1))) != HU_OK ||
+				(rc = b->dPlaces.ensure(std::max<size_t>(nc, 1))) != HU_OK || (rc = b->dPermCnt.ensure(std::max<size_t>(n, 1) * 2)) != HU_OK) return rc;
 		(void) hipGetLastError();
-		k_site_count<<<b->n, 64, 0, b->stream>>>(db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPermCnt.p);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(b->hPermCnt.data(), b->dPermCnt.p, n * 8, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		if(n) {
+			HIPCHK(hipMemcpyAsync(b->dCandCnt.p, hCnt.data(), n * 4, hipMemcpyHostToDevice, b->stream));
+			if(nc) {
+				HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
+				HIPCHK(hipMemcpyAsync(b->dPlaces.p, b->places.data(), nc * sizeof(HuPlaceRec), hipMemcpyHostToDevice, b->stream));
+			}
+			/* gap / base site counts of the regions for the split placement kernel (the estimate stage may not have run on this batch) */
+			k_site_count<<<b->n, 64, 0, b->stream>>>(db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPermCnt.p);
+			HIPCHK(hipGetLastError());
+			if((rc = scan_cands(b, true)) != HU_OK) return rc;       /* offsets + counts on the device; synchronises: the host arrays above are done with */
+		}
+		else { b->nc = 0; b->maxGapSites = b->maxBaseSites = 0; }
 	}
+	b->hostCands = true;                 /* candOffs / places above ARE the list */
 	b->placesGiven = placed != 0;
 	b->fixedRoot = false;
 	b->state = placed ? ST_PLACED : ST_FILTERED;
@@ -1839,18 +1874,15 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_FILTERED) { hu_set_error("hu_place_batch: candidates are not filtered"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
-	const size_t nc = b->hCands.size();
+	const size_t nc = b->nc;            /* the candidates are on the device already (hu_filter_batch / hu_batch_set_candidates) */
 	int rc;
-	if((rc = b->dCands.ensure(nc)) != HU_OK) return rc;
-	if((rc = b->dPlaceOut.ensure(nc)) != HU_OK) return rc;
-	b->hPlaceOut.resize(nc);
+	if((rc = b->dPlaceOut.ensure(std::max<size_t>(nc, 1))) != HU_OK) return rc;
 	(void) hipGetLastError();
 	if(nc) {
 		int maxR = 1;
 		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
 		const int spt2 = (maxR + 127) / 128, spt4 = (maxR + 255) / 256;  /* sites per thread with 2 / 4 waves per candidate */
 		const bool stream = b->knob.streaming_sep != 0 || spt4 > 12;
-		HIPCHK(hipMemcpyAsync(b->dCands.p, b->hCands.data(), nc * sizeof(HuCand), hipMemcpyHostToDevice, b->stream));
 		#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
 		if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
 			const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
@@ -1902,9 +1934,8 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 				 * slots (k_place_blk GS: 6 + 2 slots = up to 768 gap and 256 base sites, 10 + 2 = 1,280 and 256): the gap slots
 				 * need no per-site table.  The counts come from k_site_count (estimate stage, read back by the filter stage). */
 				const int S = spt2 <= 8 ? 8 : 12, G = S - 2;
-				bool split = !b->knob.place_nosplit && b->hPermCnt.size() == (size_t) b->n * 2;
-				for(int r = 0; r < b->n && split; ++r)
-					if(b->hEnd[r] >= b->hStart[r] && (b->hPermCnt[2 * r] > G * 128 || b->hPermCnt[2 * r + 1] > (S - G) * 128)) split = false;
+				/* every read with a region fits the slots: the largest counts of the batch come with the candidate count (k_cand_scan) */
+				const bool split = !b->knob.place_nosplit && b->maxGapSites <= G * 128 && b->maxBaseSites <= (S - G) * 128;
 				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", "EM across both waves");
 				if(split) {
 					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
@@ -1936,13 +1967,10 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 		HIPCHK(hipGetLastError());
 		if(o->fix_root_loglik) { /* the intended root log-likelihood at the optimised lengths (documented deviation, off by default) */
 			if((rc = b->dRootLL.ensure(nc)) != HU_OK) return rc;
-			b->hRootLL.resize(nc);
 			k_root_loglik<<<(unsigned) nc, 64, 0, b->stream>>>(b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p, (int) nc, b->dRootLL.p);
 			HIPCHK(hipGetLastError());
-			HIPCHK(hipMemcpyAsync(b->hRootLL.data(), b->dRootLL.p, nc * sizeof(double), hipMemcpyDeviceToHost, b->stream));
 		}
-		HIPCHK(hipMemcpyAsync(b->hPlaceOut.data(), b->dPlaceOut.p, nc * sizeof(HuPlaceOut), hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		/* nothing comes back here: the finish stage reads the results where they are */
 	}
 	b->fixedRoot = o->fix_root_loglik != 0 && nc > 0;
 	b->placesGiven = false;
@@ -1950,8 +1978,6 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_place_batch"); }
 
-static double add_scaled(double a, double c) { double s = std::max(a, c); return std::log(std::exp(a - s) + std::exp(c - s)) + s; }
-static double p2q(double p) { return -10 * std::log(p) / std::log(10.0); }
 
 extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
@@ -1959,75 +1985,21 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 	const hu_db* db = b->db;
 	const size_t n = (size_t) b->n;
 	if(b->knob.inject_fault == 2) throw std::length_error("injected");
+	HIPCHK(hipSetDevice(db->device));
 	b->best.assign(n, hu_place_rec());
-	/* the root message is re-initialised to INVALID_LOGLIK = 1 before treeLoglik reads it, so every
-	 * placement's final loglik is (end-start+1) * log(sum_i pi_i e^1) (src/PhyloTreeUnrooted.cpp:918-922,
-	 * SURVEY.md F4); reproduced, not fixed */
-	const double e1 = std::exp(1.0);
-	const double siteLL = std::log((db->mdl.pi[0] * e1 + db->mdl.pi[2] * e1) + (db->mdl.pi[1] * e1 + db->mdl.pi[3] * e1));
-	parallel_for(n, [&](size_t r) {
-		static thread_local std::vector<HostPlace> pl;
-		static thread_local std::vector<std::pair<int32_t, double>> tax;
-		static thread_local std::vector<double> pp, pr;
-		hu_place_rec& br = b->best[r];
-		br.c_node = br.p_node = br.a_node = -1; br.n_cand = 0;
-		br.wuv = br.ratio = br.wnr = br.loglik = br.height = br.q_place = br.q_taxon = br.anno_dist = br.est_loglik = br.root_loglik = NAN;
-		const int64_t lo = b->candOffs[r], hi = b->candOffs[r + 1];
-		if(hi <= lo) return;
-		pl.assign(b->places.begin() + lo, b->places.begin() + hi);
-		const int nsite = b->hEnd[r] - b->hStart[r] + 1;
-		double ll = 0;
-		for(int j = 0; j < nsite; ++j) ll += siteLL;
-		for(int64_t c = lo; c < hi; ++c) { /* PTUnrooted::placeSeq const (src/PhyloTreeUnrooted.cpp:936-952) */
-			HostPlace& p = pl[c - lo];
-			const HuPlaceOut none = {0, 0, 0, 0};
-			const HuPlaceOut& po = b->placesGiven ? none : b->hPlaceOut[c];
-			if(!b->placesGiven) {
-				p.rootLoglik = b->fixedRoot ? b->hRootLL[c] : NAN;
-				p.loglik = b->fixedRoot ? p.rootLoglik : ll; p.wnr = po.wnr; p.ratio = po.wur / p.wuv; p.height = db->height[p.cNode] + po.wur; p.iters = po.iters | (po.pad << 8);
-				p.aNode = (p.ratio <= 0.5 || db->height[p.pNode] > o->max_height) ? p.cNode : p.pNode;
-			}
-			p.qPlace = p.qTaxon = NAN;     /* --ML computes none */
-			b->places[c] = p;
-		}
-		if(o->only_ml) std::sort(pl.rbegin(), pl.rend(), cmpLoglik);
-		else { /* calcQValues (src/HmmUFOtu_main.cpp:182-216) */
-			tax.clear();
-			double norm = -kInf;
-			pp.assign(pl.size(), 0.0);
-			for(size_t i = 0; i < pl.size(); ++i) {
-				const HostPlace& p = pl[i];
-				const double logPrior = o->prior == HU_PRIOR_UNIFORM ? -0.0 : -(p.annoDist() - p.wnr + p.height);
-				const double v = p.loglik + logPrior;
-				pp[i] = v;
-				const int32_t key = db->annoId[p.aNode];
-				bool found = false;
-				for(auto& kv : tax) if(kv.first == key) { kv.second = add_scaled(kv.second, v); found = true; break; }
-				if(!found) tax.push_back({key, v});
-				norm = add_scaled(norm, v);
-			}
-			double mx = pp[0];
-			for(double v : pp) mx = std::max(mx, v);
-			double sum = 0;
-			pr.assign(pl.size(), 0.0);
-			for(size_t i = 0; i < pl.size(); ++i) { pr[i] = std::exp(pp[i] - mx); sum += pr[i]; }
-			for(size_t i = 0; i < pl.size(); ++i) { const double q = p2q(1 - pr[i] / sum); pl[i].qPlace = q > 250 ? 250 : q; }
-			for(size_t i = 0; i < pl.size(); ++i) {
-				const int32_t key = db->annoId[pl[i].aNode];
-				double tp = 0;
-				for(auto& kv : tax) if(kv.first == key) tp = kv.second;
-				const double q = p2q(1 - std::exp(tp - norm));
-				pl[i].qTaxon = q > 250 ? 250 : q;
-			}
-			/* the q-values belong to the candidates' records too (hu_batch_get_candidate_places): still in filter order here */
-			for(size_t i = 0; i < pl.size(); ++i) { b->places[lo + i].qPlace = pl[i].qPlace; b->places[lo + i].qTaxon = pl[i].qTaxon; }
-			std::sort(pl.rbegin(), pl.rend(), cmpQPlace);
-		}
-		const HostPlace& p = pl[0];
-		br.c_node = p.cNode; br.p_node = p.pNode; br.a_node = p.aNode; br.n_cand = (int32_t) pl.size();
-		br.wuv = p.wuv; br.ratio = p.ratio; br.wnr = p.wnr; br.loglik = p.loglik; br.height = p.height;
-		br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik; br.root_loglik = p.rootLoglik;
-	});
+	int rc;
+	if((rc = b->dBest.ensure(std::max<size_t>(n, 1))) != HU_OK) return rc;
+	(void) hipGetLastError();
+	if(n) {
+		/* PTPlacement after placeSeq (the F4 constant as loglik), calcQValues, the final std::sort and bestPlace: one thread per read
+		 * on the device (hu_kern_rank.h); only the best record of every read comes back — the candidates' records stay until somebody asks */
+		k_finish<<<(unsigned)((n + 63) / 64), 64, 0, b->stream>>>(db->dev, b->n, b->dStart.p, b->dEnd.p, b->dCandOff.p, b->dPlaces.p, b->dPlaceOut.p,
+				b->fixedRoot ? b->dRootLL.p : nullptr, db->dLlTab, db->dAnnoId, o->max_height, o->only_ml, o->prior, b->placesGiven ? 1 : 0, b->dBest.p);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(b->best.data(), b->dBest.p, n * sizeof(hu_place_rec), hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+	}
+	b->hostCands = false;                /* the records changed on the device */
 	b->state = ST_FINISHED;
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_finish_batch"); }
@@ -2071,7 +2043,8 @@ static int segment_pass(hu_batch* w, hu_batch* b, const hu_opts* o, double maxEr
 	if((rc = hu_estimate_batch(w, &so)) != HU_OK) return rc;
 	if((rc = hu_filter_batch(w, &so)) != HU_OK) return rc;
 	if((rc = hu_place_batch(w, &so)) != HU_OK) return rc;
-	return hu_finish_batch(w, &so);
+	if((rc = hu_finish_batch(w, &so)) != HU_OK) return rc;
+	return sync_host_cands(w);           /* the pools below are built on the host from every segment's candidates */
 }
 
 extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, const hu_chimera_opts* co, hu_chimera_rec* out) try {
@@ -2416,6 +2389,7 @@ extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double
 extern "C" int hu_batch_get_candidates(hu_batch* b, int64_t* offs, int32_t* c_node, double* ratio, double* wnr, double* est_loglik, int32_t* iters) try {
 	if(!b) return HU_ERR_ARG;
 	if(b->state < ST_FILTERED) { hu_set_error("no candidates yet"); return HU_ERR_STATE; }
+	{ const int rc = sync_host_cands(b); if(rc != HU_OK) return rc; }
 	if(offs) memcpy(offs, b->candOffs.data(), b->candOffs.size() * 8);
 	for(size_t c = 0; c < b->places.size(); ++c) {
 		const HostPlace& p = b->places[c];
@@ -2434,6 +2408,7 @@ static hu_place_rec to_rec(const HostPlace& p, int32_t nCand) {
 extern "C" int hu_batch_get_candidate_places(hu_batch* b, hu_place_rec* recs) try {
 	if(!b || !recs) return HU_ERR_ARG;
 	if(b->state < ST_FINISHED) { hu_set_error("batch is not finished"); return HU_ERR_STATE; }
+	{ const int rc = sync_host_cands(b); if(rc != HU_OK) return rc; }
 	for(size_t r = 0; r + 1 < b->candOffs.size(); ++r)
 		for(int64_t c = b->candOffs[r]; c < b->candOffs[r + 1]; ++c) recs[c] = to_rec(b->places[c], (int32_t)(b->candOffs[r + 1] - b->candOffs[r]));
 	return HU_OK;

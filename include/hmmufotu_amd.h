@@ -249,6 +249,10 @@ int hu_sort_prefix_libstdcxx(const double* dist, int64_t n, int64_t k, int32_t* 
  * (d << 16 | N, d <= N, N >= 1; pair16 != 0: held as 16-bit pairs, d, N <= 255), one sort per row.  out_idx [rows][k]; out_cnt [rows] =
  * min(k, n), or -1 for a row the kernel left to the host path (heap-sort branch of introsort). */
 int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt);
+/* The device routine behind filterPlacements and the final sort (hu_kern_rank.h), exposed for its parity test: rows x n doubles (n <= HU_MAX_SEEDS),
+ * order [rows][n] = for every place the index of the element that std::sort(rbegin, rend, less) — libstdc++'s introsort incl. its heap-sort
+ * branch — leaves there (descending; equal keys as the library leaves them). */
+int hu_sort_desc_device(int device, const double* keys, int rows, int n, int32_t* order);
 /* the 5' and (GLOBAL mode) 3' seed scans for n reads -> vpaths [n][2][6] for hu_batch_set_reads */
 int hu_seed_index_lookup(const hu_seed_index* ix, int n, const char* bases, const int64_t* offs, int seed_region,
 		int align_mode, int32_t* vpaths);

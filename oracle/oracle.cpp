@@ -351,6 +351,16 @@ void orc_antiqsort(long n, double* out) {
 	for(long i = 0; i < n; ++i) out[i] = (double) val[i] / (double) n;
 }
 
+/* literal std::sort(rbegin, rend, less-by-key) of n records (key, index): what filterPlacements and the final sort of the per-read task call
+ * (src/HmmUFOtu_main.cpp:164, src/hmmufotu.cpp:726, 730) — the checker of the device routine that replaced those calls (hu_sort_desc64) */
+void orc_std_sort_desc(const double* keys, int n, int* order) {
+	struct Rec { double key; int idx; };
+	std::vector<Rec> v((size_t) n);
+	for(int i = 0; i < n; ++i) { v[i].key = keys[i]; v[i].idx = i; }
+	std::sort(v.rbegin(), v.rend(), [](const Rec& l, const Rec& r) { return l.key < r.key; });
+	for(int i = 0; i < n; ++i) order[i] = v[i].idx;
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }
 
 } // extern "C"

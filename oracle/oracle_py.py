@@ -329,5 +329,13 @@ def antiqsort(n):
     return out
 
 
+def std_sort_desc(keys):
+    """the order a literal std::sort(rbegin, rend, less-by-key) leaves (orc_std_sort_desc)"""
+    keys = np.ascontiguousarray(keys, np.float64)
+    out = np.zeros(len(keys), np.int32)
+    lib().orc_std_sort_desc(_p(keys, C.c_double), C.c_int(len(keys)), _p(out, C.c_int))
+    return out
+
+
 def max_threads():
     return lib().orc_max_threads()

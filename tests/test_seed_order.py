@@ -85,6 +85,39 @@ def test_nan_is_refused():
 
 
 @pytest.mark.gpu
+def test_device_sort_of_64_records_against_the_literal_std_sort():
+    """hu_sort_desc64 (hu_kern_rank.h): the device routine behind filterPlacements and the final sort — libstdc++'s std::sort(rbegin, rend, less)
+    on <= 64 records — against the literal call in the oracle: every n from 0 to 64, all keys equal (the final sort of the reference: every
+    placed loglik ties, SURVEY.md F4 — the pick IS the tie permutation), heavy ties, distinct keys, sorted / reversed input, and McIlroy's
+    adversary for the heap-sort branch."""
+    from hmmufotu_amd import engine as E
+    from oracle import oracle_py as O
+    lib = E.load_library()
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    rng = np.random.default_rng(23)
+    for n in range(0, 65):
+        rows = []
+        rows.append(np.full(n, -1234.5))
+        rows.append(rng.standard_normal(n))
+        rows.append(rng.integers(0, 3, n).astype(float))
+        rows.append(rng.integers(0, max(2, n // 4), n).astype(float))
+        rows.append(np.sort(rng.standard_normal(n))); rows.append(np.sort(rng.standard_normal(n))[::-1].copy())
+        rows.append(O.antiqsort(n)); rows.append(O.antiqsort(n)[::-1].copy())           # the reverse iterators see it reversed
+        rows.append(np.floor(O.antiqsort(n) * 7))
+        for _ in range(8):
+            rows.append(rng.integers(0, 5, n) + rng.integers(0, 2, n) * 1e-9)
+        K = np.ascontiguousarray(np.stack(rows)) if n else np.zeros((len(rows), 0))
+        out = np.zeros(K.shape, np.int32)
+        rc = lib.hu_sort_desc_device(C.c_int(0), K.ctypes.data_as(C.c_void_p), C.c_int(len(rows)), C.c_int(n), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, lib.hu_last_error()
+        for r in range(len(rows)):
+            assert np.array_equal(out[r], O.std_sort_desc(K[r])), (n, r, K[r], out[r], O.std_sort_desc(K[r]))
+    # the all-equal permutation really is not the identity beyond 16 records (else the test above proves little)
+    assert not np.array_equal(O.std_sort_desc(np.zeros(40)), np.arange(40))
+
+
+@pytest.mark.gpu
 def test_device_sort_prefix_against_the_host_restatement():
     """k_seed_refsort (data-parallel Hoare partitions + a sequential finisher in LDS) on rows of (d, N) pairs of every shape of the CPU test —
     sizes below and above the finisher's range, heavy ties, sorted / reversed / organ-pipe rows, a row shaped like a real distance row at
