@@ -215,3 +215,70 @@ def test_engine_in_reference_seed_order_on_config_1():
     assert ndiff == 19
     # 70_otus leaves have gaps: some reads have nodes with N = 0 ... none on this fixture (tie report: reads_with_nan_dist == 0)
     B.close(); D.close()
+
+
+@pytest.mark.gpu
+def test_reference_seed_order_paths_agree_and_fall_back_where_the_reference_is_undefined(capfd):
+    """The reference-order mode on a mid-size tree: (1) the device kernel and the host restatement (knob refsort_host) give the same seed lists,
+    equal to the oracle's literal std::sort; (2) with a height filter (-H) the pair rows are compacted on the host path — same rule; (3) a database
+    with partial sequences: reads meet nodes they share no column with (N = 0: dist = 0 / 0), std::sort is undefined on NaN, the oracle falls
+    back to (dist, id) with NaN last and so must the engine — the device kernel hands such reads to the host path (trace line)."""
+    import copy, re
+    from conftest import get_db, oracle_objects, sim_reads
+    from hmmufotu_amd import engine as E
+    from oracle import oracle_py as O
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    db = get_db(2600, 300, "JC69", dg_k=0, seed=11, n_match=200)
+    reads, vps = sim_reads(db, 24, 100)
+    _, H, T = oracle_objects(db)
+    rd = [r.seq for r in reads]
+
+    def engine_lists(dbx, opts, knob=None):
+        D = E.Database.from_synth(dbx); B = E.Batch(D, len(rd))
+        if knob:
+            B.set_knob(*knob)
+        B.set_knob("trace", 1)
+        B.set_reads(rd, vps); B.align(opts); B.get_seed(opts)
+        cnt, ids, sd, sN = B.seeds(); cd, st, en = B.codes()
+        B.close(); D.close()
+        return cnt, ids, cd, st, en
+    opts = E.default_opts(max_nseed=20, seed_order=1)
+    capfd.readouterr()
+    cnt, ids, cd, st, en = engine_lists(db, opts)
+    err = capfd.readouterr().err
+    assert re.search(r"k_seed_refsort: 24 reads.* 0 reads left to the host", err), err
+    cnt_h, ids_h, _, _, _ = engine_lists(db, opts, ("refsort_host", 1))
+    assert "k_seed_refsort" not in capfd.readouterr().err
+    assert (cnt == cnt_h).all() and (ids == ids_h).all()
+    for i in range(len(rd)):
+        oid, _, _, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), tie=1, max_n=20)
+        assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all(), i
+    differs = sum(not np.array_equal(ids[i, :cnt[i]], T.get_seed(cd[i], int(st[i]), int(en[i]), tie=0, max_n=20)[0]) for i in range(len(rd)))
+    assert differs > 0                                                      # the two orders are not the same thing on this tree
+    # (2) height filter
+    hmax = float(np.median(db.height))
+    opts_h = E.default_opts(max_nseed=20, seed_order=1, max_height=hmax)
+    cnt2, ids2, _, _, _ = engine_lists(db, opts_h)
+    for i in range(len(rd)):
+        oid, _, _, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_height=hmax, tie=1, max_n=20)
+        assert cnt2[i] == len(oid) and (ids2[i, :cnt2[i]] == oid).all(), i
+    # (3) partial sequences: NaN distances
+    dbp = copy.copy(db)
+    rng = np.random.default_rng(17)
+    seq = db.seq.copy()
+    for i in rng.choice(db.n_nodes, size=int(db.n_nodes * 0.5), replace=False):
+        cut = int(rng.integers(40, db.cs_len - 40))
+        if rng.random() < 0.5:
+            seq[i, :cut] = -2
+        else:
+            seq[i, cut:] = -2
+    dbp.seq = seq
+    _, Hp, Tp = oracle_objects(dbp)
+    capfd.readouterr()
+    cnt3, ids3, cd3, st3, en3 = engine_lists(dbp, opts)
+    m = re.search(r"k_seed_refsort: 24 reads.* (\d+) reads left to the host", capfd.readouterr().err)
+    assert m and int(m.group(1)) > 0
+    for i in range(len(rd)):
+        oid, _, _, _ = Tp.get_seed(cd3[i], int(st3[i]), int(en3[i]), tie=1, max_n=20)
+        assert cnt3[i] == len(oid) and (ids3[i, :cnt3[i]] == oid).all(), i
