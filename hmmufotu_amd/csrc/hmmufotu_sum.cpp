@@ -3,11 +3,16 @@
 // taxon_id column when Q_taxon >= -q and the identity filters pass; OTUs are written in node order with their taxonomy.
 //   hmmufotu-amd-sum <HmmUFOtu-DB> <INFILE [INFILE2 ...]> -o OTU-OUT [-r FILE] [-l FILE] [--use-dbname] [-q DBL] [--aln-iden DBL]
 //                    [--hmm-iden DBL] [-n INT] [-s INT] [-v]
-// Not here: -c (consensus sequences of the OTUs, Dirichlet-density inference), -t / --pseudo-tree (Newick export) — database-side
-// functions of the reference outside the assignment path; asking for them is an error, not a silent skip.
+//                    [-t OTU-TREE]
+// -t: the OTU tree (PTUnrooted::convertToNewickTree(getAncestors(otuSeen), prefix), src/PhyloTreeUnrooted.cpp:426-447, 1127-1133; NewickTree::write,
+// src/NewickTree.cpp:61-77): the tree cut down to the paths from the OTUs to the root — a node's children are written, all of them, when one
+// of them lies on such a path.
+// Not here: -c (consensus sequences of the OTUs: Dirichlet-density inference, training-side code of the reference) and --pseudo-tree (its new
+// node ids follow the iteration order of a hash set of pointers: not reproducible); asking for them is an error, not a silent skip.
 // Host only: the tree's annotations come from <DB>.ptu through hu_tree_info_* (messages read past), the profile map from <DB>.hmm.
 #include <algorithm>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -20,6 +25,7 @@ static void usage(const char* p) {
 		"INFILE          FILE           : assignment file(s) from hmmufotu / hmmufotu-amd, plain or .gz\n"
 		"Options:    -o  FILE           : OTU summary output, required\n"
 		"            -r  FILE           : output the read IDs for each OTU\n"
+		"            -t  FILE           : write the OTU tree into FILE\n"
 		"            -l  FILE           : sample name list, with 1st field sample-name and 2nd field assignment filename\n"
 		"            --use-dbname  FLAG : use DBNAME as prefix for OTUs\n"
 		"            -q  DBL            : minimum qTaxon score required [0]\n"
@@ -28,14 +34,14 @@ static void usage(const char* p) {
 		"            -n  INT            : minimum number of observed reads required to define an OTU across all samples [0]\n"
 		"            -s  INT            : minimum number of observed samples required to define an OTU [0]\n"
 		"            -v  FLAG           : verbose\n"
-		"            (-c, -t, --pseudo-tree of hmmufotu-sum are not provided)\n";
+		"            (-c and --pseudo-tree of hmmufotu-sum are not provided)\n";
 }
 
 /* a count as Eigen's IOFormat(FullPrecision) prints a double holding an integer (src/OTUTable.cpp:26, 161) */
 static std::string num(double v) { std::ostringstream o; o.precision(15); o << v; return o.str(); }
 
 int main(int argc, char** argv) {
-	std::vector<std::string> pos; std::string otuFn, readFn, listFn;
+	std::vector<std::string> pos; std::string otuFn, readFn, listFn, treeFn;
 	double minQ = 0, minAln = 0, minHmm = 0; int minRead = 0, minSample = 0, verbose = 0; bool useDb = false;
 	for(int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -47,7 +53,8 @@ int main(int argc, char** argv) {
 		else if(a == "-q") minQ = atof(val()); else if(a == "--aln-iden") minAln = atof(val()); else if(a == "--hmm-iden") minHmm = atof(val());
 		else if(a == "-n") minRead = atoi(val()); else if(a == "-s") minSample = atoi(val());
 		else if(a == "-e" || a == "--effN") (void) val();
-		else if(a == "-c" || a == "-t" || a == "--pseudo-tree") { std::cerr << "Error: " << a << " (OTU consensus sequences / trees) is not provided by hmmufotu-amd-sum" << std::endl; return EXIT_FAILURE; }
+		else if(a == "-t") treeFn = val();
+		else if(a == "-c" || a == "--pseudo-tree") { std::cerr << "Error: " << a << " (OTU consensus sequences / trees) is not provided by hmmufotu-amd-sum" << std::endl; return EXIT_FAILURE; }
 		else if(a == "--no-gap") { }
 		else if(a.compare(0, 2, "-v") == 0) verbose += (int) a.size() - 1;
 		else if(a[0] == '-' && a.size() > 1) { std::cerr << "Error: unknown option " << a << std::endl; usage(argv[0]); return EXIT_FAILURE; }
@@ -135,6 +142,25 @@ int main(int argc, char** argv) {
 	if(readOut.is_open()) { /* src/hmmufotu-sum.cpp:433-440; the info string starts without a blank there, too */
 		readOut << "# HmmUFOtu v1.5.1" << "OTU read info generated by " << argv[0] << std::endl;
 		for(int32_t u : kept) { readOut << prefix << u << "\t"; const std::vector<std::string>& r = reads[u]; for(size_t i = 0; i < r.size(); ++i) readOut << (i ? " " : "") << r[i]; readOut << std::endl; }
+	}
+	if(!treeFn.empty()) { /* src/hmmufotu-sum.cpp:462-466 */
+		std::ofstream treeOut(treeFn);
+		if(!treeOut) { std::cerr << "Unable to write to '" << treeFn << "'" << std::endl; return EXIT_FAILURE; }
+		int32_t root = 0;
+		hu_tree_info_get(ti, nullptr, nullptr, &root, nullptr);
+		std::vector<char> onPath((size_t) N, 0);                          /* getAncestors(otuSeen): the OTUs and everything above them */
+		for(int32_t u : kept) for(int32_t v = u; v >= 0 && !onPath[v]; ) { onPath[v] = 1; int32_t par = -1; hu_tree_info_node(ti, v, &par, nullptr, nullptr, nullptr, nullptr, nullptr); v = par; }
+		std::function<void(int32_t)> write = [&](int32_t u) {
+			const int32_t* ch = nullptr; const int nc = hu_tree_info_children(ti, u, &ch);
+			bool flag = false;
+			for(int i = 0; i < nc; ++i) flag |= onPath[ch[i]] != 0;
+			if(flag) { treeOut << '('; for(int i = 0; i < nc; ++i) { if(i) treeOut << ","; write(ch[i]); } treeOut << ')'; }
+			int32_t par = -1; double len = 0;
+			hu_tree_info_node(ti, u, &par, &len, nullptr, nullptr, nullptr, nullptr);
+			treeOut << prefix << u << ':' << (par < 0 ? 0.0 : len);         /* NewickTree::write: the length whenever it is >= 0, at ostream's default precision */
+		};
+		write(root);
+		treeOut << ';';
 	}
 	if(verbose) std::cerr << kept.size() << " OTUs over " << S << " sample(s)" << std::endl;
 	hu_tree_info_free(ti);
