@@ -1299,6 +1299,7 @@ static inline HuReadPlanes read_planes(const hu_batch* b) { return HuReadPlanes{
  * become order-isomorphic integer keys in node order, and hu_sort_prefix_packed leaves in the first max_nseed places what libstdc++'s
  * introsort would.  A read with a NaN distance (a node sharing no base with it: 0 / 0) takes the (dist, node id) order with NaN last —
  * std::sort is undefined there and the oracle falls back the same way.  Seeds, their (d, N) and their parents' go back to the device. */
+
 extern "C" int hu_sort_desc_device(int device, const double* keys, int rows, int n, int32_t* order) try {
 	if(!keys || !order || rows < 1 || n < 0 || n > HU_MAX_SEEDS) { hu_set_error("hu_sort_desc_device: bad argument"); return HU_ERR_ARG; }
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
@@ -1329,8 +1330,8 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	int rc;
 	if((rc = dPar.ensure(np)) != HU_OK || (rc = dSt.ensure(rows)) != HU_OK || (rc = dEn.ensure(rows)) != HU_OK || (rc = dCnt.ensure(rows)) != HU_OK ||
 			(rc = dId.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK || (rc = dDN.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK || (rc = dPN.ensure((size_t) rows * HU_MAX_SEEDS)) != HU_OK ||
-			(rc = dBail.ensure((size_t) rows + 1)) != HU_OK) return rc;
-	HIPCHK(hipMemset(dPar.p, 0, np * 4)); HIPCHK(hipMemset(dSt.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dEn.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dBail.p, 0, 4));
+			(rc = dBail.ensure((size_t) rows + 2)) != HU_OK) return rc;
+	HIPCHK(hipMemset(dPar.p, 0, np * 4)); HIPCHK(hipMemset(dSt.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dEn.p, 0, (size_t) rows * 4)); HIPCHK(hipMemset(dBail.p, 0, 8));
 	d.parent = dPar.p;
 	std::vector<uint32_t> h32; std::vector<uint16_t> h16;
 	if(pair16) {
@@ -1363,13 +1364,20 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(e1, nullptr));
 	HIPCHK(hipDeviceSynchronize());
-	if(getenv("HU_RS_TIMING")) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d rows x %lld elements, grid %d: %.3f ms\n", rows, (long long) n, G, ms); }
-	std::vector<int32_t> cnt(rows), ids((size_t) rows * HU_MAX_SEEDS), hb((size_t) rows + 1);
+	if(getenv("HU_RS_TIMING")) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d rows x %lld elements, grid %d: %.3f ms\n", rows, (long long) n, G, ms);
+#ifdef HU_RS_PROF
+		unsigned long long pr[16]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
+		static const char* nm[9] = {"idle/output", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher"};
+		for(int i = 0; i < 9; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
+		unsigned long long z[16] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
+#endif
+	}
+	std::vector<int32_t> cnt(rows), ids((size_t) rows * HU_MAX_SEEDS), hb((size_t) rows + 2);
 	HIPCHK(hipMemcpy(cnt.data(), dCnt.p, (size_t) rows * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(ids.data(), dId.p, ids.size() * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(hb.data(), dBail.p, hb.size() * 4, hipMemcpyDeviceToHost));
 	for(int r = 0; r < rows; ++r) { out_cnt[r] = cnt[r]; for(int s = 0; s < k; ++s) out_idx[(size_t) r * k + s] = s < cnt[r] ? ids[(size_t) r * HU_MAX_SEEDS + s] : -1; }
-	for(int i = 0; i < hb[0]; ++i) out_cnt[hb[1 + i]] = -1;
+	for(int i = 0; i < hb[0]; ++i) out_cnt[hb[2 + i]] = -1;
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_sort_prefix_device"); }
 
@@ -1386,11 +1394,11 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = rsOff + m0 / 2 + 64;
 	const size_t lds = hu_refsort_lds(d.nNodes);
 	if(lds > 150 * 1024) return seed_order_libstdcxx(b, o);
-	int G = std::min(n, 1024);
+	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
 	{ const size_t budget = (size_t) 5 << 30; const size_t perWg = 2 * cap * 8; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / perWg)); }
 	int rc;
-	if((rc = b->dRefScratch.ensure((size_t) G * 2 * cap)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 1)) != HU_OK) return rc;
-	HIPCHK(hipMemsetAsync(b->dBail.p, 0, 4, b->stream));
+	if((rc = b->dRefScratch.ensure((size_t) G * 2 * cap)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;
+	HIPCHK(hipMemsetAsync(b->dBail.p, 0, 8, b->stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	HuScope evg([&] { if(e0) (void) hipEventDestroy(e0); if(e1) (void) hipEventDestroy(e1); });
 	if(b->knob.trace) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, b->stream)); }
@@ -1406,12 +1414,12 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	}
 	HIPCHK(hipGetLastError());
 	if(e1) HIPCHK(hipEventRecord(e1, b->stream));
-	std::vector<int32_t> hb((size_t) n + 1);
-	HIPCHK(hipMemcpyAsync(hb.data(), b->dBail.p, ((size_t) n + 1) * 4, hipMemcpyDeviceToHost, b->stream));
+	std::vector<int32_t> hb((size_t) n + 2);
+	HIPCHK(hipMemcpyAsync(hb.data(), b->dBail.p, ((size_t) n + 2) * 4, hipMemcpyDeviceToHost, b->stream));
 	HIPCHK(hipStreamSynchronize(b->stream));
 	b->nRefBail = hb[0];
 	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", ms, hb[0]); }
-	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 1, hb.begin() + 1 + hb[0]); std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
+	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 2, hb.begin() + 2 + hb[0]); std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
 	return HU_OK;
 }
 

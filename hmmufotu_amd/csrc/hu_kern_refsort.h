@@ -19,28 +19,64 @@
 // Elements are 64-bit words (key << idBits | node): key = the leading bits of the double d / N, order-isomorphic to dist for d <= N < 2^16
 // while idBits <= 19 (33 mantissa bits: two different fractions differ by more than 2^-32 relative) or N <= 255 (any idBits <= 24).
 #pragma once
+#include <type_traits>
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 
 #define HU_RS_SMALL 512
 #define HU_RS_THREADS 512
 #define HU_RS_U 4                 /* elements per thread and loop trip of the streaming passes: their loads are in flight together */
+#ifndef HU_RS_WAVES_PER_EU
+#define HU_RS_WAVES_PER_EU 6          /* 512 threads = 2 waves per SIMD and workgroup: three workgroups per CU need <= 85 VGPRs */
+#endif
+#define HU_RS_TRIP (HU_RS_THREADS * HU_RS_U)
 #define HU_RS_FIN (HU_RS_SMALL + 96)        /* LDS array of the sequential finisher: the set-aside prefix (< 64 places) + the last range */
 
 struct HuRsRange { int lo, hi, depth; };
 
+#ifdef HU_RS_PROF     /* development only: cycles of thread 0 per phase, summed over the reads of every workgroup */
+__device__ unsigned long long g_rs_prof[16];
+#define RS_T(i) do { if(tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_rs_prof[i], now_ - t_prof); t_prof = now_; } } while(0)
+#else
+#define RS_T(i) do { } while(0)
+#endif
+
 __device__ inline uint64_t rs_lane_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ inline uint64_t rs_lane_ge(int lane) { return ~0ull << lane; }
 
+/* An element is (d << 48 | N << 32 | node): the pair as the scan left it beside its position in node order.  dist = d / N as the reference
+ * computes it is a correctly rounded double division of two integers below 2^16: equal fractions give equal doubles and different fractions
+ * different ones (they differ by at least 2^-32 relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers, and no
+ * division in the streaming passes.  The sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives. */
+__device__ inline bool rs_lt(uint64_t a, uint64_t b) {
+	const uint32_t pa = (uint32_t)(a >> 32), pb = (uint32_t)(b >> 32);
+	return (pa >> 16) * (pb & 0xffffu) < (pb >> 16) * (pa & 0xffffu);
+}
 /* element of position p of the level-0 array: node order without the root */
 template<class PT>
-__device__ __attribute__((noinline)) uint64_t rs_elem0(const PT* __restrict__ row, int root, int p, int idBits, bool& nan) {
+__device__ inline uint64_t rs_elem0(const PT* __restrict__ row, int root, int p, bool& nan) {
 	const int node = p < root ? p : p + 1;
 	const uint32_t pr = HuPair<PT>::canon(row[node]);
-	const uint32_t d = pr >> 16, N = pr & 0xffffu;
-	if(N == 0) { nan = true; return (~0ull << idBits) | (uint64_t) node; }
-	const unsigned long long bits = (unsigned long long) __double_as_longlong((double) d / (double) N);
-	return ((bits >> idBits) << idBits) | (uint64_t) node;
+	nan |= (pr & 0xffffu) == 0;
+	return ((uint64_t) pr << 32) | (uint64_t)(uint32_t) node;
+}
+/* The streaming passes load through rs_load: no branch between the loads of one trip (the level is a template argument, the two patches
+ * of level 0 are selects), so that the HU_RS_U loads of a thread are in flight together — behind a divergent branch each one is waited for
+ * before the next is issued. */
+template<bool L0, class PT>
+__device__ inline uint64_t rs_load(const unsigned long long* __restrict__ src, const PT* __restrict__ row, int root, int p,
+		int pA, uint64_t vA, int pB, uint64_t vB, bool& nan) {
+	if(!L0) return src[p];
+	uint64_t e = rs_elem0(row, root, p, nan);
+	e = p == pA ? vA : e;
+	e = p == pB ? vB : e;
+	return e;
+}
+/* key of an element for the finisher: the leading bits of the double d / N above the node id */
+__device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e, int idBits) {
+	const uint32_t pr = (uint32_t)(e >> 32);
+	const unsigned long long bits = (unsigned long long) __double_as_longlong((double)(pr >> 16) / (double)(pr & 0xffffu));
+	return ((bits >> idBits) << idBits) | (e & 0xffffffffull);
 }
 
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
@@ -85,7 +121,7 @@ __device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* L
 }
 
 template<class PT>
-__global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
+__global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K, int idBits,
 		unsigned long long* __restrict__ scratch, size_t cap, int rsOff,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
@@ -97,14 +133,24 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 	uint64_t* lsb = fin + HU_RS_FIN;                                       /* [64]: left stoppers of a tiny left part */
 	uint32_t* preL = reinterpret_cast<uint32_t*>(lsb + 64);                /* [NT + 2] */
 	uint32_t* sufR = preL + (NT + 2);                                      /* [NT + 2] */
-	__shared__ uint32_t part[HU_RS_THREADS];
+	__shared__ unsigned long long wtot[HU_RS_THREADS / 64];
 	__shared__ uint64_t shE[4];              /* pivot element, patch values */
 	__shared__ int shI[12];                  /* broadcast slots */
 	__shared__ HuRsRange stash[12];
 	__shared__ int seqStack[72];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for(int read = blockIdx.x; read < nReads; read += gridDim.x) {
+#ifdef HU_RS_PROF
+	unsigned long long t_prof = wall_clock64();
+#endif
+	/* reads are handed out through a counter (bail[1]): their cost differs with the pivots they meet, and the last ones do not wait for the
+	 * slowest workgroup of a fixed schedule */
+	for(;;) {
 		__syncthreads();
+		if(tid == 0) shI[6] = atomicAdd(&bail[1], 1);
+		__syncthreads();
+		const int read = shI[6];
+		if(read >= nReads) break;
+		RS_T(0);
 		if(rend[read] < rstart[read] || m0 < 1) { if(tid == 0) seedCnt[read] = 0; continue; }
 		const PT* __restrict__ row = pairs + (size_t) read * db.nNodesPad;
 		unsigned long long* bufA = scratch + (size_t) blockIdx.x * 2 * cap;
@@ -120,7 +166,7 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 			if(src) return src[p];
 			if(p == pA) return vA;
 			if(p == pB) return vB;
-			return rs_elem0(row, db.root, p, idBits, nan);
+			return rs_elem0(row, db.root, p, nan);
 		};
 		while(hi - lo > HU_RS_SMALL) {
 			if(depth == 0) { failed = true; break; }
@@ -129,57 +175,63 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 			if(tid == 0) {
 				const int mid = lo + (hi - lo) / 2;
 				const uint64_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
-				const uint64_t x = ea >> idBits, y = eb >> idBits, z = ec >> idBits;
 				int w; uint64_t ew;
-				if(x < y) { if(y < z) { w = mid; ew = eb; } else if(x < z) { w = hi - 1; ew = ec; } else { w = lo + 1; ew = ea; } }
-				else if(x < z) { w = lo + 1; ew = ea; }
-				else if(y < z) { w = hi - 1; ew = ec; }
+				if(rs_lt(ea, eb)) { if(rs_lt(eb, ec)) { w = mid; ew = eb; } else if(rs_lt(ea, ec)) { w = hi - 1; ew = ec; } else { w = lo + 1; ew = ea; } }
+				else if(rs_lt(ea, ec)) { w = lo + 1; ew = ea; }
+				else if(rs_lt(eb, ec)) { w = hi - 1; ew = ec; }
 				else { w = mid; ew = eb; }
 				shE[0] = ew; shE[1] = ef; shI[0] = w;
 				if(src) { const_cast<unsigned long long*>(src)[lo] = ew; const_cast<unsigned long long*>(src)[w] = ef; }
 			}
 			__threadfence_block();
 			__syncthreads();
+			RS_T(1);
 			const uint64_t pivE = shE[0];
 			if(!src) { pA = lo; vA = pivE; pB = shI[0]; vB = shE[1]; }
-			const uint64_t pk = pivE >> idBits;
 			const int M = hi - lo - 1, NTl = (M + 63) >> 6;
 			/* ---- pass A: stoppers per subtile of 64 positions q = p - (lo + 1) */
-			for(int base = 0; base < M; base += HU_RS_THREADS * HU_RS_U) {
-				uint64_t ev[HU_RS_U];
+			auto passA = [&](auto l0) {
+				constexpr bool L0 = decltype(l0)::value;
+				for(int base = 0; base < M; base += HU_RS_TRIP) {
+					uint64_t ev[HU_RS_U];
 #pragma unroll
-				for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < M ? E(lo + 1 + q) : 0; }
+					for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
-				for(int u = 0; u < HU_RS_U; ++u) {
-					const int qb = base + u * HU_RS_THREADS, q = qb + tid;
-					const bool valid = q < M;
-					const uint64_t k = ev[u] >> idBits;
-					const unsigned long long mL = __ballot(valid && !(k < pk)), mR = __ballot(valid && !(pk < k));
-					if(lane == 0 && qb + wave * 64 < M) { preL[(qb >> 6) + wave] = (uint32_t) __popcll(mL); sufR[(qb >> 6) + wave] = (uint32_t) __popcll(mR); }
+					for(int u = 0; u < HU_RS_U; ++u) {
+						const int qb = base + u * HU_RS_THREADS, q = qb + tid;
+						const bool valid = q < M;
+						const unsigned long long mL = __ballot(valid && !rs_lt(ev[u], pivE)), mR = __ballot(valid && !rs_lt(pivE, ev[u]));
+						if(lane == 0 && qb + wave * 64 < M) { preL[(qb >> 6) + wave] = (uint32_t) __popcll(mL); sufR[(qb >> 6) + wave] = (uint32_t) __popcll(mR); }
+					}
 				}
-			}
+			};
+			if(src) passA(std::false_type{}); else passA(std::true_type{});
 			if(__syncthreads_or(nan ? 1 : 0)) { failed = true; break; }
+			RS_T(2);
 			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
 			{
 				const int per = (NTl + HU_RS_THREADS - 1) / HU_RS_THREADS, a0 = tid * per, a1 = min(NTl, a0 + per);
 				uint32_t sL = 0, sR = 0;
 				for(int t = a0; t < a1; ++t) { sL += preL[t]; sR += sufR[t]; }
-				part[tid] = sL;
+				/* both sums in one 64-bit word through one scan: inclusive within the wave on __shfl_up, the waves' totals through LDS */
+				unsigned long long w = (unsigned long long) sL | ((unsigned long long) sR << 32);
+#pragma unroll
+				for(int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(w, o); if(lane >= o) w += t; }
+				if(lane == 63) wtot[wave] = w;
 				__syncthreads();
-				if(tid == 0) { uint32_t acc = 0; for(int i = 0; i < HU_RS_THREADS; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } shI[1] = (int) acc; }
-				__syncthreads();
-				uint32_t accL = part[tid];
-				__syncthreads();
-				part[tid] = sR;
-				__syncthreads();
-				if(tid == 0) { uint32_t acc = 0; for(int i = HU_RS_THREADS - 1; i >= 0; --i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } }
-				__syncthreads();
-				uint32_t accR = part[tid];     /* right stoppers in the chunks after this thread's */
+				unsigned long long before = 0, total = 0;
+#pragma unroll
+				for(int x = 0; x < HU_RS_THREADS / 64; ++x) { const unsigned long long t = wtot[x]; if(x < wave) before += t; total += t; }
+				w += before;                                             /* inclusive prefix over the threads */
+				uint32_t accL = (uint32_t) w - sL;                       /* left stoppers in the chunks before this thread's */
+				uint32_t accR = (uint32_t)(total >> 32) - (uint32_t)(w >> 32);     /* right stoppers in the chunks after it */
+				if(tid == 0) shI[1] = (int)(uint32_t) total;
 				for(int t = a0; t < a1; ++t) { const uint32_t v = preL[t]; preL[t] = accL; accL += v; }
 				for(int t = a1 - 1; t >= a0; --t) { accR += sufR[t]; sufR[t] = accR; }
 				if(tid == 0) { preL[NTl] = (uint32_t) shI[1]; sufR[NTl] = 0; }
 				__syncthreads();
 			}
+			RS_T(3);
 			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
 			 * the swapped pairs are the left stoppers with g < 0; c0 = the first position with g >= 0 */
 			if(wave == 0) {
@@ -188,8 +240,8 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
 				auto masks = [&](int t, unsigned long long& mL, unsigned long long& mR) {
 					const int q = t * 64 + lane; const bool valid = q < M;
-					const uint64_t k = valid ? (E(lo + 1 + q) >> idBits) : 0;
-					mL = __ballot(valid && !(k < pk)); mR = __ballot(valid && !(pk < k));
+					const uint64_t e = valid ? E(lo + 1 + q) : 0;
+					mL = __ballot(valid && !rs_lt(e, pivE)); mR = __ballot(valid && !rs_lt(pivE, e));
 				};
 				unsigned long long mL, mR;
 				masks(t0, mL, mR);
@@ -223,44 +275,57 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 				if(lane == 0) { shI[2] = cutq; shI[3] = m; shI[4] = jm; }
 			}
 			__syncthreads();
+			RS_T(4);
 			const int cutq = shI[2], m = shI[3], jm = shI[4];
 			if(cutq < 0) { failed = true; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
 			const int cutAbs = lo + 1 + cutq;
 			unsigned long long* RS = dst + rsOff;                    /* right stoppers by rank, beyond the positions */
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
-			if(m >= 1) {
-				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_THREADS * HU_RS_U) {
+			auto passB1 = [&](auto l0) {
+				constexpr bool L0 = decltype(l0)::value;
+				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_TRIP) {
 					uint64_t ev[HU_RS_U];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < M ? E(lo + 1 + q) : 0; }
+					for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
 					for(int u = 0; u < HU_RS_U; ++u) {
 						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-						const bool rs = q < M && !(pk < (ev[u] >> idBits));
+						const bool rs = q < M && !rs_lt(pivE, ev[u]);
 						const unsigned long long mR = __ballot(rs);
 						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) RS[rk - 1] = ev[u]; }
 					}
 				}
-			}
+			};
+			if(m >= 1) { if(src) passB1(std::false_type{}); else passB1(std::true_type{}); }
 			__threadfence_block();
 			__syncthreads();
+			RS_T(5);
 			const bool tiny = cutAbs < K;        /* the left part ends inside the first K places: the right part is needed too */
 			if(!tiny) {
 				/* ---- pass B2: the left part [lo, cut) of the next level */
 				if(tid == 0) dst[lo] = pivE;
-				for(int base = 0; base < cutq; base += HU_RS_THREADS * HU_RS_U) {
-					uint64_t ev[HU_RS_U];
+				auto passB2 = [&](auto l0) {
+					constexpr bool L0 = decltype(l0)::value;
+					for(int base = 0; base < cutq; base += HU_RS_TRIP) {
+						uint64_t ev[HU_RS_U], rv[HU_RS_U];
+						bool lsv[HU_RS_U];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) { const int q = base + u * HU_RS_THREADS + tid; ev[u] = q < cutq ? E(lo + 1 + q) : 0; }
+						for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) {
-						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-						const bool valid = q < cutq;
-						const bool ls = valid && !((ev[u] >> idBits) < pk);
-						const unsigned long long mL = __ballot(ls);
-						if(valid) dst[lo + 1 + q] = ls ? RS[(int) preL[t] + __popcll(mL & rs_lane_lt(lane))] : ev[u];
+						for(int u = 0; u < HU_RS_U; ++u) {       /* a left stopper takes the right stopper of its rank; the others read RS[0] (one address) */
+							const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
+							lsv[u] = q < cutq && !rs_lt(ev[u], pivE);
+							const unsigned long long mL = __ballot(lsv[u]);
+							rv[u] = RS[lsv[u] ? (int) preL[min(t, NTl)] + __popcll(mL & rs_lane_lt(lane)) : 0];
+						}
+#pragma unroll
+						for(int u = 0; u < HU_RS_U; ++u) {
+							const int q = base + u * HU_RS_THREADS + tid;
+							if(q < cutq) dst[lo + 1 + q] = lsv[u] ? rv[u] : ev[u];
+						}
 					}
-				}
+				};
+				if(src) passB2(std::false_type{}); else passB2(std::true_type{});
 				hi = cutAbs;
 			}
 			else {
@@ -268,12 +333,12 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 				if(tid < 64) {
 					const int q = tid; const bool valid = q < cutq;
 					const uint64_t e = valid ? E(lo + 1 + q) : 0;
-					const bool ls = valid && !((e >> idBits) < pk);
+					const bool ls = valid && !rs_lt(e, pivE);
 					const unsigned long long mL = __ballot(ls);
 					const int k = __popcll(mL & rs_lane_lt(lane));
 					if(ls) lsb[k] = e;
-					if(valid) fin[lo + 1 + q] = ls ? RS[k] : e;
-					if(tid == 0) { fin[lo] = pivE; if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
+					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS[k] : e, idBits);
+					if(tid == 0) { fin[lo] = rs_key(pivE, idBits); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
 				}
 				__syncthreads();
 				if(nStash >= 12) { failed = true; break; }
@@ -283,7 +348,7 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 					const int q = base + tid, t = q >> 6;
 					const bool valid = q < M;
 					const uint64_t e = valid ? E(lo + 1 + q) : 0;
-					const bool rs = valid && !(pk < (e >> idBits));
+					const bool rs = valid && !rs_lt(pivE, e);
 					const unsigned long long mR = __ballot(rs);
 					if(valid && q >= cutq) {
 						const int rk = rs ? (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)) : 0;
@@ -294,16 +359,18 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 			}
 			__threadfence_block();
 			__syncthreads();
+			RS_T(6);
 			src = dst; dst = (dst == bufA) ? bufB : bufA;
 			pA = pB = -1;
 		}
 		if(__syncthreads_or((failed || nan) ? 1 : 0)) { /* the host path finishes this read */
-			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; }
+			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; }
 			continue;
 		}
 		/* ---- the last range into LDS beside the set-aside prefix; one thread finishes with the literal algorithm */
-		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) fin[p] = E(p);
-		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; } continue; }
+		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint64_t e = E(p); if(!nan) fin[p] = rs_key(e, idBits); }
+		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; } continue; }
+		RS_T(7);
 		if(tid == 0) {
 			bool ok = true;
 			for(int s = 0; s < nStash && ok; ++s) ok = rs_seq_loop(fin, seqStack, stash[s].lo, stash[s].hi, stash[s].depth, K, idBits);
@@ -319,7 +386,8 @@ __global__ __launch_bounds__(HU_RS_THREADS) void k_seed_refsort(HuDbDev db, cons
 			shI[5] = ok ? 1 : 0;
 		}
 		__syncthreads();
-		if(!shI[5]) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[1 + at] = read; } continue; }
+		RS_T(8);
+		if(!shI[5]) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; } continue; }
 		const int keep = min(K, hi);
 		if(tid == 0) seedCnt[read] = keep;
 		if(tid < keep) {
