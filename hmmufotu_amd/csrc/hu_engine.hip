@@ -1346,9 +1346,9 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 		if((rc = dP32.ensure(h32.size())) != HU_OK) return rc;
 		HIPCHK(hipMemcpy(dP32.p, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
 	}
-	const size_t m0 = (size_t) n, rsOff = (m0 + 63) & ~(size_t) 63, cap = rsOff + m0 / 2 + 64, lds = hu_refsort_lds(d.nNodes);
-	const int G = std::min(rows, getenv("HU_RS_GRID") ? atoi(getenv("HU_RS_GRID")) : 256);
-	if((rc = scr.ensure((size_t) G * 2 * cap)) != HU_OK) return rc;
+	const size_t m0 = (size_t) n, rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0), lds = hu_refsort_lds(d.nNodes);
+	const int G = std::min(rows, getenv("HU_RS_GRID") ? atoi(getenv("HU_RS_GRID")) : 768);
+	if((rc = scr.ensure((size_t) G * hu_refsort_words(m0, pair16 ? 2 : 4))) != HU_OK) return rc;
 	(void) hipGetLastError();
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HuScope evg([&] { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); });
@@ -1391,13 +1391,14 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	int idBits = 1; while((1 << idBits) < d.nNodes) ++idBits;
 	if(b->knob.refsort_host || o->max_height != INFINITY || (!b->pair16 && idBits > 19) || idBits > 24 || d.nNodes < 3) return seed_order_libstdcxx(b, o);
 	const size_t m0 = (size_t) d.nNodes - 1;
-	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = rsOff + m0 / 2 + 64;
+	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
 	if(lds > 150 * 1024) return seed_order_libstdcxx(b, o);
 	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
-	{ const size_t budget = (size_t) 5 << 30; const size_t perWg = 2 * cap * 8; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / perWg)); }
+	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
+	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
 	int rc;
-	if((rc = b->dRefScratch.ensure((size_t) G * 2 * cap)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;
+	if((rc = b->dRefScratch.ensure((size_t) G * perWg)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;
 	HIPCHK(hipMemsetAsync(b->dBail.p, 0, 8, b->stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	HuScope evg([&] { if(e0) (void) hipEventDestroy(e0); if(e1) (void) hipEventDestroy(e1); });

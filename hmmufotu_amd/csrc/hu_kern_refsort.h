@@ -25,7 +25,9 @@
 
 #define HU_RS_SMALL 512
 #define HU_RS_THREADS 512
+#ifndef HU_RS_U
 #define HU_RS_U 4                 /* elements per thread and loop trip of the streaming passes: their loads are in flight together */
+#endif
 #ifndef HU_RS_WAVES_PER_EU
 #define HU_RS_WAVES_PER_EU 6          /* 512 threads = 2 waves per SIMD and workgroup: three workgroups per CU need <= 85 VGPRs */
 #endif
@@ -44,33 +46,38 @@ __device__ unsigned long long g_rs_prof[16];
 __device__ inline uint64_t rs_lane_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ inline uint64_t rs_lane_ge(int lane) { return ~0ull << lane; }
 
-/* An element is (d << 48 | N << 32 | node): the pair as the scan left it beside its position in node order.  dist = d / N as the reference
- * computes it is a correctly rounded double division of two integers below 2^16: equal fractions give equal doubles and different fractions
- * different ones (they differ by at least 2^-32 relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers, and no
- * division in the streaming passes.  The sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives. */
-__device__ inline bool rs_lt(uint64_t a, uint64_t b) {
-	const uint32_t pa = (uint32_t)(a >> 32), pb = (uint32_t)(b >> 32);
-	return (pa >> 16) * (pb & 0xffffu) < (pb >> 16) * (pa & 0xffffu);
-}
-/* element of position p of the level-0 array: node order without the root */
-template<class PT>
-__device__ inline uint64_t rs_elem0(const PT* __restrict__ row, int root, int p, bool& nan) {
-	const int node = p < root ? p : p + 1;
-	const uint32_t pr = HuPair<PT>::canon(row[node]);
-	nan |= (pr & 0xffffu) == 0;
-	return ((uint64_t) pr << 32) | (uint64_t)(uint32_t) node;
-}
-/* The streaming passes load through rs_load: no branch between the loads of one trip (the level is a template argument, the two patches
- * of level 0 are selects), so that the HU_RS_U loads of a thread are in flight together — behind a divergent branch each one is waited for
- * before the next is issued. */
+/* An element is (d << 48 | N << 32 | node) in registers: the pair as the scan left it beside its position in node order.  dist = d / N as the
+ * reference computes it is a correctly rounded double division of two integers below 2^16: equal fractions give equal doubles and different
+ * fractions different ones (they differ by at least 2^-32 relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers,
+ * and no division in the streaming passes.  The sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives.
+ * In memory a level is two arrays — the pairs in the width the scan wrote them (2 or 4 bytes) and the node ids (4 bytes): the counting pass
+ * reads the pairs only. */
+__device__ inline bool rs_ltp(uint32_t pa, uint32_t pb) { return (pa >> 16) * (pb & 0xffffu) < (pb >> 16) * (pa & 0xffffu); }
+__device__ inline bool rs_lt(uint64_t a, uint64_t b) { return rs_ltp((uint32_t)(a >> 32), (uint32_t)(b >> 32)); }
+template<class PT> struct HuRsLevel {          /* one level in the workgroup's scratch: [cap] ids, [cap] pairs; positions are absolute */
+	uint32_t* ids; PT* keys;
+	__device__ inline uint64_t load(int p) const { return ((uint64_t) HuPair<PT>::canon(keys[p]) << 32) | (uint64_t) ids[p]; }
+	__device__ inline void store(int p, uint64_t e) const { keys[p] = HuPair<PT>::pack((uint32_t)(e >> 32)); ids[p] = (uint32_t) e; }
+};
+/* The streaming passes load through rs_pair / rs_node: no branch between the loads of one trip (the level is a template argument, the two
+ * patches of level 0 are selects), so that the loads of a thread are in flight together — behind a divergent branch each one is waited for
+ * before the next is issued.  Level 0 is the row itself in node order without the root. */
 template<bool L0, class PT>
-__device__ inline uint64_t rs_load(const unsigned long long* __restrict__ src, const PT* __restrict__ row, int root, int p,
-		int pA, uint64_t vA, int pB, uint64_t vB, bool& nan) {
-	if(!L0) return src[p];
-	uint64_t e = rs_elem0(row, root, p, nan);
-	e = p == pA ? vA : e;
-	e = p == pB ? vB : e;
-	return e;
+__device__ inline uint32_t rs_pair(const HuRsLevel<PT>& src, const PT* __restrict__ row, int root, int p, int pA, uint64_t vA, int pB, uint64_t vB, bool& nan) {
+	if(!L0) return HuPair<PT>::canon(src.keys[p]);
+	uint32_t pr = HuPair<PT>::canon(row[p < root ? p : p + 1]);
+	nan |= (pr & 0xffffu) == 0;
+	pr = p == pA ? (uint32_t)(vA >> 32) : pr;
+	pr = p == pB ? (uint32_t)(vB >> 32) : pr;
+	return pr;
+}
+template<bool L0, class PT>
+__device__ inline uint32_t rs_node(const HuRsLevel<PT>& src, int root, int p, int pA, uint64_t vA, int pB, uint64_t vB) {
+	if(!L0) return src.ids[p];
+	uint32_t id = (uint32_t)(p < root ? p : p + 1);
+	id = p == pA ? (uint32_t) vA : id;
+	id = p == pB ? (uint32_t) vB : id;
+	return id;
 }
 /* key of an element for the finisher: the leading bits of the double d / N above the node id */
 __device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e, int idBits) {
@@ -79,6 +86,10 @@ __device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e, int idBits) {
 	return ((bits >> idBits) << idBits) | (e & 0xffffffffull);
 }
 
+/* scratch of one workgroup: two levels of cap positions (the m0 positions, then room for the right stoppers of a partition: at most half of
+ * them are swapped), each a 4-byte id array and a pairBytes-wide pair array; in 8-byte words */
+static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 63) + m0 / 2 + 64 + 63) & ~(size_t) 63; }
+static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return 2 * hu_refsort_cap(m0) * (4 + (size_t) pairBytes) / 8; }
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
 static inline size_t hu_refsort_lds(int nNodes) { const size_t NT = ((size_t) nNodes - 1 + 63) / 64; return (HU_RS_FIN + 64) * 8 + 2 * (NT + 2) * 4; }
 
@@ -153,20 +164,23 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		RS_T(0);
 		if(rend[read] < rstart[read] || m0 < 1) { if(tid == 0) seedCnt[read] = 0; continue; }
 		const PT* __restrict__ row = pairs + (size_t) read * db.nNodesPad;
-		unsigned long long* bufA = scratch + (size_t) blockIdx.x * 2 * cap;
-		unsigned long long* bufB = bufA + cap;
-		const unsigned long long* src = nullptr;        /* nullptr: the implicit level-0 array */
-		unsigned long long* dst = bufA;
+		HuRsLevel<PT> bufA, bufB;
+		{
+			unsigned char* base = reinterpret_cast<unsigned char*>(scratch) + (size_t) blockIdx.x * 2 * cap * (4 + sizeof(PT));
+			bufA.ids = reinterpret_cast<uint32_t*>(base); bufA.keys = reinterpret_cast<PT*>(base + cap * 4);
+			base += cap * (4 + sizeof(PT));
+			bufB.ids = reinterpret_cast<uint32_t*>(base); bufB.keys = reinterpret_cast<PT*>(base + cap * 4);
+		}
+		HuRsLevel<PT> src = {nullptr, nullptr}, dst = bufA;       /* src.ids == nullptr: the implicit level-0 array */
+		bool level0 = true;
 		int lo = 0, hi = m0, depth = 0, nStash = 0;
 		for(int x = m0; x > 1; x >>= 1) ++depth;
 		depth *= 2;
 		int pA = -1, pB = -1; uint64_t vA = 0, vB = 0;   /* level 0: the one swap of the pivot selection, kept as two patches */
 		bool failed = false, nan = false;
-		auto E = [&](int p) -> uint64_t {
-			if(src) return src[p];
-			if(p == pA) return vA;
-			if(p == pB) return vB;
-			return rs_elem0(row, db.root, p, nan);
+		auto E = [&](int p) -> uint64_t {                /* any element, off the streaming passes */
+			if(!level0) return src.load(p);
+			return ((uint64_t) rs_pair<true>(src, row, db.root, p, pA, vA, pB, vB, nan) << 32) | (uint64_t) rs_node<true>(src, db.root, p, pA, vA, pB, vB);
 		};
 		while(hi - lo > HU_RS_SMALL) {
 			if(depth == 0) { failed = true; break; }
@@ -181,31 +195,32 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				else if(rs_lt(eb, ec)) { w = hi - 1; ew = ec; }
 				else { w = mid; ew = eb; }
 				shE[0] = ew; shE[1] = ef; shI[0] = w;
-				if(src) { const_cast<unsigned long long*>(src)[lo] = ew; const_cast<unsigned long long*>(src)[w] = ef; }
+				if(!level0) { src.store(lo, ew); src.store(w, ef); }
 			}
 			__threadfence_block();
 			__syncthreads();
 			RS_T(1);
 			const uint64_t pivE = shE[0];
-			if(!src) { pA = lo; vA = pivE; pB = shI[0]; vB = shE[1]; }
+			if(level0) { pA = lo; vA = pivE; pB = shI[0]; vB = shE[1]; }
+			const uint32_t pivP = (uint32_t)(pivE >> 32);
 			const int M = hi - lo - 1, NTl = (M + 63) >> 6;
 			/* ---- pass A: stoppers per subtile of 64 positions q = p - (lo + 1) */
 			auto passA = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
 				for(int base = 0; base < M; base += HU_RS_TRIP) {
-					uint64_t ev[HU_RS_U];
+					uint32_t kv[HU_RS_U];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+					for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
 					for(int u = 0; u < HU_RS_U; ++u) {
 						const int qb = base + u * HU_RS_THREADS, q = qb + tid;
 						const bool valid = q < M;
-						const unsigned long long mL = __ballot(valid && !rs_lt(ev[u], pivE)), mR = __ballot(valid && !rs_lt(pivE, ev[u]));
+						const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], pivP)), mR = __ballot(valid && !rs_ltp(pivP, kv[u]));
 						if(lane == 0 && qb + wave * 64 < M) { preL[(qb >> 6) + wave] = (uint32_t) __popcll(mL); sufR[(qb >> 6) + wave] = (uint32_t) __popcll(mR); }
 					}
 				}
 			};
-			if(src) passA(std::false_type{}); else passA(std::true_type{});
+			if(level0) passA(std::true_type{}); else passA(std::false_type{});
 			if(__syncthreads_or(nan ? 1 : 0)) { failed = true; break; }
 			RS_T(2);
 			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
@@ -240,8 +255,8 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
 				auto masks = [&](int t, unsigned long long& mL, unsigned long long& mR) {
 					const int q = t * 64 + lane; const bool valid = q < M;
-					const uint64_t e = valid ? E(lo + 1 + q) : 0;
-					mL = __ballot(valid && !rs_lt(e, pivE)); mR = __ballot(valid && !rs_lt(pivE, e));
+					const uint32_t k = valid ? (uint32_t)(E(lo + 1 + q) >> 32) : 0;
+					mL = __ballot(valid && !rs_ltp(k, pivP)); mR = __ballot(valid && !rs_ltp(pivP, k));
 				};
 				unsigned long long mL, mR;
 				masks(t0, mL, mR);
@@ -279,53 +294,66 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			const int cutq = shI[2], m = shI[3], jm = shI[4];
 			if(cutq < 0) { failed = true; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
 			const int cutAbs = lo + 1 + cutq;
-			unsigned long long* RS = dst + rsOff;                    /* right stoppers by rank, beyond the positions */
+			const HuRsLevel<PT> RS = {dst.ids + rsOff, dst.keys + rsOff};        /* right stoppers by rank, beyond the positions */
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
 				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_TRIP) {
-					uint64_t ev[HU_RS_U];
+					uint32_t kv[HU_RS_U], iv[HU_RS_U];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+					for(int u = 0; u < HU_RS_U; ++u) {
+						const int p = lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1);
+						kv[u] = rs_pair<L0>(src, row, db.root, p, pA, vA, pB, vB, nan);
+						iv[u] = rs_node<L0>(src, db.root, p, pA, vA, pB, vB);
+					}
 #pragma unroll
 					for(int u = 0; u < HU_RS_U; ++u) {
 						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-						const bool rs = q < M && !rs_lt(pivE, ev[u]);
+						const bool rs = q < M && !rs_ltp(pivP, kv[u]);
 						const unsigned long long mR = __ballot(rs);
-						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) RS[rk - 1] = ev[u]; }
+						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) { RS.keys[rk - 1] = HuPair<PT>::pack(kv[u]); RS.ids[rk - 1] = iv[u]; } }
 					}
 				}
 			};
-			if(m >= 1) { if(src) passB1(std::false_type{}); else passB1(std::true_type{}); }
+			if(m >= 1) { if(level0) passB1(std::true_type{}); else passB1(std::false_type{}); }
 			__threadfence_block();
 			__syncthreads();
 			RS_T(5);
 			const bool tiny = cutAbs < K;        /* the left part ends inside the first K places: the right part is needed too */
 			if(!tiny) {
 				/* ---- pass B2: the left part [lo, cut) of the next level */
-				if(tid == 0) dst[lo] = pivE;
+				if(tid == 0) dst.store(lo, pivE);
 				auto passB2 = [&](auto l0) {
 					constexpr bool L0 = decltype(l0)::value;
 					for(int base = 0; base < cutq; base += HU_RS_TRIP) {
-						uint64_t ev[HU_RS_U], rv[HU_RS_U];
-						bool lsv[HU_RS_U];
+						uint32_t kv[HU_RS_U], iv[HU_RS_U]; int rr[HU_RS_U];
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) ev[u] = rs_load<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+						for(int u = 0; u < HU_RS_U; ++u) {
+							const int p = lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1);
+							kv[u] = rs_pair<L0>(src, row, db.root, p, pA, vA, pB, vB, nan);
+							iv[u] = rs_node<L0>(src, db.root, p, pA, vA, pB, vB);
+						}
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {       /* a left stopper takes the right stopper of its rank; the others read RS[0] (one address) */
+						for(int u = 0; u < HU_RS_U; ++u) {       /* a left stopper takes the right stopper of its rank */
 							const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-							lsv[u] = q < cutq && !rs_lt(ev[u], pivE);
-							const unsigned long long mL = __ballot(lsv[u]);
-							rv[u] = RS[lsv[u] ? (int) preL[min(t, NTl)] + __popcll(mL & rs_lane_lt(lane)) : 0];
+							const bool ls = q < cutq && !rs_ltp(kv[u], pivP);
+							const unsigned long long mL = __ballot(ls);
+							rr[u] = ls ? (int) preL[min(t, NTl)] + __popcll(mL & rs_lane_lt(lane)) : -1;
+						}
+#pragma unroll
+						for(int u = 0; u < HU_RS_U; ++u) {       /* the others read RS[0] (one address) and keep their own: no branch around the loads */
+							const int ri = max(rr[u], 0);
+							const uint32_t rk = HuPair<PT>::canon(RS.keys[ri]), rid = RS.ids[ri];
+							kv[u] = rr[u] >= 0 ? rk : kv[u]; iv[u] = rr[u] >= 0 ? rid : iv[u];
 						}
 #pragma unroll
 						for(int u = 0; u < HU_RS_U; ++u) {
 							const int q = base + u * HU_RS_THREADS + tid;
-							if(q < cutq) dst[lo + 1 + q] = lsv[u] ? rv[u] : ev[u];
+							if(q < cutq) { dst.keys[lo + 1 + q] = HuPair<PT>::pack(kv[u]); dst.ids[lo + 1 + q] = iv[u]; }
 						}
 					}
 				};
-				if(src) passB2(std::false_type{}); else passB2(std::true_type{});
+				if(level0) passB2(std::true_type{}); else passB2(std::false_type{});
 				hi = cutAbs;
 			}
 			else {
@@ -337,7 +365,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const unsigned long long mL = __ballot(ls);
 					const int k = __popcll(mL & rs_lane_lt(lane));
 					if(ls) lsb[k] = e;
-					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS[k] : e, idBits);
+					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS.load(k) : e, idBits);
 					if(tid == 0) { fin[lo] = rs_key(pivE, idBits); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
 				}
 				__syncthreads();
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const unsigned long long mR = __ballot(rs);
 					if(valid && q >= cutq) {
 						const int rk = rs ? (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)) : 0;
-						dst[lo + 1 + q] = (rs && rk <= m) ? lsb[rk - 1] : e;
+						dst.store(lo + 1 + q, (rs && rk <= m) ? lsb[rk - 1] : e);
 					}
 				}
 				lo = cutAbs;
@@ -360,7 +388,8 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			__threadfence_block();
 			__syncthreads();
 			RS_T(6);
-			src = dst; dst = (dst == bufA) ? bufB : bufA;
+			src = dst; dst = (dst.ids == bufA.ids) ? bufB : bufA;
+			level0 = false;
 			pA = pB = -1;
 		}
 		if(__syncthreads_or((failed || nan) ? 1 : 0)) { /* the host path finishes this read */
