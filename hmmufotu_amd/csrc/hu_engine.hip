@@ -1323,8 +1323,9 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	/* a tree of n + 1 nodes whose LAST node is the root: position p of the sort is node p */
 	HuDbDev d; memset(&d, 0, sizeof(d));
 	d.nNodes = (int32_t) n + 1; d.nNodesPad = (d.nNodes + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD; d.root = (int32_t) n;
-	int idBits = 1; while((1 << idBits) < d.nNodes) ++idBits;
-	if((!pair16 && idBits > 19) || hu_refsort_lds(d.nNodes) > 150 * 1024) { hu_set_error("hu_sort_prefix_device: %lld elements are more than the kernel takes", (long long) n); return HU_ERR_ARG; }
+	if(hu_refsort_lds(d.nNodes) > 150 * 1024) { hu_set_error("hu_sort_prefix_device: %lld elements are more than the kernel takes", (long long) n); return HU_ERR_ARG; }
+	for(size_t i = 0, e = (size_t) rows * (size_t) n; i < e; ++i) /* a p-distance: d differing sites of N compared ones (N = 0: NaN, left to the host path) */
+		if((pairs[i] >> 16) > (pairs[i] & 0xffffu) && (pairs[i] & 0xffffu)) { hu_set_error("hu_sort_prefix_device: pair %zu has d > N", i); return HU_ERR_ARG; }
 	const size_t np = (size_t) d.nNodesPad;
 	DBuf<int32_t> dPar, dSt, dEn, dCnt, dId, dBail; DBuf<uint32_t> dDN, dPN, dP32; DBuf<uint16_t> dP16; DBuf<unsigned long long> scr;
 	int rc;
@@ -1355,11 +1356,11 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	HIPCHK(hipEventRecord(e0, nullptr));
 	if(pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds>>>(d, dP16.p, rows, dSt.p, dEn.p, k, idBits, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds>>>(d, dP16.p, rows, dSt.p, dEn.p, k, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds>>>(d, dP32.p, rows, dSt.p, dEn.p, k, idBits, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds>>>(d, dP32.p, rows, dSt.p, dEn.p, k, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(e1, nullptr));
@@ -1388,8 +1389,7 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector
 static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	const HuDbDev& d = b->db->dev;
 	const int n = b->n;
-	int idBits = 1; while((1 << idBits) < d.nNodes) ++idBits;
-	if(b->knob.refsort_host || o->max_height != INFINITY || (!b->pair16 && idBits > 19) || idBits > 24 || d.nNodes < 3) return seed_order_libstdcxx(b, o);
+	if(b->knob.refsort_host || o->max_height != INFINITY || d.nNodes < 3) return seed_order_libstdcxx(b, o);
 	const size_t m0 = (size_t) d.nNodes - 1;
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
@@ -1405,12 +1405,12 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	if(b->knob.trace) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, b->stream)); }
 	if(b->pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed, idBits,
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
 				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed, idBits,
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
 				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	HIPCHK(hipGetLastError());

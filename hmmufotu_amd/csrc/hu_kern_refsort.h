@@ -16,8 +16,8 @@
 // by one thread in LDS with the literal sequential algorithm.  Reads the device does not finish (a NaN distance, the heap-sort branch of
 // introsort, keys that do not fit) are listed for the host path.
 //
-// Elements are 64-bit words (key << idBits | node): key = the leading bits of the double d / N, order-isomorphic to dist for d <= N < 2^16
-// while idBits <= 19 (33 mantissa bits: two different fractions differ by more than 2^-32 relative) or N <= 255 (any idBits <= 24).
+// No floating point anywhere: dist = d / N is compared through d_a * N_b < d_b * N_a in the streaming passes, and the sequential finisher works on
+// the exact integer keys floor(d * 2^32 / N) of the few hundred elements it receives (rs_key).
 #pragma once
 #include <type_traits>
 #include "hu_common.h"
@@ -79,11 +79,13 @@ __device__ inline uint32_t rs_node(const HuRsLevel<PT>& src, int root, int p, in
 	id = p == pB ? (uint32_t) vB : id;
 	return id;
 }
-/* key of an element for the finisher: the leading bits of the double d / N above the node id */
-__device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e, int idBits) {
+/* key of an element for the finisher: floor(d * 2^32 / N) above the node id.  Exact: d <= N < 2^16, so the key has 33 bits, and two different
+ * fractions differ by at least 1 / (N_a N_b) > 2^-32 — their keys differ; equal fractions have equal keys.  One 64-bit division per element
+ * of the last range (<= HU_RS_FIN per read). */
+#define HU_RS_IDBITS 31
+__device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e) {
 	const uint32_t pr = (uint32_t)(e >> 32);
-	const unsigned long long bits = (unsigned long long) __double_as_longlong((double)(pr >> 16) / (double)(pr & 0xffffu));
-	return ((bits >> idBits) << idBits) | (e & 0xffffffffull);
+	return ((((uint64_t)(pr >> 16) << 32) / (uint64_t)(pr & 0xffffu)) << HU_RS_IDBITS) | (e & 0x7fffffffull);
 }
 
 /* scratch of one workgroup: two levels of cap positions (the m0 positions, then room for the right stoppers of a partition: at most half of
@@ -94,7 +96,8 @@ static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return 2 * hu_
 static inline size_t hu_refsort_lds(int nNodes) { const size_t NT = ((size_t) nNodes - 1 + 63) / 64; return (HU_RS_FIN + 64) * 8 + 2 * (NT + 2) * 4; }
 
 /* the literal sequential algorithm on an LDS array, for one thread: introsort loop restricted to ranges that start before place K */
-__device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* LDS [72] */, int first, int last, int depth, int K, int idBits) {
+__device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* LDS [72] */, int first, int last, int depth, int K) {
+	constexpr int idBits = HU_RS_IDBITS;
 	/* explicit stack of (first, last, depth): the recursion into [cut, last) happens only when cut < K */
 	int* sf = stk; int* sl = stk + 24; int* sd = stk + 48; int sp = 0;
 	sf[0] = first; sl[0] = last; sd[0] = depth; sp = 1;
@@ -133,7 +136,7 @@ __device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* L
 
 template<class PT>
 __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K, int idBits,
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K,
 		unsigned long long* __restrict__ scratch, size_t cap, int rsOff,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
 		int32_t* __restrict__ bail) {
@@ -365,8 +368,8 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const unsigned long long mL = __ballot(ls);
 					const int k = __popcll(mL & rs_lane_lt(lane));
 					if(ls) lsb[k] = e;
-					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS.load(k) : e, idBits);
-					if(tid == 0) { fin[lo] = rs_key(pivE, idBits); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
+					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS.load(k) : e);
+					if(tid == 0) { fin[lo] = rs_key(pivE); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
 				}
 				__syncthreads();
 				if(nStash >= 12) { failed = true; break; }
@@ -397,18 +400,18 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			continue;
 		}
 		/* ---- the last range into LDS beside the set-aside prefix; one thread finishes with the literal algorithm */
-		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint64_t e = E(p); if(!nan) fin[p] = rs_key(e, idBits); }
+		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint64_t e = E(p); if(!nan) fin[p] = rs_key(e); }
 		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; } continue; }
 		RS_T(7);
 		if(tid == 0) {
 			bool ok = true;
-			for(int s = 0; s < nStash && ok; ++s) ok = rs_seq_loop(fin, seqStack, stash[s].lo, stash[s].hi, stash[s].depth, K, idBits);
-			if(ok) ok = rs_seq_loop(fin, seqStack, lo, hi, depth, K, idBits);
+			for(int s = 0; s < nStash && ok; ++s) ok = rs_seq_loop(fin, seqStack, stash[s].lo, stash[s].hi, stash[s].depth, K);
+			if(ok) ok = rs_seq_loop(fin, seqStack, lo, hi, depth, K);
 			if(ok) { /* __final_insertion_sort over the blocks that hold the first K places */
 				const int e = min(hi, K + 16);
 				for(int i = 1; i < e; ++i) {
 					const uint64_t v = fin[i]; int j = i;
-					while(j > 0 && (v >> idBits) < (fin[j - 1] >> idBits)) { fin[j] = fin[j - 1]; --j; }
+					while(j > 0 && (v >> HU_RS_IDBITS) < (fin[j - 1] >> HU_RS_IDBITS)) { fin[j] = fin[j - 1]; --j; }
 					fin[j] = v;
 				}
 			}
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		const int keep = min(K, hi);
 		if(tid == 0) seedCnt[read] = keep;
 		if(tid < keep) {
-			const int node = (int)(fin[tid] & ((1ull << idBits) - 1));
+			const int node = (int)(fin[tid] & ((1ull << HU_RS_IDBITS) - 1));
 			seedId[(size_t) read * HU_MAX_SEEDS + tid] = node;
 			seedDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[node]);
 			parDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[db.parent[node]]);

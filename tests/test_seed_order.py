@@ -161,6 +161,16 @@ def test_device_sort_prefix_against_the_host_restatement():
                     assert cnt[r] == len(want) and np.array_equal(got[r, :cnt[r]], want), (n, shape, k, r, got[r, :12], want[:12])
     print("rows handed back to the host path:", handed_back)
     assert handed_back == 0
+    # more than 2^19 elements with 32-bit pairs (a SILVA-scale tree under paired reads): the kernel's keys are exact integers, no width limit
+    n, rows = 700001, 2
+    Nm = rng.integers(300, 600, (rows, n)); dm = np.minimum(Nm, rng.binomial(500, 0.1, (rows, n)))
+    got, cnt = run(dm, Nm, 50, False)
+    for r in range(rows):
+        want = _prefix(dm[r] / Nm[r], 50)
+        assert cnt[r] == 50 and np.array_equal(got[r], want), (n, r, got[r, :12], want[:12])
+    # d > N is not a p-distance: refused
+    assert lib.hu_sort_prefix_device(C.c_int(0), np.array([(5 << 16) | 3] * 8, np.uint32).ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int64(8), C.c_int(4), C.c_int(0),
+                                     np.zeros(4, np.int32).ctypes.data_as(C.c_void_p), np.zeros(1, np.int32).ctypes.data_as(C.c_void_p)) != 0
     # the adversarial input reaches the depth limit: the kernel must hand the row back, not answer wrongly
     from oracle import oracle_py as O
     a = O.antiqsort(60000)
