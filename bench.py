@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 15 s worth)")
     ap.add_argument("--seed-order", choices=["stable", "reference"], default="stable",
                     help="hu_opts.seed_order: 'stable' = (dist, node id), selected on the device [default]; 'reference' = the first max_nseed of libstdc++'s "
-                         "std::sort on dist alone (HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, reproduced on the host)")
+                         "std::sort on dist alone (HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, reproduced on the device by k_seed_refsort)")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("HU_BENCH_E2E_READS", 1 << 20)),
                     help="distinct reads of the end-to-end block (host seed lookup + upload + engine + TSV formatting, measured after the timed region; 0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
@@ -414,7 +414,7 @@ def main():
                config=dict(workload="%s synthetic DB (%d nodes x %d CS columns, K=%d), GTR%s, %s %s reads, "
                                     "batch %d reads/step/GPU, %d batches in flight" % ("SILVA-scale" if args.leaves >= 150000 else "gg_97_otus-scale" if args.leaves >= 90000 else "reduced-scale", D.n_nodes, args.cs_len, D.K, "+dGamma(%d)" % args.dg_k if args.dg_k else "",
                                                                                          shape, "uniform-start" if args.uniform_starts else "amplicon", args.batch, nb) +
-                                    (", seeds in the reference's std::sort order (host)" if args.seed_order == "reference" else ""),
+                                    (", seeds in the reference's std::sort order (k_seed_refsort)" if args.seed_order == "reference" else ""),
                            seed_order=args.seed_order,
                            db_hbm_gb=D.hbm_bytes / 1e9, message_window_cols=db.win[1], parallelism="read-sharded x%d" % world,
                            hbm_in_use_gb=(total_b - free_b) / 1e9, hbm_total_gb=total_b / 1e9),
