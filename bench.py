@@ -476,8 +476,10 @@ def main():
             id_arrays = [(Ct.c_char_p * (b0 - a0))(*[b"r%d" % i for i in range(a0, b0)]) for a0, b0 in chunks]
             anno_strs = [b"taxon%d" % int(x) for x in db.anno_id]
             anno_arr = (Ct.c_char_p * len(anno_strs))(*anno_strs)
+            e2e_diag = bool(os.environ.get("HU_BENCH_E2E_PROFILE"))      # diagnostic: per-kernel HIP events stay on and the last batch's stage times are reported
             for B_ in batches:
-                B_.profile(False)
+                B_.profile(e2e_diag)
+            seeded = [[0, 0] for _ in range(nb)]
             stage = [dict(lookup=0.0, upload=0.0, engine=0.0, tsv=0.0) for _ in range(nb)]
             done = [0] * nb; tsv_bytes = [0] * nb; placed = [0] * nb
             q = queue.Queue()
@@ -494,6 +496,7 @@ def main():
                     a0, b0 = chunks[c_]
                     sub = cat[offs[a0]:offs[b0]]; so = offs[a0:b0 + 1] - offs[a0]
                     x0 = time.perf_counter(); vp = ix.lookup_packed(sub, so, 50, 0)
+                    seeded[w][0] += int(vp[:, 0].any(axis=1).sum()); seeded[w][1] += int(vp[:, 1].any(axis=1).sum())
                     x1 = time.perf_counter(); B_.set_reads_packed(sub, so, vp)
                     x2 = time.perf_counter(); B_.assign(opts)
                     x3 = time.perf_counter(); tsv_bytes[w] += B_.format_tsv_bytes(id_arrays[c_], None, anno_arr)
@@ -512,7 +515,12 @@ def main():
                                             "hu_batch_format_tsv_ptr (one line per read incl. the csLen-character alignment)",
                                      stage_busy_sec={k: round(sum(s_[k] for s_ in stage), 2) for k in stage[0]},
                                      seed_index_build_sec=round(t_index, 1), seed_index_gb=ix.bytes / 1e9,
+                                     reads_with_5p_seed=sum(x[0] for x in seeded), reads_with_3p_seed=sum(x[1] for x in seeded),
                                      excluded="FASTA parsing and the file write (profiles/measure_cli.py times the product CLI with both)")
+            if e2e_diag:
+                out["end_to_end"]["last_batch_kernel_ms"] = [{k: round(v, 2) for k, v in B_.timings().items()} for B_ in batches]
+                out["end_to_end"]["last_batch_host_wall_ms"] = [{k: round(float(v), 2) for k, v in B_.wall().items()} for B_ in batches]
+                out["end_to_end"]["last_batch_full_dp_reads"] = [int(B_.alignments(want_align=False)["recs"]["used_full"].sum()) for B_ in batches]
             log("end to end: %.0f reads/s over %d distinct reads (%.1fs; index build %.1fs)" % (sum(done) / de, nr, de, t_index))
             del ix
         except Exception as ex:

@@ -832,6 +832,7 @@ struct hu_batch {
 	int64_t cellsTotal = 0, cornerTotal = 0;   /* DP cells of all phases of all sequences / of their corner blocks (set with the reads) */
 	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
 	int nFullRedo = 0;          /* sequences of the last align call whose banded DP found no path: full DP, one launch */
+	DBuf<double> dRedoScr; DBuf<HuReadDesc> dRedoDesc; DBuf<HuVitOut> dRedoVit;    /* the redo launches' own scratch: kept (an allocation or a release stalls every stream of the device) */
 	PinnedVec<HuAlnDev> hAlns;
 	PinnedVec<int32_t> hStart, hEnd, hSeedCnt, hSeedId;
 	PinnedVec<uint32_t> hSeedDN;
@@ -1199,7 +1200,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 						rd.scratchOff = cells; cells += c;
 						rdv.push_back(rd); hv.push_back(b->hVit[rs[e]]);
 					}
-					DBuf<double> scr; DBuf<HuReadDesc> dd; DBuf<HuVitOut> vo;
+					DBuf<double>& scr = b->dRedoScr; DBuf<HuReadDesc>& dd = b->dRedoDesc; DBuf<HuVitOut>& vo = b->dRedoVit;
 					if((rc = scr.ensure((size_t) cells * 3 + 1)) != HU_OK || (rc = dd.ensure(rdv.size())) != HU_OK || (rc = vo.ensure(rdv.size())) != HU_OK) return rc;
 					HIPCHK(hipMemcpyAsync(dd.p, rdv.data(), rdv.size() * sizeof(HuReadDesc), hipMemcpyHostToDevice, b->stream));
 					HIPCHK(hipMemcpyAsync(vo.p, hv.data(), hv.size() * sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
@@ -1207,7 +1208,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 					k_viterbi_trace<<<((unsigned) rdv.size() + 63) / 64, 64, 0, b->stream>>>(d, dd.p, scr.p, b->dTraces.p, tNN, tNB, vo.p, (int) rdv.size());
 					HIPCHK(hipGetLastError());
 					HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
-					HIPCHK(hipStreamSynchronize(b->stream));     /* the temporaries die here */
+					HIPCHK(hipStreamSynchronize(b->stream));
 					for(size_t k = 0; k < rdv.size(); ++k) {
 						b->hVit[rs[at + k]] = hv[k];               /* the trace is written at the sequence's own traceOff */
 						HIPCHK(hipMemcpyAsync(b->dVit.p + rs[at + k], &b->hVit[rs[at + k]], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
@@ -1244,11 +1245,17 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 				rd.scratchOff = cells; cells += c;
 				rdv.push_back(rd);
 			}
-			DBuf<double> scr; DBuf<HuReadDesc> dd; DBuf<HuVitOut> vo;
-			if((rc = scr.ensure((size_t) cells * 3)) != HU_OK || (rc = dd.ensure(rdv.size())) != HU_OK || (rc = vo.ensure(rdv.size())) != HU_OK) return rc;
+			DBuf<double>& scr = b->dRedoScr; DBuf<HuReadDesc>& dd = b->dRedoDesc; DBuf<HuVitOut>& vo = b->dRedoVit;
+			if((rc = scr.ensure((size_t) cells * 3 + 1)) != HU_OK || (rc = dd.ensure(rdv.size())) != HU_OK || (rc = vo.ensure(rdv.size())) != HU_OK) return rc;
 			std::vector<HuVitOut> hv(rdv.size());
 			HIPCHK(hipMemcpyAsync(dd.p, rdv.data(), rdv.size() * sizeof(HuReadDesc), hipMemcpyHostToDevice, b->stream));
-			k_viterbi<<<(unsigned) rdv.size(), 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
+			if(vlds <= 96 * 1024 && !kb.viterbi_hbm) { /* a workgroup per sequence, the wavefront staged in LDS, every value filed for the traceback: K + len steps of a barrier
+			                                           * each instead of as many round trips to HBM by one wave (30 - 100 ms for a handful of 150-base reads) */
+				if(vlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_viterbi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) vlds));
+				k_viterbi_lds<<<(unsigned) rdv.size(), HU_VIT_THREADS, vlds, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p, ldsRows, 0);
+				k_viterbi_trace<<<((unsigned) rdv.size() + 63) / 64, 64, 0, b->stream>>>(d, dd.p, scr.p, b->dTraces.p, tNN, tNB, vo.p, (int) rdv.size());
+			}
+			else k_viterbi<<<(unsigned) rdv.size(), 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
 			HIPCHK(hipStreamSynchronize(b->stream));
@@ -1259,7 +1266,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 				HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
 				b->hDescs[s].nRegions = -1; /* mark: full DP was used */
 			}
-			HIPCHK(hipStreamSynchronize(b->stream)); /* the temporaries die here */
+			HIPCHK(hipStreamSynchronize(b->stream));
 			at = e;
 		}
 		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL) {
