@@ -74,7 +74,13 @@ struct HuDbDev {
 	const double* EMt;
 	const double* EIt;
 	const double* placeConst;  /* [HU_PC_COUNT] */
+	/* width classes of one launch of the estimate / placement kernels (0, 0, nullptr: every read).  The kernel shape goes with the widest
+	 * alignment region it must hold, and a handful of reads per batch whose seeds land far apart have regions of thousands of columns:
+	 * they get a launch of their own (the few slots listed in wideList) instead of dragging the whole batch onto the wide kernel */
+	int32_t rLo, rHi;          /* rHi != 0: only reads with rLo < region columns <= rHi */
+	const uint32_t* wideList;  /* streaming kernels: workgroup -> slot / candidate (the others take it as their `order`) */
 };
+__device__ inline bool hu_skip_width(const HuDbDev& db, int cols) { return db.rHi != 0 && (cols <= db.rLo || cols > db.rHi); }
 
 /* one dynamic-programming phase of the banded Viterbi (src/BandedHMMP7.cpp:794-881) */
 struct HuRegion {
@@ -159,6 +165,14 @@ int hu_read_hmm_stream(std::istream& in, const char* name, HuProfileHost& out, s
 		std::vector<double>& T, std::vector<int32_t>& p2cs, int& K, int& L);
 int hu_read_model_text(std::istream& in, hu_model_desc& m);
 
+/* The CPUs this process may really use: the smallest of the hardware's, the affinity mask's and the cgroup's CPU quota (a container that shows
+ * 256 CPUs with a quota of 16 stops EVERY thread of the process for the rest of the period once its threads have used the quota — also the ones
+ * that feed the GPU).  HU_CPU_BUDGET overrides.  Helper threads of all pools together stay within it: a run asks for helpers and takes what is
+ * left (possibly none: the caller always works itself). */
+int hu_cpu_budget();
+int hu_helpers_acquire(int want);
+void hu_helpers_release(int n);
+
 /* work() on up to nt threads, the caller being one of them (work is a self-scheduling loop: fewer helpers only means larger shares).
  * An exception inside a helper is carried to the calling thread and rethrown there once every helper has been joined — a std::thread
  * destroyed while joinable, or an exception leaving a thread body, would end the process; a helper that cannot be started is done without. */
@@ -167,9 +181,11 @@ template<class F> void hu_run_threads(unsigned nt, F work) {
 	std::mutex m;
 	auto guarded = [&] { try { work(); } catch(...) { std::lock_guard<std::mutex> lk(m); if(!first) first = std::current_exception(); } };
 	std::vector<std::thread> th;
-	try { th.reserve(nt); for(unsigned t = 1; t < nt; ++t) th.emplace_back(guarded); } catch(...) { }
+	const int got = nt > 1 ? hu_helpers_acquire((int) nt - 1) : 0;
+	try { th.reserve(got); for(int t = 0; t < got; ++t) th.emplace_back(guarded); } catch(...) { }
 	guarded();
 	for(auto& t : th) t.join();
+	hu_helpers_release(got);
 	if(first) std::rethrow_exception(first);
 }
 /* runs f when the scope is left, by return or by exception */

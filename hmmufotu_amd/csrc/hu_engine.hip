@@ -44,7 +44,7 @@ struct HuPool {
 	size_t n = 0, chunk = 64;
 	std::atomic<size_t> next{0};
 	uint64_t gen = 0;
-	int active = 0;
+	int active = 0, permit = 0;  /* permit: helpers of the current run that may work (hu_helpers_acquire); the others only report back */
 	bool quit = false;
 	std::exception_ptr err;      /* first exception of a work item of the current run: rethrown on the calling thread (hu_catch_all turns it into a status) */
 	explicit HuPool(unsigned nt) {
@@ -57,6 +57,7 @@ struct HuPool {
 					cvGo.wait(lk, [&] { return quit || gen != seen; });
 					if(quit) return;
 					seen = gen;
+					if(permit > 0) --permit; else { if(--active == 0) cvDone.notify_all(); continue; }
 				}
 				work();
 				std::lock_guard<std::mutex> lk(m);
@@ -72,14 +73,16 @@ struct HuPool {
 		}
 	}
 	template<class F> void run(size_t count, F f) {
+		const int got = hu_helpers_acquire((int) th.size());
 		{
 			std::lock_guard<std::mutex> lk(m);
-			fn = f; n = count; next = 0; active = (int) th.size(); err = nullptr; ++gen;
+			fn = f; n = count; next = 0; active = (int) th.size(); permit = got; err = nullptr; ++gen;
 		}
 		cvGo.notify_all();
 		work();                                   /* the caller works too */
 		std::unique_lock<std::mutex> lk(m);
 		cvDone.wait(lk, [&] { return active == 0; });
+		hu_helpers_release(got);
 		if(err) { std::exception_ptr e = err; err = nullptr; lk.unlock(); std::rethrow_exception(e); }
 	}
 	~HuPool() { { std::lock_guard<std::mutex> lk(m); quit = true; } cvGo.notify_all(); for(auto& t : th) t.join(); }
@@ -746,6 +749,7 @@ struct HuKnobs {
 	int vit_lds_pad = 0;         /* the same for the one-wave Viterbi kernel                                          */
 	int scan_lds_pad = 0;        /* the same for the distance-only scan                                               */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
+	int width_split = 1;         /* 0: one launch of the estimate / placement kernels for the whole batch, shaped by its widest region (rounds 1-2) */
 	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
 	                              * host pool, 2 = std::length_error on the calling thread of the finish stage, 3 = std::runtime_error in a pool worker
@@ -757,7 +761,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"viterbi_dec1", &HuKnobs::viterbi_dec1}, {"vw_diag", &HuKnobs::vw_diag}, {"viterbi_force_redo", &HuKnobs::viterbi_force_redo},
 	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
-	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit},
+	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit}, {"width_split", &HuKnobs::width_split},
 	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host},
 };
 static void knobs_from_env(HuKnobs& k) {
@@ -831,6 +835,10 @@ struct hu_batch {
 	PinnedVec<HuVitOut> hVit;
 	int64_t cellsTotal = 0, cornerTotal = 0;   /* DP cells of all phases of all sequences / of their corner blocks (set with the reads) */
 	int nVitRedo = 0;           /* sequences of the last align call redone by the value-filing Viterbi */
+	int rMain = 0;              /* width split of the batch (plan_width_split): regions of at most rMain columns take the main launch; 0 = one launch for all */
+	std::vector<int32_t> wideReads;     /* the reads beyond it */
+	std::vector<uint32_t> hWideOrd, hWideCand; DBuf<uint32_t> dWideOrd, dWideCand;      /* their (read, seed) slots and their candidates: the lists of the second launches */
+	std::vector<int32_t> hCandOffAll;   /* candidate offsets on the host when there are wide reads (scan_cands) */
 	int nFullRedo = 0;          /* sequences of the last align call whose banded DP found no path: full DP, one launch */
 	DBuf<double> dRedoScr; DBuf<HuReadDesc> dRedoDesc; DBuf<HuVitOut> dRedoVit;    /* the redo launches' own scratch: kept (an allocation or a release stalls every stream of the device) */
 	PinnedVec<HuAlnDev> hAlns;
@@ -1699,6 +1707,30 @@ __global__ void k_seed_sortkeys(int n, const int32_t* __restrict__ seedCnt, cons
 	val[i] = (uint32_t) i;
 }
 
+/* The estimate / placement kernels hold a read's whole alignment region in registers, so their shape (sites per thread, waves per candidate,
+ * workgroups per CU) goes with the WIDEST region of the launch — and with seeds from the index instead of the truth a few reads per batch have
+ * seeds that land far apart: regions of 2,000 - 6,000 columns beside 8,000 reads of ~800 (measured on the 1 M-read pool at 150 bases: 1 - 4 such
+ * reads in five batches of eight, placement 23 ms instead of 5).  Those reads get a launch of their own: the class boundary above the
+ * (W + 1)-th widest region, W <= 64, splits the batch when the widest region lies in a higher class. */
+static void plan_width_split(hu_batch* b) {
+	b->rMain = 0; b->wideReads.clear();
+	if(!b->knob.width_split || b->n < 256 || (int) b->hStart.size() < b->n || (int) b->hEnd.size() < b->n) return;
+	std::vector<int> R((size_t) b->n);
+	int maxAll = 0;
+	for(int r = 0; r < b->n; ++r) { R[r] = std::max(0, b->hEnd[r] - b->hStart[r] + 1); maxAll = std::max(maxAll, R[r]); }
+	const int W = std::min(64, b->n / 128);
+	std::vector<int> tmp(R);
+	std::nth_element(tmp.begin(), tmp.begin() + W, tmp.end(), std::greater<int>());
+	const int kth = tmp[W];
+	static const int bounds[] = {512, 768, 1024, 1536, 2048, 3072};
+	int bound = 0;
+	for(int x : bounds) if(kth <= x) { bound = x; break; }
+	if(!bound || bound >= maxAll) return;
+	b->rMain = bound;
+	for(int r = 0; r < b->n; ++r) if(R[r] > bound) b->wideReads.push_back(r);
+	if(b->knob.trace) fprintf(stderr, "[hu] width split: %zu of %d reads beyond %d columns (widest %d) take a launch of their own\n", b->wideReads.size(), b->n, bound, maxAll);
+}
+
 extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_SEEDED) { hu_set_error("hu_estimate_batch: no seeds"); return HU_ERR_STATE; }
@@ -1709,53 +1741,66 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) try {
 	(void) hipGetLastError();
 	if(n) {
 		Timer t(b, HU_T_ESTIMATE);
-		int maxR = 1;
-		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
+		plan_width_split(b);
+		int maxAll = 1, maxMain = 1;
+		for(int r = 0; r < b->n; ++r) { const int R = b->hEnd[r] - b->hStart[r] + 1; maxAll = std::max(maxAll, R); if(!b->rMain || R <= b->rMain) maxMain = std::max(maxMain, R); }
 		const bool stream = b->knob.streaming_sep != 0;
-		#define EST_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dParDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
-		const unsigned eg = (unsigned) b->n * HU_MAX_SEEDS;
-		/* launch order of the table-driven kernels: by seed node */
-		const uint32_t* order = nullptr;
-		if(!b->knob.est_unsorted) {
-			if((rc = b->dSortK.ensure((size_t) eg * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) eg * 2)) != HU_OK) return rc;
-			size_t tb = 0;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
-			if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
-			k_seed_sortkeys<<<(eg + 255) / 256, 256, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dSeedId.p, b->dSortK.p, b->dSortV.p);
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
-			order = b->dSortV.p + eg;
+		if(b->rMain) { /* the wide reads' (read, seed) slots: the second launch's list */
+			b->hWideOrd.clear();
+			for(int r : b->wideReads) for(int sd = 0; sd < HU_MAX_SEEDS; ++sd) b->hWideOrd.push_back((uint32_t) r * HU_MAX_SEEDS + sd);
+			if((rc = b->dWideOrd.ensure(b->hWideOrd.size())) != HU_OK) return rc;
+			HIPCHK(hipMemcpyAsync(b->dWideOrd.p, b->hWideOrd.data(), b->hWideOrd.size() * 4, hipMemcpyHostToDevice, b->stream));
 		}
-		/* register-resident variant (messages cross HBM once) while a read's region fits 256 x SPT sites, the
-		 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
-		 * streaming 12.3 ms with twice the HBM traffic. */
-		const int spt = (maxR + 255) / 256;
-		/* sorted launch: the valid slots come first and number at most n x (seeds per read), so only that many workgroups
-		 * start; and XCD x (workgroups b = x mod 8) walks the contiguous eighth x of the sorted list, so that the reads sharing
-		 * a seed node share an L2 (5.13 -> 4.55 ms; without the trim the empty slots all fall to one XCD: 5.48 ms) */
-		const int xm = b->knob.xcd_map;
-		const unsigned egl = order ? std::min<unsigned>(eg, (unsigned) b->n * (unsigned) b->seedCap) : eg;
-		const int var = b->knob.est_var;
-		if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
-		else if(var == 2) { /* the per-site log() form, kept for comparison */
-			if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-			else if(spt <= 4) k_estimate_blk<4, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-			else if(spt <= 6) k_estimate_blk<6, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-			else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
-			else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+		for(int pass = 0; pass < (b->rMain ? 2 : 1); ++pass) { /* pass 1: the reads beyond rMain, on the kernel their width asks for */
+			const int maxR = pass ? maxAll : maxMain;
+			HuDbDev dev = b->db->dev;
+			if(b->rMain) { dev.rLo = pass ? b->rMain : -1; dev.rHi = pass ? 0x7fffffff : b->rMain; dev.wideList = pass ? b->dWideOrd.p : nullptr; }
+			#define EST_ARGS dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dParDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, o->weighted, b->dEst.p
+			const unsigned eg = pass ? (unsigned) b->hWideOrd.size() : (unsigned) b->n * HU_MAX_SEEDS;
+			/* launch order of the table-driven kernels: by seed node */
+			const uint32_t* order = nullptr;
+			if(pass) order = b->dWideOrd.p;
+			else if(!b->knob.est_unsorted) {
+				if((rc = b->dSortK.ensure((size_t) eg * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) eg * 2)) != HU_OK) return rc;
+				size_t tb = 0;
+				HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
+				if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
+				k_seed_sortkeys<<<(eg + 255) / 256, 256, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dSeedId.p, b->dSortK.p, b->dSortV.p);
+				HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
+				order = b->dSortV.p + eg;
+			}
+			/* register-resident variant (messages cross HBM once) while a read's region fits 256 x SPT sites, the
+			 * two-pass streaming kernel beyond.  Measured at R = 1363: 256 threads 11.6 ms, 512 13.1, 1024 25.4;
+			 * streaming 12.3 ms with twice the HBM traffic. */
+			const int spt = (maxR + 255) / 256;
+			/* sorted launch: the valid slots come first and number at most n x (seeds per read), so only that many workgroups
+			 * start; and XCD x (workgroups b = x mod 8) walks the contiguous eighth x of the sorted list, so that the reads sharing
+			 * a seed node share an L2 (5.13 -> 4.55 ms; without the trim the empty slots all fall to one XCD: 5.48 ms) */
+			const int xm = b->knob.xcd_map;
+			const unsigned egl = pass ? eg : order ? std::min<unsigned>(eg, (unsigned) b->n * (unsigned) b->seedCap) : eg;
+			const int var = b->knob.est_var;
+			if(stream || spt > 12) k_estimate<<<eg, 64, 0, b->stream>>>(EST_ARGS);
+			else if(var == 2) { /* the per-site log() form, kept for comparison */
+				if(spt <= 2) k_estimate_blk<2, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+				else if(spt <= 4) k_estimate_blk<4, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+				else if(spt <= 6) k_estimate_blk<6, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+				else if(spt <= 8) k_estimate_blk<8, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+				else k_estimate_blk<12, 256><<<eg, 256, 0, b->stream>>>(EST_ARGS);
+			}
+			else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<egl, 128, 0, b->stream>>>(EST_ARGS, order, xm);
+			else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+			else if(spt <= 2) k_estimate_prod<2, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+			else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
+			/* measured and not kept: <3, 8, 3> (512 threads x 3 sites, 66 VGPRs, three pairs per CU on 24 waves): 5.04 ms against 4.40;
+			 * <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
+			else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, (size_t)(b->knob.est_lds_pad > 0 && b->knob.est_lds_pad <= 60 ? b->knob.est_lds_pad : 0) * 1024, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
+			else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* (512 threads x 4 sites measured slower here: 6.99 against 6.36 ms at R ~ 1,850) */
+			else if(var == 4) k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);    /* est_var = 4: 256 threads x 12 sites, 231 VGPRs, two workgroups of four waves per CU */
+			/* regions of 2,049 .. 3,072 columns (merged mate pairs): 512 threads x 6 sites, 120 VGPRs — the same two pairs per CU as with 256 x 12, but sixteen
+			 * waves instead of eight work on them and a pair's life is shorter: 5.67 -> 4.92 ms per 4,096 pairs of 2 x 250 bases, 265.6 k -> 276.6 k pairs/s */
+			else k_estimate_prod<6, 8, 2><<<egl, 512, 0, b->stream>>>(EST_ARGS, order, xm);
+			#undef EST_ARGS
 		}
-		else if(var == 1 && spt <= 6) k_estimate_prod<12, 2><<<egl, 128, 0, b->stream>>>(EST_ARGS, order, xm);
-		else if(var == 3 && spt <= 6) k_estimate_prod<6, 4, 1><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		else if(spt <= 2) k_estimate_prod<2, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		else if(spt <= 4) k_estimate_prod<4, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);
-		/* measured and not kept: <3, 8, 3> (512 threads x 3 sites, 66 VGPRs, three pairs per CU on 24 waves): 5.04 ms against 4.40;
-		 * <6, 4, 5> / <6, 4, 6> (five / six workgroups per CU by launch bounds): 96 / 80 VGPRs with 140 / 204 B of scratch, 9.2 / 11.3 ms against 4.4 */
-		else if(spt <= 6) k_estimate_prod<6, 4, 4><<<egl, 256, (size_t)(b->knob.est_lds_pad > 0 && b->knob.est_lds_pad <= 60 ? b->knob.est_lds_pad : 0) * 1024, b->stream>>>(EST_ARGS, order, xm);   /* 128 VGPRs: four workgroups per CU (7.4 -> 6.7 ms) */
-		else if(spt <= 8) k_estimate_prod<8, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);   /* (512 threads x 4 sites measured slower here: 6.99 against 6.36 ms at R ~ 1,850) */
-		else if(var == 4) k_estimate_prod<12, 4><<<egl, 256, 0, b->stream>>>(EST_ARGS, order, xm);    /* est_var = 4: 256 threads x 12 sites, 231 VGPRs, two workgroups of four waves per CU */
-		/* regions of 2,049 .. 3,072 columns (merged mate pairs): 512 threads x 6 sites, 120 VGPRs — the same two pairs per CU as with 256 x 12, but sixteen
-		 * waves instead of eight work on them and a pair's life is shorter: 5.67 -> 4.92 ms per 4,096 pairs of 2 x 250 bases, 265.6 k -> 276.6 k pairs/s */
-		else k_estimate_prod<6, 8, 2><<<egl, 512, 0, b->stream>>>(EST_ARGS, order, xm);
-		#undef EST_ARGS
 	}
 	HIPCHK(hipGetLastError());
 	if(n) { /* gap / base site counts per read for the split placement kernel (read back in the filter stage) */
@@ -1786,10 +1831,11 @@ static int sync_host_cands(hu_batch* b) {
 static int scan_cands(hu_batch* b, bool withPerm) {
 	int rc;
 	if((rc = b->dCandOff.ensure((size_t) b->n + 1)) != HU_OK || (rc = b->dMeta.ensure(4)) != HU_OK) return rc;
-	k_cand_scan<<<1, 1024, 0, b->stream>>>(b->n, b->dCandCnt.p, b->dCandOff.p, withPerm ? b->dPermCnt.p : nullptr, b->dStart.p, b->dEnd.p, b->dMeta.p);
+	k_cand_scan<<<1, 1024, 0, b->stream>>>(b->n, b->dCandCnt.p, b->dCandOff.p, withPerm ? b->dPermCnt.p : nullptr, b->dStart.p, b->dEnd.p, b->dMeta.p, b->rMain);
 	HIPCHK(hipGetLastError());
 	int32_t meta[4] = {0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(meta, b->dMeta.p, 12, hipMemcpyDeviceToHost, b->stream));
+	if(b->rMain) { b->hCandOffAll.resize((size_t) b->n + 1); HIPCHK(hipMemcpyAsync(b->hCandOffAll.data(), b->dCandOff.p, ((size_t) b->n + 1) * 4, hipMemcpyDeviceToHost, b->stream)); }   /* the wide reads' candidates: the placement stage lists them */
 	HIPCHK(hipStreamSynchronize(b->stream));
 	b->nc = (size_t) meta[0]; b->maxGapSites = meta[1]; b->maxBaseSites = meta[2];
 	return HU_OK;
@@ -1869,6 +1915,7 @@ extern "C" int hu_batch_set_candidates(hu_batch* b, const int64_t* offs, const h
 			/* gap / base site counts of the regions for the split placement kernel (the estimate stage may not have run on this batch) */
 			k_site_count<<<b->n, 64, 0, b->stream>>>(db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dPermCnt.p);
 			HIPCHK(hipGetLastError());
+			plan_width_split(b);
 			if((rc = scan_cands(b, true)) != HU_OK) return rc;       /* offsets + counts on the device; synchronises: the host arrays above are done with */
 		}
 		else { b->nc = 0; b->maxGapSites = b->maxBaseSites = 0; }
@@ -1895,91 +1942,108 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 	if((rc = b->dPlaceOut.ensure(std::max<size_t>(nc, 1))) != HU_OK) return rc;
 	(void) hipGetLastError();
 	if(nc) {
-		int maxR = 1;
-		for(int r = 0; r < b->n; ++r) maxR = std::max(maxR, b->hEnd[r] - b->hStart[r] + 1);
-		const int spt2 = (maxR + 127) / 128, spt4 = (maxR + 255) / 256;  /* sites per thread with 2 / 4 waves per candidate */
-		const bool stream = b->knob.streaming_sep != 0 || spt4 > 12;
-		#define PL_ARGS b->db->dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
-		if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
-			const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
-			if(lds > 160 * 1024) { hu_set_error("alignment region of %d columns does not fit the placement kernel's LDS", maxR); return HU_ERR_ARG; }
-			if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-			Timer t(b, HU_T_PLACE);
-			k_place<<<(unsigned) nc, 64, lds, b->stream>>>(PL_ARGS);
+		Timer t(b, HU_T_PLACE);
+		int maxAll = 1, maxMain = 1;
+		for(int r = 0; r < b->n; ++r) { const int R = b->hEnd[r] - b->hStart[r] + 1; maxAll = std::max(maxAll, R); if(!b->rMain || R <= b->rMain) maxMain = std::max(maxMain, R); }
+		int passes = 1;
+		if(b->rMain) { /* the candidates of the wide reads: the second launch's list (plan_width_split) */
+			b->hWideCand.clear();
+			if(b->hCandOffAll.size() < (size_t) b->n + 1) { hu_set_error("hu_place_batch: candidate offsets of the wide reads are missing"); return HU_ERR_STATE; }
+			for(int r : b->wideReads) for(int32_t c = b->hCandOffAll[r]; c < b->hCandOffAll[r + 1]; ++c) b->hWideCand.push_back((uint32_t) c);
+			if(!b->hWideCand.empty()) {
+				if((rc = b->dWideCand.ensure(b->hWideCand.size())) != HU_OK) return rc;
+				HIPCHK(hipMemcpyAsync(b->dWideCand.p, b->hWideCand.data(), b->hWideCand.size() * 4, hipMemcpyHostToDevice, b->stream));
+				passes = 2;
+			}
 		}
-		else { /* one workgroup per candidate, messages and per-site ratios register-resident.  Measured on MI355X
-		        * (8192 reads, R = 1363, 25.6 candidates per read): 4 waves x 6 sites 11.9 ms, 2 waves x 12 sites with two
-		        * workgroups per SIMD pair 9.5 ms (fewer reduction / exchange / loop instructions per candidate) */
-			Timer t(b, HU_T_PLACE);
-			const int var = b->knob.place_var;
-			const int xm = b->knob.xcd_map;   /* an eighth of the node-sorted list per XCD, as in the estimate stage */
-			const uint32_t* order = nullptr;
-			if(!b->knob.place_unsorted) { /* launch order: by candidate node */
-				if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
-				size_t tb = 0;
-				HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
-				if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
-				k_cand_sortkeys<<<(unsigned)((nc + 255) / 256), 256, 0, b->stream>>>((int) nc, b->dCands.p, b->dSortK.p, b->dSortV.p);
-				HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
-				order = b->dSortV.p + nc;
+		for(int pass = 0; pass < passes; ++pass) { /* pass 1: the candidates of the reads beyond rMain, on the kernel their width asks for */
+			const int maxR = pass ? maxAll : maxMain;
+			HuDbDev dev = b->db->dev;
+			if(b->rMain) { dev.rLo = pass ? b->rMain : -1; dev.rHi = pass ? 0x7fffffff : b->rMain; dev.wideList = pass ? b->dWideCand.p : nullptr; }
+			const unsigned grid = pass ? (unsigned) b->hWideCand.size() : (unsigned) nc;
+			const int spt2 = (maxR + 127) / 128, spt4 = (maxR + 255) / 256;  /* sites per thread with 2 / 4 waves per candidate */
+			const bool stream = b->knob.streaming_sep != 0 || spt4 > 12;
+			#define PL_ARGS dev, b->db->mdl, b->dCodes.p, b->dStart.p, b->dEnd.p, b->dCands.p, b->dPlaceOut.p
+			if(stream) { /* regions of more than 3,072 columns: one wave per candidate, messages re-streamed per sweep */
+				const size_t lds = (size_t)(3 * HU_MAX_DGK * 4 + HU_MAX_DGK * 5 * 4 + maxR) * sizeof(double);
+				if(lds > 160 * 1024) { hu_set_error("alignment region of %d columns does not fit the placement kernel's LDS", maxR); return HU_ERR_ARG; }
+				if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+				k_place<<<grid, 64, lds, b->stream>>>(PL_ARGS);
 			}
-			#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<(unsigned) nc, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
-			if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
-				DBuf<long long> ddb;
-				if((rc = ddb.ensure(nc * 12)) != HU_OK) return rc;
-				long long* dd = ddb.p;
-				HIPCHK(hipMemsetAsync(dd, 0, nc * 12 * sizeof(long long), b->stream));
-				if(var == 99) k_place_blk<6, 4, 3, 0, 1, true><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, dd);
-				else k_place_blk<12, 2, 3, 0, 2, true, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, dd);
-				std::vector<long long> hd(nc * 12);
-				HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 12 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
-				HIPCHK(hipStreamSynchronize(b->stream));
-				double acc[8] = {0}, ae[4] = {0};
-				for(size_t c = 0; c < nc; ++c) { for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i]; for(int i = 0; i < 4; ++i) ae[i] += (double) hd[nc * 8 + c * 4 + i]; }
-				fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
-						acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
-				fprintf(stderr, "[place dbg] inside the EM steps, per step: arithmetic %.0f wave reduction %.0f exchange between the waves %.0f tail %.0f\n",
-						ae[0] / acc[6], ae[1] / acc[6], ae[2] / acc[6], ae[3] / acc[6]);
-			}
-			else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
-			else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
-			else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
-			else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
-			else if(spt2 <= 12 && !(var == 7)) {
-				/* 8 or 12 sites per thread.  When every read of the batch fits, its gap sites and its base sites go to separate
-				 * slots (k_place_blk GS: 6 + 2 slots = up to 768 gap and 256 base sites, 10 + 2 = 1,280 and 256): the gap slots
-				 * need no per-site table.  The counts come from k_site_count (estimate stage, read back by the filter stage). */
-				const int S = spt2 <= 8 ? 8 : 12, G = S - 2;
-				/* every read with a region fits the slots: the largest counts of the batch come with the candidate count (k_cand_scan) */
-				const bool split = !b->knob.place_nosplit && b->maxGapSites <= G * 128 && b->maxBaseSites <= (S - G) * 128;
-				if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", "EM across both waves");
-				if(split) {
-					if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
-					k_site_perm<<<b->n, 64, 0, b->stream>>>(b->db->dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
-					/* regions of <= 1,024 sites (150-base reads): the whole v message in LDS (VL = 3, 24 KB per workgroup), 168 VGPRs, three waves per
-					 * SIMD: FIVE workgroups per CU instead of four (the LDS holds five) — the kernel's time goes with the resident candidates
-					 * (DESIGN.md section 7): 4.18 -> 3.78 ms per 8,192 reads at gg_97 scale, 853 k -> 896 k reads/s.  Same arithmetic (results equal to 1e-12, iteration counts identical).
-					 * Measured and not kept: the model constants read from global memory instead of 1.5 KB of LDS, which lets a sixth workgroup in — 32 B of scratch, 3.97 ms. */
-					if(S == 8 && var != 6) k_place_blk<8, 2, 3, 0, 3, false, 3, 6><<<(unsigned) nc, 128, 3 * 8 * 128 * sizeof(double), b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
-					else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);   /* place_var = 6: v in registers, two waves per SIMD */
-					else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<(unsigned) nc, 128, (size_t)(b->knob.place_lds_pad > 0 && b->knob.place_lds_pad <= 44 ? b->knob.place_lds_pad : 0) * 1024, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+			else { /* one workgroup per candidate, messages and per-site ratios register-resident.  Measured on MI355X
+			        * (8192 reads, R = 1363, 25.6 candidates per read): 4 waves x 6 sites 11.9 ms, 2 waves x 12 sites with two
+			        * workgroups per SIMD pair 9.5 ms (fewer reduction / exchange / loop instructions per candidate) */
+				const int var = b->knob.place_var;
+				const int xm = b->knob.xcd_map;   /* an eighth of the node-sorted list per XCD, as in the estimate stage */
+				const uint32_t* order = nullptr;
+				if(pass) order = b->dWideCand.p;
+				else if(!b->knob.place_unsorted) { /* launch order: by candidate node */
+					if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
+					size_t tb = 0;
+					HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
+					if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
+					k_cand_sortkeys<<<(unsigned)((nc + 255) / 256), 256, 0, b->stream>>>((int) nc, b->dCands.p, b->dSortK.p, b->dSortV.p);
+					HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
+					order = b->dSortV.p + nc;
 				}
-				else if(S == 8) PL_GO(8, 2, 3, 0, 2);
-				else k_place_blk<12, 2, 3, 0, 2, false, 1><<<(unsigned) nc, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
+				#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<grid, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
+				if((var == 99 || var == 98) && spt4 <= 6) { /* diagnostic: per-phase s_memtime stamps, averaged over the candidates, to stderr */
+					DBuf<long long> ddb;
+					if((rc = ddb.ensure(nc * 12)) != HU_OK) return rc;
+					long long* dd = ddb.p;
+					HIPCHK(hipMemsetAsync(dd, 0, nc * 12 * sizeof(long long), b->stream));
+					if(var == 99) k_place_blk<6, 4, 3, 0, 1, true><<<grid, 256, 0, b->stream>>>(PL_ARGS, dd);
+					else k_place_blk<12, 2, 3, 0, 2, true, 1><<<grid, 128, 0, b->stream>>>(PL_ARGS, dd);
+					std::vector<long long> hd(nc * 12);
+					HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 12 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+					HIPCHK(hipStreamSynchronize(b->stream));
+					double acc[8] = {0}, ae[4] = {0};
+					for(size_t c = 0; c < nc; ++c) { for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i]; for(int i = 0; i < 4; ++i) ae[i] += (double) hd[nc * 8 + c * 4 + i]; }
+					fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
+							acc[0] / nc, acc[1] / nc, acc[2] / nc, acc[3] / nc, acc[4] / nc, acc[5] / nc, acc[6] / nc);
+					fprintf(stderr, "[place dbg] inside the EM steps, per step: arithmetic %.0f wave reduction %.0f exchange between the waves %.0f tail %.0f\n",
+							ae[0] / acc[6], ae[1] / acc[6], ae[2] / acc[6], ae[3] / acc[6]);
+				}
+				else if(var == 4 && spt4 <= 6) PL_GO(6, 4, 1, 0, 1);
+				else if(var == 5 && spt4 <= 6) PL_GO(6, 4, 2, 1, 1);
+				else if(var == 6 && spt2 <= 12) PL_GO(12, 2, 1, 0, 2);
+				else if(spt2 <= 4) PL_GO(4, 2, 3, 0, 2);
+				else if(spt2 <= 12 && !(var == 7)) {
+					/* 8 or 12 sites per thread.  When every read of the batch fits, its gap sites and its base sites go to separate
+					 * slots (k_place_blk GS: 6 + 2 slots = up to 768 gap and 256 base sites, 10 + 2 = 1,280 and 256): the gap slots
+					 * need no per-site table.  The counts come from k_site_count (estimate stage, read back by the filter stage). */
+					const int S = spt2 <= 8 ? 8 : 12, G = S - 2;
+					/* every read with a region fits the slots: the largest counts of the batch come with the candidate count (k_cand_scan) */
+					const bool split = !pass && !b->knob.place_nosplit && b->maxGapSites <= G * 128 && b->maxBaseSites <= (S - G) * 128;
+					if(b->knob.trace) fprintf(stderr, "[hu] place: %zu candidates, max region %d, %d sites per thread, %s, %s\n", nc, maxR, S, split ? "gap/base split slots" : "column order", "EM across both waves");
+					if(split) {
+						if((rc = b->dPerm.ensure((size_t) b->n * S * 128)) != HU_OK) return rc;
+						k_site_perm<<<b->n, 64, 0, b->stream>>>(dev, b->n, b->dCodes.p, b->dStart.p, b->dEnd.p, G * 128, (S - G) * 128, b->dPerm.p);
+						/* regions of <= 1,024 sites (150-base reads): the whole v message in LDS (VL = 3, 24 KB per workgroup), 168 VGPRs, three waves per
+						 * SIMD: FIVE workgroups per CU instead of four (the LDS holds five) — the kernel's time goes with the resident candidates
+						 * (DESIGN.md section 7): 4.18 -> 3.78 ms per 8,192 reads at gg_97 scale, 853 k -> 896 k reads/s.  Same arithmetic (results equal to 1e-12, iteration counts identical).
+						 * Measured and not kept: the model constants read from global memory instead of 1.5 KB of LDS, which lets a sixth workgroup in — 32 B of scratch, 3.97 ms. */
+						if(S == 8 && var != 6) k_place_blk<8, 2, 3, 0, 3, false, 3, 6><<<grid, 128, 3 * 8 * 128 * sizeof(double), b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+						else if(S == 8) k_place_blk<8, 2, 3, 0, 2, false, 0, 6><<<grid, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);   /* place_var = 6: v in registers, two waves per SIMD */
+						else k_place_blk<12, 2, 3, 0, 2, false, 1, 10><<<grid, 128, (size_t)(b->knob.place_lds_pad > 0 && b->knob.place_lds_pad <= 44 ? b->knob.place_lds_pad : 0) * 1024, b->stream>>>(PL_ARGS, nullptr, order, b->dPerm.p, b->dPermCnt.p, xm);
+					}
+					else if(S == 8) PL_GO(8, 2, 3, 0, 2);
+					else k_place_blk<12, 2, 3, 0, 2, false, 1><<<grid, 128, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
+				}
+				else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
+				else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
+				/* 256 VGPRs: one candidate of four waves per CU.  Measured and not kept: six waves x 8 sites with the v message in LDS (72 KB; 156 VGPRs, two
+				 * candidates on twelve waves per CU): 8.53 ms against 8.2 per 4,096 pairs of 2 x 250 bases, 244 k against 277 k pairs/s — the sweeps read v
+				 * through the LDS return path and every EM step crosses six waves */
+				/* regions of 2,049 .. 3,072 columns (merged mate pairs).  With everything in registers the kernel needs all 256 VGPRs (+ AGPRs): ONE candidate of
+				 * four waves per CU.  One component of v in LDS (VL = 1, 24 KB per workgroup) -> 239 VGPRs, two waves per SIMD, TWO candidates per CU:
+				 * 8.2 -> 4.96 ms per 4,096 pairs of 2 x 250 bases, 277 k -> 309 k pairs/s (the kernel's time goes with the resident candidates) */
+				else if(var == 9) PL_GO(12, 4, 3, 0, 1);     /* place_var = 9: the all-register form */
+				else k_place_blk<12, 4, 3, 0, 2, false, 1><<<grid, 256, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
+				#undef PL_GO
 			}
-			else if(var == 7 && spt2 <= 12) PL_GO(12, 2, 3, 0, 2);
-			else if(spt4 <= 8) PL_GO(8, 4, 3, 0, 1);
-			/* 256 VGPRs: one candidate of four waves per CU.  Measured and not kept: six waves x 8 sites with the v message in LDS (72 KB; 156 VGPRs, two
-			 * candidates on twelve waves per CU): 8.53 ms against 8.2 per 4,096 pairs of 2 x 250 bases, 244 k against 277 k pairs/s — the sweeps read v
-			 * through the LDS return path and every EM step crosses six waves */
-			/* regions of 2,049 .. 3,072 columns (merged mate pairs).  With everything in registers the kernel needs all 256 VGPRs (+ AGPRs): ONE candidate of
-			 * four waves per CU.  One component of v in LDS (VL = 1, 24 KB per workgroup) -> 239 VGPRs, two waves per SIMD, TWO candidates per CU:
-			 * 8.2 -> 4.96 ms per 4,096 pairs of 2 x 250 bases, 277 k -> 309 k pairs/s (the kernel's time goes with the resident candidates) */
-			else if(var == 9) PL_GO(12, 4, 3, 0, 1);     /* place_var = 9: the all-register form */
-			else k_place_blk<12, 4, 3, 0, 2, false, 1><<<(unsigned) nc, 256, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm);
-			#undef PL_GO
+			#undef PL_ARGS
 		}
-		#undef PL_ARGS
 		HIPCHK(hipGetLastError());
 		if(o->fix_root_loglik) { /* the intended root log-likelihood at the optimised lengths (documented deviation, off by default) */
 			if((rc = b->dRootLL.ensure(nc)) != HU_OK) return rc;

@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <new>
 #include <stdexcept>
+#include <sched.h>
+#include <atomic>
+#include <thread>
 #include "hu_common.h"
 
 static thread_local char g_err[512] = "";
@@ -24,6 +27,39 @@ void hu_set_error(const char* fmt, ...) {
 	va_end(ap);
 }
 extern "C" const char* hu_last_error(void) { return g_err; }
+
+/* ---- CPU budget (hu_common.h) */
+static int cpu_budget_compute() {
+	if(const char* e = getenv("HU_CPU_BUDGET")) { const int v = atoi(e); if(v >= 1) return v; }
+	long best = (long) std::thread::hardware_concurrency();
+	if(best < 1) best = 1;
+	{ cpu_set_t set; CPU_ZERO(&set); if(sched_getaffinity(0, sizeof(set), &set) == 0) { const long c = CPU_COUNT(&set); if(c >= 1 && c < best) best = c; } }
+	{ /* cgroup v2: "<quota> <period>" or "max <period>" */
+		FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+		if(f) { char q[64]; long per = 0; if(fscanf(f, "%63s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long c = (atol(q) + per - 1) / per; if(c >= 1 && c < best) best = c; } fclose(f); }
+	}
+	{ /* cgroup v1 */
+		FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"); FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+		long q = -1, per = 0;
+		if(fq && fp && fscanf(fq, "%ld", &q) == 1 && fscanf(fp, "%ld", &per) == 1 && q > 0 && per > 0) { const long c = (q + per - 1) / per; if(c >= 1 && c < best) best = c; }
+		if(fq) fclose(fq);
+		if(fp) fclose(fp);
+	}
+	return (int) best;
+}
+int hu_cpu_budget() { static const int b = cpu_budget_compute(); return b; }
+static std::atomic<int>& helper_tokens() { static std::atomic<int> t{hu_cpu_budget()}; return t; }
+int hu_helpers_acquire(int want) {
+	if(want <= 0) return 0;
+	std::atomic<int>& t = helper_tokens();
+	int have = t.load();
+	for(;;) {
+		const int take = std::min(want, std::max(have, 0));
+		if(take == 0) return 0;
+		if(t.compare_exchange_weak(have, have - take)) return take;
+	}
+}
+void hu_helpers_release(int n) { if(n > 0) helper_tokens().fetch_add(n); }
 
 int hu_catch_all(const char* fn) noexcept {
 	try { throw; }

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(THREADS) void k_estimate_blk(HuDbDev db, HuModelDev
 	__shared__ double red[2 * THREADS / 64];
 	__shared__ long long redl[2 * THREADS / 64];
 	constexpr int NW = THREADS / 64;
-	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, tid = threadIdx.x;
-	if(s >= seedCnt[read]) return;
+	const uint32_t slot = db.wideList ? db.wideList[blockIdx.x] : blockIdx.x;
+	const int read = slot / HU_MAX_SEEDS, s = slot % HU_MAX_SEEDS, tid = threadIdx.x;
+	if(s >= seedCnt[read] || hu_skip_width(db, rend[read] - rstart[read] + 1)) return;
 	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int v = db.parent[u];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_estimate_prod(HuDbDev db, HuMo
 	 * together and all but the first find them in the Infinity Cache / L2 (reads of one sample share their seeds) */
 	const uint32_t slot = order ? order[hu_xcd_pos(blockIdx.x, gridDim.x, xmap)] : blockIdx.x;
 	const int read = slot / HU_MAX_SEEDS, s = slot % HU_MAX_SEEDS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if(s >= seedCnt[read]) return;
+	if(s >= seedCnt[read] || hu_skip_width(db, rend[read] - rstart[read] + 1)) return;
 	const int un = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int vn = db.parent[un];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(64) void k_site_perm(HuDbDev db, int n, const int8_
 		const int32_t* __restrict__ rend, int gapCap, int baseCap, uint16_t* __restrict__ perm) {
 	const int read = blockIdx.x, lane = threadIdx.x;
 	const int start = rstart[read], len = rend[read] - start + 1;
+	if(hu_skip_width(db, len)) return;
 	uint16_t* __restrict__ pr = perm + (size_t) read * (gapCap + baseCap);
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	int g = 0, bc = 0;
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_place_blk(HuDbDev db, HuModelD
 	const HuCand cd = cands[ci];
 	const int read = cd.read, un = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
+	if(hu_skip_width(db, n)) return;
 	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
 	const double rKc = 1.0 / (double) Kc;
 	const int8_t* __restrict__ cdr = codes + (size_t) read * db.csLen + start;

@@ -130,13 +130,13 @@ __global__ __launch_bounds__(64) void k_filter(int n, const int32_t* __restrict_
 }
 
 /* candidate offsets (exclusive scan of the counts, total at [n]) and what the placement launch needs to know of the batch: the number of
- * candidates and the largest gap / base site counts of a read with a region (k_site_count) — one workgroup */
+ * candidates and the largest gap / base site counts of a read with a region of at most rMain columns (0: any; k_site_count) — one workgroup */
 __global__ __launch_bounds__(1024) void k_cand_scan(int n, const int32_t* __restrict__ candCnt, int32_t* __restrict__ candOff, const int32_t* __restrict__ permCnt,
-		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int32_t* __restrict__ meta) {
+		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int32_t* __restrict__ meta, int rMain) {
 	__shared__ int part[1024], mg[1024], mb[1024];
 	const int tid = threadIdx.x, per = (n + 1023) / 1024, a0 = tid * per, a1 = min(n, a0 + per);
 	int s = 0, g = 0, bs = 0;
-	for(int r = a0; r < a1; ++r) { s += candCnt[r]; if(permCnt && rend[r] >= rstart[r]) { g = max(g, permCnt[2 * r]); bs = max(bs, permCnt[2 * r + 1]); } }
+	for(int r = a0; r < a1; ++r) { s += candCnt[r]; if(permCnt && rend[r] >= rstart[r] && (!rMain || rend[r] - rstart[r] + 1 <= rMain)) { g = max(g, permCnt[2 * r]); bs = max(bs, permCnt[2 * r + 1]); } }   /* the maxima of the main launch's reads */
 	part[tid] = s; mg[tid] = g; mb[tid] = bs;
 	__syncthreads();
 	if(tid == 0) { int acc = 0, G = 0, B = 0; for(int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = acc; acc += v; G = max(G, mg[i]); B = max(B, mb[i]); } candOff[n] = acc; meta[0] = acc; meta[1] = G; meta[2] = B; }

@@ -1218,8 +1218,9 @@ __device__ inline void estimate_body(const HuDbDev& db, const HuModelDev& mdl, c
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, const uint32_t* __restrict__ parDN,
 		const int32_t* __restrict__ seedCnt, const int32_t* __restrict__ seedId, const uint32_t* __restrict__ seedDN,
 		int weighted, HuEstOut* __restrict__ out) {
-	const int read = blockIdx.x / HU_MAX_SEEDS, s = blockIdx.x % HU_MAX_SEEDS, lane = threadIdx.x;
-	if(s >= seedCnt[read]) return;
+	const uint32_t slot = db.wideList ? db.wideList[blockIdx.x] : blockIdx.x;
+	const int read = slot / HU_MAX_SEEDS, s = slot % HU_MAX_SEEDS, lane = threadIdx.x;
+	if(s >= seedCnt[read] || hu_skip_width(db, rend[read] - rstart[read] + 1)) return;
 	const int u = seedId[(size_t) read * HU_MAX_SEEDS + s];
 	const int v = db.parent[u];
 	const uint32_t dn = seedDN[(size_t) read * HU_MAX_SEEDS + s];
@@ -1478,9 +1479,11 @@ __device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, cons
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
 		const HuCand* __restrict__ cands, HuPlaceOut* __restrict__ out, double* lds) {
 	const int lane = threadIdx.x;
-	const HuCand cd = cands[blockIdx.x];
+	const uint32_t ci = db.wideList ? db.wideList[blockIdx.x] : blockIdx.x;
+	const HuCand cd = cands[ci];
 	const int read = cd.read, u = cd.node;
 	const int start = rstart[read], end = rend[read], n = end - start + 1;
+	if(hu_skip_width(db, n)) return;
 	const int Kc = mdl.dgK > 0 ? mdl.dgK : 1;
 	double* Gtab = lds;                    /* [16]    G_mn for the (u, v) pair of branches                 */
 	double* Ttab = Gtab + 16;              /* [5][16] T^b_mn for the (v, n) pair and each leaf vector      */
@@ -1580,7 +1583,7 @@ __device__ inline void place_body(const HuDbDev& db, const HuModelDev& mdl, cons
 		if(fabs(wur - wur0) < HU_BRANCH_EPS && fabs(wnr - wnr0) < HU_BRANCH_EPS) { ++iter; break; }
 		wur0 = wur; wnr0 = wnr;
 	}
-	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[blockIdx.x] = o; }
+	if(lane == 0) { HuPlaceOut o; o.wnr = lenNR; o.wur = lenUR; o.iters = iter; o.pad = emIters; out[ci] = o; }
 }
 
 #define HU_PLACE_KERNEL(NAME, PAIR, MINW) \

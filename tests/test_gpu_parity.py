@@ -1531,3 +1531,50 @@ def test_align_with_misplaced_and_overlapping_seeds():
             v[0] = v[1]; v[1] = 0
         seqs.append(r.seq); vps.append(v)
     _check_alignments(E, db, H, seqs, np.stack(vps))
+
+
+@pytest.mark.gpu
+def test_width_split_of_a_batch(capfd):
+    """A few reads with alignment regions of ~1,500 columns among 400 reads of ~300: the estimate and placement kernels take their shape from the widest
+    region of a launch, so those reads get launches of their own (plan_width_split: HuDbDev::rLo / rHi / wideList) and the rest keep the narrow kernels —
+    same candidates, same iteration counts and the same numbers as the one-launch form (knob width_split = 0), and parity with the oracle as ever."""
+    E = _engine()
+    from hmmufotu_amd import synth
+    from oracle import oracle_py as O
+    db = get_db(80, 2800, "GTR", dg_k=4)
+    _, H, T = oracle_objects(db)
+    rng = np.random.default_rng(33)
+    narrow = synth.simulate_reads(db, 400, 150, rng, amplicon_start=300, amplicon_cols=330, jitter=20)
+    wide = synth.simulate_reads(db, 3, 100000, rng, amplicon_start=100, amplicon_cols=1500, jitter=20)
+    sims = list(narrow)
+    for k, w in zip((17, 211, 399), wide):
+        sims[k] = w
+    reads = [r.seq for r in sims]
+    vps = np.stack([synth.read_vpaths(db.hmm, r) for r in sims])
+    opts = E.default_opts()
+    D = E.Database.from_synth(db); B = E.Batch(D, 512)
+    B.set_knob("trace", 1)
+    B.set_reads(reads, vps); B.assign(opts)
+    err = capfd.readouterr().err
+    assert "width split: 3 of 400 reads beyond" in err, err[-600:]
+    recs = B.alignments(want_align=False)["recs"]
+    span = recs["cs_end"] - recs["cs_start"] + 1
+    assert (span > 1024).sum() == 3 and np.sort(span)[-4] <= 512, np.sort(span)[-6:]
+    best = B.placements().copy(); c1 = {k: v.copy() for k, v in B.candidates().items()}
+    er, ew, el = [x.copy() for x in B.estimates()]
+    ref = O.pipeline_batch(H, T, reads, vps, threads=4, want_cands=True)
+    assert np.array_equal(recs["cost"], ref["cost"]) and (best["n_cand"] == ref["n_cand"]).all()
+    tot = classify_batch(ref, c1, best, db.parent)
+    assert tot["set_differs"] == 0 and tot["swaps_unexplained"] == 0 and tot["best_unexplained"] == 0, tot
+    for k in (17, 211, 399):                                       # the wide reads are placed like any other
+        assert best["c_node"][k] >= 0 and best["n_cand"][k] == ref["n_cand"][k]
+    # one launch for everything, shaped by the widest region: the same results
+    B.set_knob("width_split", 0); B.assign(opts)
+    assert "width split" not in capfd.readouterr().err
+    c0 = B.candidates(); b0 = B.placements()
+    er0, ew0, el0 = B.estimates()
+    assert np.array_equal(er, er0, equal_nan=True) and np.array_equal(ew, ew0, equal_nan=True) and np.nanmax(np.abs(el - el0) / np.maximum(np.abs(el0), 1.0)) < 1e-12
+    assert np.array_equal(c1["offs"], c0["offs"]) and np.array_equal(c1["c_node"], c0["c_node"]) and np.array_equal(c1["iters"], c0["iters"])
+    assert np.abs(c1["ratio"] - c0["ratio"]).max() < 1e-11 and np.abs(c1["wnr"] - c0["wnr"]).max() < 1e-11
+    assert np.array_equal(best["c_node"], b0["c_node"])
+    B.close(); D.close()

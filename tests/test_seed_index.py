@@ -152,3 +152,29 @@ def test_bad_arguments():
     ix = E.SeedIndex(db.parent, db.seq, db.hmm, 15)
     assert (ix.lookup(["ACGTNNNNACGT", "AC"], 50, 0) == 0).all()   # shorter than the seed: no path, not an error
     assert ix.bytes > 0 and ix.size <= ix.positions
+
+
+def test_lookup_is_the_same_under_any_cpu_budget():
+    """the helper threads of every host pool come out of one budget (hu_cpu_budget: hardware, affinity mask, cgroup CPU quota; HU_CPU_BUDGET
+    overrides): with none left the caller does all the work itself — same paths either way"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, zlib, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import get_db, sim_reads
+from hmmufotu_amd import engine as E
+db = get_db(120, 700, "GTR", dg_k=4)
+ix = E.SeedIndex(db.parent, db.seq, db.hmm, 20)
+reads, _ = sim_reads(db, 3000, 150, seed=5)
+vp = ix.lookup([r.seq for r in reads], 50, 0)
+print(zlib.crc32(np.ascontiguousarray(vp).tobytes()), int(np.asarray(vp).any(axis=(1, 2)).sum()))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for budget in ("1", "3", "64"):
+        env = dict(os.environ, HU_CPU_BUDGET=budget)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2] and int(outs[0].split()[1]) > 1000, outs
