@@ -81,7 +81,8 @@ def cpu_quota():
                 c = min(c, max(1, -(-q // per)))
         except Exception:
             pass
-    return c
+    w = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return max(1, c // w) if w > 1 else c
 
 
 def kernel_source_hash():

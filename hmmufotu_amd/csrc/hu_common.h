@@ -167,7 +167,7 @@ int hu_read_model_text(std::istream& in, hu_model_desc& m);
 
 /* The CPUs this process may really use: the smallest of the hardware's, the affinity mask's and the cgroup's CPU quota (a container that shows
  * 256 CPUs with a quota of 16 stops EVERY thread of the process for the rest of the period once its threads have used the quota — also the ones
- * that feed the GPU).  HU_CPU_BUDGET overrides.  Helper threads of all pools together stay within it: a run asks for helpers and takes what is
+ * that feed the GPU), divided by LOCAL_WORLD_SIZE when a launcher runs one rank per GPU.  HU_CPU_BUDGET overrides.  Helper threads of all pools together stay within it: a run asks for helpers and takes what is
  * left (possibly none: the caller always works itself). */
 int hu_cpu_budget();
 int hu_helpers_acquire(int want);

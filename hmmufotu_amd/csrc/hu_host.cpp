@@ -45,6 +45,8 @@ static int cpu_budget_compute() {
 		if(fq) fclose(fq);
 		if(fp) fclose(fp);
 	}
+	/* one process per GPU under a launcher (torch.distributed.run sets LOCAL_WORLD_SIZE): the ranks of a node share its CPUs */
+	if(const char* e = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(e); if(w > 1) best = std::max<long>(1, best / w); }
 	return (int) best;
 }
 int hu_cpu_budget() { static const int b = cpu_budget_compute(); return b; }
