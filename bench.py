@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--amplicon-cols", type=int, default=0, help="CS columns of the simulated amplicon (0: from the read length)")
     ap.add_argument("--uniform-starts", action="store_true", help="read starts uniform over the resident window (SURVEY §8d second run)")
     ap.add_argument("--partial-frac", type=float, default=0.0, help="fraction of the leaves that lose a prefix or suffix (partial reference sequences)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 15 s worth)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 30 s worth on the CPUs the process may use)")
     ap.add_argument("--seed-order", choices=["stable", "reference"], default="stable",
                     help="hu_opts.seed_order: 'stable' = (dist, node id), selected on the device [default]; 'reference' = the first max_nseed of libstdc++'s "
                          "std::sort on dist alone (HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, reproduced on the device by k_seed_refsort)")
@@ -248,7 +248,7 @@ def main():
                                         threads=cores, mode=1, want_lib=lib)
             n0 = min(len(reads_c), max(cores, 16))
             tc = time.perf_counter(); phase_a(n0, False); d0 = time.perf_counter() - tc
-            ns = args.cpu_sample if args.cpu_sample > 0 else int(min(len(reads_c), max(n0, 12.0 / max(d0 / n0, 1e-6))))
+            ns = args.cpu_sample if args.cpu_sample > 0 else int(min(len(reads_c), max(n0, 24.0 / max(d0 / n0, 1e-6))))
             ns = min(ns, len(reads_c))
             tc = time.perf_counter(); p1 = phase_a(ns, True); dA = time.perf_counter() - tc
             dA -= p1["extra_thread_sec"] / cores               # the libstdc++ order of the same scan is not part of the task
