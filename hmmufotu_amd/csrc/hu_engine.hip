@@ -809,7 +809,7 @@ struct hu_batch {
 	DBuf<uint32_t> dRp, dPairs, dSeedDN, dParDN, dBmin, dRSpan, dTileSpan;     /* dRSpan / dTileSpan: uint2 per read / tile */
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
-	DBuf<unsigned long long> dRefScratch;      /* k_seed_refsort: two arrays of 64-bit elements per resident workgroup */
+	DBuf<unsigned long long> dRefScratch;      /* k_seed_refsort: two key arrays + the level tables per resident workgroup */
 	DBuf<int32_t> dBail;
 	int nRefBail = 0;                            /* reads of the last seed stage that the device sort left to the host */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
@@ -1371,11 +1371,11 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	HIPCHK(hipEventRecord(e0, nullptr));
 	if(pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds>>>(d, dP16.p, rows, dSt.p, dEn.p, k, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds>>>(d, dP16.p, rows, dSt.p, dEn.p, k, scr.p, hu_refsort_words(m0, 2), cap, (int) rsOff, (int) hu_refsort_tabcap(m0), dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds>>>(d, dP32.p, rows, dSt.p, dEn.p, k, scr.p, cap, (int) rsOff, dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds>>>(d, dP32.p, rows, dSt.p, dEn.p, k, scr.p, hu_refsort_words(m0, 4), cap, (int) rsOff, (int) hu_refsort_tabcap(m0), dCnt.p, dId.p, dDN.p, dPN.p, dBail.p);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(e1, nullptr));
@@ -1383,8 +1383,8 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	if(getenv("HU_RS_TIMING")) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d rows x %lld elements, grid %d: %.3f ms\n", rows, (long long) n, G, ms);
 #ifdef HU_RS_PROF
 		unsigned long long pr[16]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
-		static const char* nm[9] = {"idle/output", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher"};
-		for(int i = 0; i < 9; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
+		static const char* nm[10] = {"idle", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher", "trace-back"};
+		for(int i = 0; i < 10; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
 		unsigned long long z[16] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
 #endif
 	}
@@ -1393,7 +1393,10 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	HIPCHK(hipMemcpy(ids.data(), dId.p, ids.size() * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(hb.data(), dBail.p, hb.size() * 4, hipMemcpyDeviceToHost));
 	for(int r = 0; r < rows; ++r) { out_cnt[r] = cnt[r]; for(int s = 0; s < k; ++s) out_idx[(size_t) r * k + s] = s < cnt[r] ? ids[(size_t) r * HU_MAX_SEEDS + s] : -1; }
-	for(int i = 0; i < hb[0]; ++i) out_cnt[hb[2 + i]] = -1;
+	for(int i = 0; i < hb[0]; ++i) {
+		out_cnt[hb[2 + i] & 0x3ffffff] = -1;
+		if(getenv("HU_RS_TIMING")) fprintf(stderr, "[hu]   row %d left to the host: reason %d (1 depth, 2 tables, 3 NaN, 4 no stopper, 5 stash, 6 finisher)\n", hb[2 + i] & 0x3ffffff, hb[2 + i] >> 26);
+	}
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_sort_prefix_device"); }
 
@@ -1421,12 +1424,12 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	if(b->pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
-				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
-				b->dRefScratch.p, cap, (int) rsOff, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	HIPCHK(hipGetLastError());
 	if(e1) HIPCHK(hipEventRecord(e1, b->stream));
@@ -1435,7 +1438,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	HIPCHK(hipStreamSynchronize(b->stream));
 	b->nRefBail = hb[0];
 	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", ms, hb[0]); }
-	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 2, hb.begin() + 2 + hb[0]); std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
+	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 2, hb.begin() + 2 + hb[0]); for(int32_t& x : only) x &= 0x3ffffff; std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
 	return HU_OK;
 }
 

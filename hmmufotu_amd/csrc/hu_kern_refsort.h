@@ -9,12 +9,21 @@
 // left, i_1 < i_2 < ..., and the RIGHT STOPPERS (elements <= pivot) numbered from the right, j_1 > j_2 > ..., the sequential scans swap
 // exactly the pairs (i_k, j_k) with i_k < j_k, k = 1 .. m, and return cut = min(i_(m+1), j_m) (the left scan of the last round stops at
 // the next original left stopper or at the swapped-in element at j_m, whichever comes first; cut = i_1 when nothing is swapped).  Ranks
-// are prefix counts, so a partition is two data-parallel passes: count the stoppers per 64-element subtile (ballots), scan the counts,
-// locate cut and m, copy the right stoppers j_1 .. j_m out by rank, and write the left part [first, cut) of the next level with the left
-// stoppers replaced by them.  Only the left part is written: the right part matters only when cut falls inside the first K places —
-// then the (tiny) left part is set aside and the right part is written instead.  Ranges of at most HU_RS_SMALL elements are finished
-// by one thread in LDS with the literal sequential algorithm.  Reads the device does not finish (a NaN distance, the heap-sort branch of
-// introsort, keys that do not fit) are listed for the host path.
+// are prefix counts, so a partition is data-parallel: stopper masks per 64-element subtile (ballots), a scan of their counts, cut and m,
+// the right stoppers j_1 .. j_m copied out by rank (pass B1), and the left part [first, cut) of the next level written with its left
+// stoppers replaced by them (pass B2).  Only the left part is written: the right part matters only when cut falls inside the first K
+// places — then the (tiny) left part is set aside and the right part is written instead.
+//
+// Second form (round 3, second half).  A level carries the KEYS ONLY (the (d, N) pair, 2 or 4 bytes): the first form moved a 4-byte node id
+// beside every key through every level — two thirds of its bytes — although only the K elements that end in the first places ever need
+// theirs.  Instead every level leaves its stopper masks and their scanned counts behind (24 bytes per 64 elements), and the K survivors are
+// TRACED BACK through the levels afterwards: a position of the array after a partition came from the same position (not a stopper), or from
+// the partner of its rank (select on the other mask through the scanned counts), then through the pivot swap.  And the count pass of a level
+// is fused into the pass that writes it: the next pivot is the median of three elements of an array that is not written yet, but each of
+// them is either an element of the current array or a right stopper of known rank — three lookups; pass B2 then classifies what it writes
+// against that pivot.  Only level 0 (the pair row itself) and a level after a tiny left part run a counting pass of their own (pass A).
+// Ranges of at most HU_RS_SMALL elements are finished by one thread in LDS with the literal sequential algorithm.  Reads the device does
+// not finish (a NaN distance, the heap-sort branch of introsort, tables that overflow) are listed for the host path.
 //
 // No floating point anywhere: dist = d / N is compared through d_a * N_b < d_b * N_a in the streaming passes, and the sequential finisher works on
 // the exact integer keys floor(d * 2^32 / N) of the few hundred elements it receives (rs_key).
@@ -33,6 +42,7 @@
 #endif
 #define HU_RS_TRIP (HU_RS_THREADS * HU_RS_U)
 #define HU_RS_FIN (HU_RS_SMALL + 96)        /* LDS array of the sequential finisher: the set-aside prefix (< 64 places) + the last range */
+#define HU_RS_MAXLEV 64                     /* partitions of one read on the device; introsort's own limit is 2 lg n (<= 48 for n < 2^24) */
 
 struct HuRsRange { int lo, hi, depth; };
 
@@ -45,55 +55,55 @@ __device__ unsigned long long g_rs_prof[16];
 
 __device__ inline uint64_t rs_lane_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ inline uint64_t rs_lane_ge(int lane) { return ~0ull << lane; }
+/* position of the n-th (1-based) set bit of m from bit 0; m holds at least n bits */
+__device__ inline int rs_nth_low(uint64_t m, int n) {
+	int pos = 0;
+#pragma unroll
+	for(int w = 32; w >= 1; w >>= 1) {
+		const int c = __popcll(m & (((1ull << w) - 1ull) << pos));
+		if(c < n) { n -= c; pos += w; }
+	}
+	return pos;
+}
+__device__ inline int rs_nth_high(uint64_t m, int n) { return 63 - rs_nth_low(__brevll(m), n); }
 
-/* An element is (d << 48 | N << 32 | node) in registers: the pair as the scan left it beside its position in node order.  dist = d / N as the
- * reference computes it is a correctly rounded double division of two integers below 2^16: equal fractions give equal doubles and different
- * fractions different ones (they differ by at least 2^-32 relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers,
- * and no division in the streaming passes.  The sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives.
- * In memory a level is two arrays — the pairs in the width the scan wrote them (2 or 4 bytes) and the node ids (4 bytes): the counting pass
- * reads the pairs only. */
+/* An element is its (d << 16 | N) pair as the scan left it.  dist = d / N as the reference computes it is a correctly rounded double division
+ * of two integers below 2^16: equal fractions give equal doubles and different fractions different ones (they differ by at least 2^-32
+ * relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers, and no division in the streaming passes.  The
+ * sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives. */
 __device__ inline bool rs_ltp(uint32_t pa, uint32_t pb) { return (pa >> 16) * (pb & 0xffffu) < (pb >> 16) * (pa & 0xffffu); }
-__device__ inline bool rs_lt(uint64_t a, uint64_t b) { return rs_ltp((uint32_t)(a >> 32), (uint32_t)(b >> 32)); }
-template<class PT> struct HuRsLevel {          /* one level in the workgroup's scratch: [cap] ids, [cap] pairs; positions are absolute */
-	uint32_t* ids; PT* keys;
-	__device__ inline uint64_t load(int p) const { return ((uint64_t) HuPair<PT>::canon(keys[p]) << 32) | (uint64_t) ids[p]; }
-	__device__ inline void store(int p, uint64_t e) const { keys[p] = HuPair<PT>::pack((uint32_t)(e >> 32)); ids[p] = (uint32_t) e; }
-};
-/* The streaming passes load through rs_pair / rs_node: no branch between the loads of one trip (the level is a template argument, the two
+/* The streaming passes load through rs_pair: no branch between the loads of one trip (the level is a template argument, the two
  * patches of level 0 are selects), so that the loads of a thread are in flight together — behind a divergent branch each one is waited for
- * before the next is issued.  Level 0 is the row itself in node order without the root. */
+ * before the next is issued.  Level 0 is the row itself in node order without the root; later levels are arrays of pairs by absolute position. */
 template<bool L0, class PT>
-__device__ inline uint32_t rs_pair(const HuRsLevel<PT>& src, const PT* __restrict__ row, int root, int p, int pA, uint64_t vA, int pB, uint64_t vB, bool& nan) {
-	if(!L0) return HuPair<PT>::canon(src.keys[p]);
+__device__ inline uint32_t rs_pair(const PT* __restrict__ src, const PT* __restrict__ row, int root, int p, int pA, uint32_t vA, int pB, uint32_t vB, bool& nan) {
+	if(!L0) return HuPair<PT>::canon(src[p]);
 	uint32_t pr = HuPair<PT>::canon(row[p < root ? p : p + 1]);
 	nan |= (pr & 0xffffu) == 0;
-	pr = p == pA ? (uint32_t)(vA >> 32) : pr;
-	pr = p == pB ? (uint32_t)(vB >> 32) : pr;
+	pr = p == pA ? vA : pr;
+	pr = p == pB ? vB : pr;
 	return pr;
 }
-template<bool L0, class PT>
-__device__ inline uint32_t rs_node(const HuRsLevel<PT>& src, int root, int p, int pA, uint64_t vA, int pB, uint64_t vB) {
-	if(!L0) return src.ids[p];
-	uint32_t id = (uint32_t)(p < root ? p : p + 1);
-	id = p == pA ? (uint32_t) vA : id;
-	id = p == pB ? (uint32_t) vB : id;
-	return id;
-}
-/* key of an element for the finisher: floor(d * 2^32 / N) above the node id.  Exact: d <= N < 2^16, so the key has 33 bits, and two different
- * fractions differ by at least 1 / (N_a N_b) > 2^-32 — their keys differ; equal fractions have equal keys.  One 64-bit division per element
- * of the last range (<= HU_RS_FIN per read). */
+/* key of an element for the finisher: floor(d * 2^32 / N) above a 31-bit tag (the level whose array the element sits in << 24 | its position
+ * there; the trace-back turns it into a node).  Exact: d <= N < 2^16, so the key has 33 bits, and two different fractions differ by at least
+ * 1 / (N_a N_b) > 2^-32 — their keys differ; equal fractions have equal keys.  One 64-bit division per element of the last range. */
 #define HU_RS_IDBITS 31
-__device__ __attribute__((noinline)) uint64_t rs_key(uint64_t e) {
-	const uint32_t pr = (uint32_t)(e >> 32);
-	return ((((uint64_t)(pr >> 16) << 32) / (uint64_t)(pr & 0xffffu)) << HU_RS_IDBITS) | (e & 0x7fffffffull);
+__device__ __attribute__((noinline)) uint64_t rs_key(uint32_t pr, uint32_t tag) {
+	return ((((uint64_t)(pr >> 16) << 32) / (uint64_t)(pr & 0xffffu)) << HU_RS_IDBITS) | (uint64_t) tag;
 }
 
-/* scratch of one workgroup: two levels of cap positions (the m0 positions, then room for the right stoppers of a partition: at most half of
- * them are swapped), each a 4-byte id array and a pairBytes-wide pair array; in 8-byte words */
+/* scratch of one workgroup.  Two key buffers of cap positions (the m0 positions, then room for the right stoppers of a partition: at most half
+ * of them are swapped); the tables of all levels: per 64-element subtile the scanned counts (2 x 4 bytes) and the two stopper masks (2 x 8
+ * bytes), tabCap subtiles in all (a level takes its subtiles + 1 rounded up to 64; levels shrink geometrically on anything but adversarial
+ * rows, and a read whose tables do not fit goes to the host path) */
 static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 63) + m0 / 2 + 64 + 63) & ~(size_t) 63; }
-static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return 2 * hu_refsort_cap(m0) * (4 + (size_t) pairBytes) / 8; }
+static inline size_t hu_refsort_tabcap(size_t m0) { const size_t nt = ((m0 + 63) / 64 + 64) & ~(size_t) 63; return 4 * nt + 2048; }
+static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * hu_refsort_cap(m0) * (size_t) pairBytes + 7) / 8 + 3 * hu_refsort_tabcap(m0)) + 1) & ~(size_t) 1; }
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
-static inline size_t hu_refsort_lds(int nNodes) { const size_t NT = ((size_t) nNodes - 1 + 63) / 64; return (HU_RS_FIN + 64) * 8 + 2 * (NT + 2) * 4; }
+static inline size_t hu_refsort_lds(int nNodes) {
+	const size_t m0 = (size_t) nNodes - 1, NT = (m0 + 63) / 64;
+	return HU_RS_FIN * 8 + 64 * 4 + 2 * (NT + 2) * 4 + 2 * (hu_refsort_tabcap(m0) / 64) * 4 + (NT + 2) * 2;
+}
 
 /* the literal sequential algorithm on an LDS array, for one thread: introsort loop restricted to ranges that start before place K */
 __device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* LDS [72] */, int first, int last, int depth, int K) {
@@ -134,25 +144,46 @@ __device__ __attribute__((noinline)) bool rs_seq_loop(uint64_t* a, int* stk /* L
 	return true;
 }
 
+/* which of three elements __move_median_to_first picks: 0 = the one at first + 1, 1 = mid, 2 = last - 1 */
+__device__ inline int rs_median3(uint32_t a, uint32_t b, uint32_t c) {
+	if(rs_ltp(a, b)) { if(rs_ltp(b, c)) return 1; else if(rs_ltp(a, c)) return 2; else return 0; }
+	else if(rs_ltp(a, c)) return 0;
+	else if(rs_ltp(b, c)) return 2;
+	return 1;
+}
+
 template<class PT>
 __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K,
-		unsigned long long* __restrict__ scratch, size_t cap, int rsOff,
+		unsigned long long* __restrict__ scratch, size_t wgWords, size_t cap, int rsOff, int tabCap,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
 		int32_t* __restrict__ bail) {
 	extern __shared__ unsigned char rs_smem[];
 	const int m0 = db.nNodes - 1;
 	const int NT = (m0 + 63) >> 6;
+	const int NC = tabCap >> 6;
 	uint64_t* fin = reinterpret_cast<uint64_t*>(rs_smem);                  /* [HU_RS_FIN]: the sequential finisher's array, by absolute position */
-	uint64_t* lsb = fin + HU_RS_FIN;                                       /* [64]: left stoppers of a tiny left part */
-	uint32_t* preL = reinterpret_cast<uint32_t*>(lsb + 64);                /* [NT + 2] */
+	uint32_t* lsb = reinterpret_cast<uint32_t*>(fin + HU_RS_FIN);          /* [64]: left stoppers of a tiny left part */
+	uint32_t* preL = lsb + 64;                                             /* [NT + 2] */
 	uint32_t* sufR = preL + (NT + 2);                                      /* [NT + 2] */
+	uint32_t* cPre = sufR + (NT + 2);                                      /* [NC]: every 64th entry of every level's scanned counts (trace-back) */
+	uint32_t* cSuf = cPre + NC;                                            /* [NC] */
+	uint16_t* cnt16 = reinterpret_cast<uint16_t*>(cSuf + NC);              /* [NT + 2]: stoppers per subtile, left | right << 8, before the scan */
 	__shared__ unsigned long long wtot[HU_RS_THREADS / 64];
-	__shared__ uint64_t shE[4];              /* pivot element, patch values */
+	__shared__ uint32_t shP[4];              /* pivot pair, the pair it displaced, next pivot pair */
 	__shared__ int shI[12];                  /* broadcast slots */
 	__shared__ HuRsRange stash[12];
 	__shared__ int seqStack[72];
+	__shared__ int hLo[HU_RS_MAXLEV], hW[HU_RS_MAXLEV], hCut[HU_RS_MAXLEV], hM[HU_RS_MAXLEV], hOff[HU_RS_MAXLEV], hNC[HU_RS_MAXLEV];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	/* this workgroup's scratch */
+	PT* bufA; PT* bufB; uint32_t* gPre; uint32_t* gSuf; unsigned long long* gML; unsigned long long* gMR;
+	{
+		unsigned long long* base = scratch + (size_t) blockIdx.x * wgWords;
+		gML = base; gMR = base + tabCap;
+		gPre = reinterpret_cast<uint32_t*>(base + 2 * (size_t) tabCap); gSuf = gPre + tabCap;
+		bufA = reinterpret_cast<PT*>(base + 3 * (size_t) tabCap); bufB = bufA + cap;
+	}
 #ifdef HU_RS_PROF
 	unsigned long long t_prof = wall_clock64();
 #endif
@@ -167,70 +198,73 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		RS_T(0);
 		if(rend[read] < rstart[read] || m0 < 1) { if(tid == 0) seedCnt[read] = 0; continue; }
 		const PT* __restrict__ row = pairs + (size_t) read * db.nNodesPad;
-		HuRsLevel<PT> bufA, bufB;
-		{
-			unsigned char* base = reinterpret_cast<unsigned char*>(scratch) + (size_t) blockIdx.x * 2 * cap * (4 + sizeof(PT));
-			bufA.ids = reinterpret_cast<uint32_t*>(base); bufA.keys = reinterpret_cast<PT*>(base + cap * 4);
-			base += cap * (4 + sizeof(PT));
-			bufB.ids = reinterpret_cast<uint32_t*>(base); bufB.keys = reinterpret_cast<PT*>(base + cap * 4);
-		}
-		HuRsLevel<PT> src = {nullptr, nullptr}, dst = bufA;       /* src.ids == nullptr: the implicit level-0 array */
+		const PT* src = nullptr; PT* dst = bufA;              /* src == nullptr: the implicit level-0 array */
 		bool level0 = true;
-		int lo = 0, hi = m0, depth = 0, nStash = 0;
+		int lo = 0, hi = m0, depth = 0, nStash = 0, level = 0, tabNext = 0;
 		for(int x = m0; x > 1; x >>= 1) ++depth;
 		depth *= 2;
-		int pA = -1, pB = -1; uint64_t vA = 0, vB = 0;   /* level 0: the one swap of the pivot selection, kept as two patches */
-		bool failed = false, nan = false;
-		auto E = [&](int p) -> uint64_t {                /* any element, off the streaming passes */
-			if(!level0) return src.load(p);
-			return ((uint64_t) rs_pair<true>(src, row, db.root, p, pA, vA, pB, vB, nan) << 32) | (uint64_t) rs_node<true>(src, db.root, p, pA, vA, pB, vB);
+		int pA = -1, pB = -1; uint32_t vA = 0, vB = 0;   /* level 0: the one swap of the pivot selection, kept as two patches */
+		bool failed = false, nan = false; int why = 0;        /* why a read is left to the host (bits 26.. of its entry in the list) */
+		bool counted = false;                            /* this level's pivot, swap, masks and counts were made by the pass that wrote it */
+		uint32_t pivP = 0; int wAbs = -1, off = 0;
+		auto E = [&](int p) -> uint32_t {                /* any element, off the streaming passes */
+			if(!level0) return HuPair<PT>::canon(src[p]);
+			return rs_pair<true, PT>(src, row, db.root, p, pA, vA, pB, vB, nan);
 		};
 		while(hi - lo > HU_RS_SMALL) {
-			if(depth == 0) { failed = true; break; }
+			if(depth == 0 || level >= HU_RS_MAXLEV) { failed = true; why = 1; break; }
 			--depth;
-			/* ---- pivot: median of lo + 1, mid, hi - 1 swapped into lo */
-			if(tid == 0) {
-				const int mid = lo + (hi - lo) / 2;
-				const uint64_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
-				int w; uint64_t ew;
-				if(rs_lt(ea, eb)) { if(rs_lt(eb, ec)) { w = mid; ew = eb; } else if(rs_lt(ea, ec)) { w = hi - 1; ew = ec; } else { w = lo + 1; ew = ea; } }
-				else if(rs_lt(ea, ec)) { w = lo + 1; ew = ea; }
-				else if(rs_lt(eb, ec)) { w = hi - 1; ew = ec; }
-				else { w = mid; ew = eb; }
-				shE[0] = ew; shE[1] = ef; shI[0] = w;
-				if(!level0) { src.store(lo, ew); src.store(w, ef); }
-			}
-			__threadfence_block();
-			__syncthreads();
-			RS_T(1);
-			const uint64_t pivE = shE[0];
-			if(level0) { pA = lo; vA = pivE; pB = shI[0]; vB = shE[1]; }
-			const uint32_t pivP = (uint32_t)(pivE >> 32);
 			const int M = hi - lo - 1, NTl = (M + 63) >> 6;
-			/* ---- pass A: stoppers per subtile of 64 positions q = p - (lo + 1) */
-			auto passA = [&](auto l0) {
-				constexpr bool L0 = decltype(l0)::value;
-				for(int base = 0; base < M; base += HU_RS_TRIP) {
-					uint32_t kv[HU_RS_U];
-#pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
-#pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) {
-						const int qb = base + u * HU_RS_THREADS, q = qb + tid;
-						const bool valid = q < M;
-						const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], pivP)), mR = __ballot(valid && !rs_ltp(pivP, kv[u]));
-						if(lane == 0 && qb + wave * 64 < M) { preL[(qb >> 6) + wave] = (uint32_t) __popcll(mL); sufR[(qb >> 6) + wave] = (uint32_t) __popcll(mR); }
-					}
+			const int R = (NTl + 1 + 63) & ~63;             /* table entries of this level: 0 .. NTl, padded */
+			if(!counted) {
+				off = tabNext;
+				if(off + R > tabCap) { failed = true; why = 2; break; }
+				tabNext = off + R;
+				/* ---- pivot: median of lo + 1, mid, hi - 1 swapped into lo */
+				if(tid == 0) {
+					const int mid = lo + (hi - lo) / 2;
+					const uint32_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
+					const int c = rs_median3(ea, eb, ec);
+					const int w = c == 0 ? lo + 1 : (c == 1 ? mid : hi - 1);
+					const uint32_t ew = c == 0 ? ea : (c == 1 ? eb : ec);
+					shP[0] = ew; shP[1] = ef; shI[0] = w;
+					if(!level0) { PT* s = const_cast<PT*>(src); s[lo] = HuPair<PT>::pack(ew); s[w] = HuPair<PT>::pack(ef); }
 				}
-			};
-			if(level0) passA(std::true_type{}); else passA(std::false_type{});
-			if(__syncthreads_or(nan ? 1 : 0)) { failed = true; break; }
-			RS_T(2);
+				__threadfence_block();
+				__syncthreads();
+				RS_T(1);
+				pivP = shP[0]; wAbs = shI[0];
+				if(level0) { pA = lo; vA = pivP; pB = wAbs; vB = shP[1]; }
+				/* ---- pass A: stopper masks per subtile of 64 positions q = p - (lo + 1) */
+				auto passA = [&](auto l0) {
+					constexpr bool L0 = decltype(l0)::value;
+					for(int base = 0; base < M; base += HU_RS_TRIP) {
+						uint32_t kv[HU_RS_U];
+#pragma unroll
+						for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+#pragma unroll
+						for(int u = 0; u < HU_RS_U; ++u) {
+							const int qb = base + u * HU_RS_THREADS, q = qb + tid;
+							const bool valid = q < M;
+							const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], pivP)), mR = __ballot(valid && !rs_ltp(pivP, kv[u]));
+							if(lane == 0 && qb + wave * 64 < M) {
+								const int t = (qb >> 6) + wave;
+								cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
+								gML[off + t] = mL; gMR[off + t] = mR;
+							}
+						}
+					}
+				};
+				if(level0) passA(std::true_type{}); else passA(std::false_type{});
+				if(__syncthreads_or(nan ? 1 : 0)) { failed = true; why = 3; break; }
+				RS_T(2);
+			}
+			counted = false;
 			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
 			{
 				const int per = (NTl + HU_RS_THREADS - 1) / HU_RS_THREADS, a0 = tid * per, a1 = min(NTl, a0 + per);
 				uint32_t sL = 0, sR = 0;
-				for(int t = a0; t < a1; ++t) { sL += preL[t]; sR += sufR[t]; }
+				for(int t = a0; t < a1; ++t) { const uint32_t c = cnt16[t]; sL += c & 0xffu; sR += c >> 8; }
 				/* both sums in one 64-bit word through one scan: inclusive within the wave on __shfl_up, the waves' totals through LDS */
 				unsigned long long w = (unsigned long long) sL | ((unsigned long long) sR << 32);
 #pragma unroll
@@ -243,11 +277,16 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				w += before;                                             /* inclusive prefix over the threads */
 				uint32_t accL = (uint32_t) w - sL;                       /* left stoppers in the chunks before this thread's */
 				uint32_t accR = (uint32_t)(total >> 32) - (uint32_t)(w >> 32);     /* right stoppers in the chunks after it */
-				if(tid == 0) shI[1] = (int)(uint32_t) total;
-				for(int t = a0; t < a1; ++t) { const uint32_t v = preL[t]; preL[t] = accL; accL += v; }
-				for(int t = a1 - 1; t >= a0; --t) { accR += sufR[t]; sufR[t] = accR; }
-				if(tid == 0) { preL[NTl] = (uint32_t) shI[1]; sufR[NTl] = 0; }
+				for(int t = a0; t < a1; ++t) { const uint32_t v = cnt16[t] & 0xffu; preL[t] = accL; accL += v; }
+				for(int t = a1 - 1; t >= a0; --t) { accR += cnt16[t] >> 8; sufR[t] = accR; }
+				if(tid == 0) { preL[NTl] = (uint32_t) total; sufR[NTl] = 0; }
 				__syncthreads();
+				/* the level's tables for the trace-back: entries 0 .. NTl, padded so that a block of 64 can be counted blindly */
+				for(int t = tid; t < R; t += HU_RS_THREADS) {
+					const uint32_t vL = t <= NTl ? preL[t] : 0xffffffffu, vR = t <= NTl ? sufR[t] : 0u;
+					gPre[off + t] = vL; gSuf[off + t] = vR;
+					if((t & 63) == 0) { cPre[(off + t) >> 6] = vL; cSuf[(off + t) >> 6] = vR; }
+				}
 			}
 			RS_T(3);
 			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
@@ -256,13 +295,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				/* first subtile t0 with preL[t0 + 1] >= sufR[t0 + 1] (positions of earlier subtiles all have g < 0) */
 				int t0;
 				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
-				auto masks = [&](int t, unsigned long long& mL, unsigned long long& mR) {
-					const int q = t * 64 + lane; const bool valid = q < M;
-					const uint32_t k = valid ? (uint32_t)(E(lo + 1 + q) >> 32) : 0;
-					mL = __ballot(valid && !rs_ltp(k, pivP)); mR = __ballot(valid && !rs_ltp(pivP, k));
-				};
-				unsigned long long mL, mR;
-				masks(t0, mL, mR);
+				unsigned long long mL = gML[off + t0], mR = gMR[off + t0];
 				int c0;
 				{
 					const int Lq = (int) preL[t0] + __popcll(mL & rs_lane_lt(lane));
@@ -272,11 +305,11 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				}
 				int tc = c0 >> 6, m, iNext = -1;                     /* iNext: i_(m+1), the first left stopper at or after c0 (-1: none) */
 				if(tc < NTl) {
-					if(tc != t0) masks(tc, mL, mR);
+					if(tc != t0) mL = gML[off + tc];
 					m = (int) preL[tc] + __popcll(mL & rs_lane_lt(c0 & 63));
 					unsigned long long cand = mL & rs_lane_ge(c0 & 63);
 					int t = tc;
-					while(!cand && ++t < NTl) { if(preL[t + 1] > preL[t]) { unsigned long long x, y; masks(t, x, y); cand = x; } }
+					while(!cand && ++t < NTl) { if(preL[t + 1] > preL[t]) cand = gML[off + t]; }
 					if(cand) iNext = t * 64 + (__ffsll((long long) cand) - 1);
 				}
 				else m = (int) preL[NTl];
@@ -284,10 +317,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				if(m >= 1) {
 					int a = 0, b = NTl - 1;                           /* last subtile t with sufR[t] >= m */
 					while(a < b) { const int md = (a + b + 1) >> 1; if((int) sufR[md] >= m) a = md; else b = md - 1; }
-					unsigned long long x, y; masks(a, x, y);
-					const int want = m - (int) sufR[a + 1];
-					const unsigned long long hit = __ballot(((y >> lane) & 1ull) && __popcll(y & rs_lane_ge(lane)) == want);
-					jm = a * 64 + (__ffsll((long long) hit) - 1);
+					jm = a * 64 + rs_nth_high(gMR[off + a], m - (int) sufR[a + 1]);
 				}
 				const int cutq = (m >= 1 && (iNext < 0 || iNext > jm)) ? jm : iNext;
 				if(lane == 0) { shI[2] = cutq; shI[3] = m; shI[4] = jm; }
@@ -295,26 +325,23 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			__syncthreads();
 			RS_T(4);
 			const int cutq = shI[2], m = shI[3], jm = shI[4];
-			if(cutq < 0) { failed = true; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
+			if(cutq < 0) { failed = true; why = 4; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
 			const int cutAbs = lo + 1 + cutq;
-			const HuRsLevel<PT> RS = {dst.ids + rsOff, dst.keys + rsOff};        /* right stoppers by rank, beyond the positions */
+			PT* RS = dst + rsOff;                                   /* right stoppers by rank, beyond the positions */
+			if(tid == 0) { hLo[level] = lo; hW[level] = wAbs; hCut[level] = cutAbs; hM[level] = m; hOff[level] = off; hNC[level] = R >> 6; }
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
 				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_TRIP) {
-					uint32_t kv[HU_RS_U], iv[HU_RS_U];
+					uint32_t kv[HU_RS_U];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) {
-						const int p = lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1);
-						kv[u] = rs_pair<L0>(src, row, db.root, p, pA, vA, pB, vB, nan);
-						iv[u] = rs_node<L0>(src, db.root, p, pA, vA, pB, vB);
-					}
+					for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
 					for(int u = 0; u < HU_RS_U; ++u) {
 						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
 						const bool rs = q < M && !rs_ltp(pivP, kv[u]);
 						const unsigned long long mR = __ballot(rs);
-						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) { RS.keys[rk - 1] = HuPair<PT>::pack(kv[u]); RS.ids[rk - 1] = iv[u]; } }
+						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) RS[rk - 1] = HuPair<PT>::pack(kv[u]); }
 					}
 				}
 			};
@@ -324,18 +351,36 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			RS_T(5);
 			const bool tiny = cutAbs < K;        /* the left part ends inside the first K places: the right part is needed too */
 			if(!tiny) {
-				/* ---- pass B2: the left part [lo, cut) of the next level */
-				if(tid == 0) dst.store(lo, pivE);
+				/* ---- the next level is [lo, cut).  While it is still a streaming level its pivot is chosen NOW — the median of the elements that
+				 * WILL stand at lo + 1, mid and cut - 1: each is the element there, or the right stopper of its rank if that one is a left stopper —
+				 * and pass B2 classifies what it writes against it */
+				const int nM = cutq, nNTl = (nM + 63) >> 6, nR = (nNTl + 1 + 63) & ~63;
+				const bool fuse = cutAbs - lo > HU_RS_SMALL && depth > 0 && level + 1 < HU_RS_MAXLEV && tabNext + nR <= tabCap;
+				if(fuse && wave == 0) {
+					const int mid = lo + (cutAbs - lo) / 2;
+					const int P = lane == 0 ? lo + 1 : (lane == 1 ? mid : cutAbs - 1);
+					uint32_t pr = 0;
+					if(lane < 3) {
+						pr = E(P);
+						if(!rs_ltp(pr, pivP)) { const int q = P - (lo + 1); pr = HuPair<PT>::canon(RS[(int) preL[q >> 6] + __popcll(gML[off + (q >> 6)] & rs_lane_lt(q & 63))]); }
+					}
+					const uint32_t ea = __shfl(pr, 0), eb = __shfl(pr, 1), ec = __shfl(pr, 2);
+					if(lane == 0) {
+						const int c = rs_median3(ea, eb, ec);
+						shP[2] = c == 0 ? ea : (c == 1 ? eb : ec);
+						shI[7] = c == 0 ? lo + 1 : (c == 1 ? mid : cutAbs - 1);
+					}
+				}
+				__syncthreads();
+				const uint32_t nPiv = fuse ? shP[2] : 0u; const int nW = fuse ? shI[7] : -1, nOff = tabNext;
+				/* ---- pass B2: the left part [lo, cut) of the next level — after the next pivot's swap when that is known */
+				if(tid == 0) dst[lo] = HuPair<PT>::pack(fuse ? nPiv : pivP);
 				auto passB2 = [&](auto l0) {
 					constexpr bool L0 = decltype(l0)::value;
 					for(int base = 0; base < cutq; base += HU_RS_TRIP) {
-						uint32_t kv[HU_RS_U], iv[HU_RS_U]; int rr[HU_RS_U];
+						uint32_t kv[HU_RS_U]; int rr[HU_RS_U];
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {
-							const int p = lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1);
-							kv[u] = rs_pair<L0>(src, row, db.root, p, pA, vA, pB, vB, nan);
-							iv[u] = rs_node<L0>(src, db.root, p, pA, vA, pB, vB);
-						}
+						for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
 #pragma unroll
 						for(int u = 0; u < HU_RS_U; ++u) {       /* a left stopper takes the right stopper of its rank */
 							const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
@@ -345,45 +390,57 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 						}
 #pragma unroll
 						for(int u = 0; u < HU_RS_U; ++u) {       /* the others read RS[0] (one address) and keep their own: no branch around the loads */
-							const int ri = max(rr[u], 0);
-							const uint32_t rk = HuPair<PT>::canon(RS.keys[ri]), rid = RS.ids[ri];
-							kv[u] = rr[u] >= 0 ? rk : kv[u]; iv[u] = rr[u] >= 0 ? rid : iv[u];
+							const uint32_t rk = HuPair<PT>::canon(RS[max(rr[u], 0)]);
+							kv[u] = rr[u] >= 0 ? rk : kv[u];
 						}
 #pragma unroll
 						for(int u = 0; u < HU_RS_U; ++u) {
-							const int q = base + u * HU_RS_THREADS + tid;
-							if(q < cutq) { dst.keys[lo + 1 + q] = HuPair<PT>::pack(kv[u]); dst.ids[lo + 1 + q] = iv[u]; }
+							const int qb = base + u * HU_RS_THREADS, q = qb + tid;
+							if(lo + 1 + q == nW) kv[u] = pivP;         /* the next pivot's swap: the element of lo — this level's pivot — goes where it stood */
+							if(q < cutq) dst[lo + 1 + q] = HuPair<PT>::pack(kv[u]);
+							if(fuse) {
+								const bool valid = q < cutq;
+								const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], nPiv)), mR = __ballot(valid && !rs_ltp(nPiv, kv[u]));
+								if(lane == 0 && qb + wave * 64 < cutq) {
+									const int t = (qb >> 6) + wave;
+									cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
+									gML[nOff + t] = mL; gMR[nOff + t] = mR;
+								}
+							}
 						}
 					}
 				};
 				if(level0) passB2(std::true_type{}); else passB2(std::false_type{});
 				hi = cutAbs;
+				if(fuse) { counted = true; pivP = nPiv; wAbs = nW; off = nOff; tabNext = nOff + nR; }
 			}
 			else {
-				/* the tiny left part goes to the finisher's array as it is after this partition; its left stoppers are kept for the right part */
+				/* the tiny left part goes to the finisher's array as it is after this partition (positions of the array of level + 1); its left
+				 * stoppers are kept for the right part */
 				if(tid < 64) {
 					const int q = tid; const bool valid = q < cutq;
-					const uint64_t e = valid ? E(lo + 1 + q) : 0;
-					const bool ls = valid && !rs_lt(e, pivE);
+					const uint32_t e = valid ? E(lo + 1 + q) : 0;
+					const bool ls = valid && !rs_ltp(e, pivP);
 					const unsigned long long mL = __ballot(ls);
 					const int k = __popcll(mL & rs_lane_lt(lane));
 					if(ls) lsb[k] = e;
-					if(valid) fin[lo + 1 + q] = rs_key(ls ? RS.load(k) : e);
-					if(tid == 0) { fin[lo] = rs_key(pivE); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
+					const uint32_t tag = ((uint32_t)(level + 1) << 24);
+					if(valid) fin[lo + 1 + q] = rs_key(ls ? HuPair<PT>::canon(RS[k]) : e, tag | (uint32_t)(lo + 1 + q));
+					if(tid == 0) { fin[lo] = rs_key(pivP, tag | (uint32_t) lo); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
 				}
 				__syncthreads();
-				if(nStash >= 12) { failed = true; break; }
+				if(nStash >= 12) { failed = true; why = 5; break; }
 				++nStash;
 				/* the right part [cut, hi): a right stopper of rank k <= m receives the k-th left stopper (the element that sat at i_k) */
 				for(int base = cutq / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_THREADS) {
 					const int q = base + tid, t = q >> 6;
 					const bool valid = q < M;
-					const uint64_t e = valid ? E(lo + 1 + q) : 0;
-					const bool rs = valid && !rs_lt(pivE, e);
+					const uint32_t e = valid ? E(lo + 1 + q) : 0;
+					const bool rs = valid && !rs_ltp(pivP, e);
 					const unsigned long long mR = __ballot(rs);
 					if(valid && q >= cutq) {
 						const int rk = rs ? (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)) : 0;
-						dst.store(lo + 1 + q, (rs && rk <= m) ? lsb[rk - 1] : e);
+						dst[lo + 1 + q] = HuPair<PT>::pack((rs && rk <= m) ? lsb[rk - 1] : e);
 					}
 				}
 				lo = cutAbs;
@@ -391,17 +448,18 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			__threadfence_block();
 			__syncthreads();
 			RS_T(6);
-			src = dst; dst = (dst.ids == bufA.ids) ? bufB : bufA;
+			src = dst; dst = (dst == bufA) ? bufB : bufA;
 			level0 = false;
 			pA = pB = -1;
+			++level;
 		}
 		if(__syncthreads_or((failed || nan) ? 1 : 0)) { /* the host path finishes this read */
-			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; }
+			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | ((why ? why : 3) << 26); }
 			continue;
 		}
 		/* ---- the last range into LDS beside the set-aside prefix; one thread finishes with the literal algorithm */
-		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint64_t e = E(p); if(!nan) fin[p] = rs_key(e); }
-		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; } continue; }
+		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint32_t e = E(p); if(!nan) fin[p] = rs_key(e, ((uint32_t) level << 24) | (uint32_t) p); }
+		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | (3 << 26); } continue; }
 		RS_T(7);
 		if(tid == 0) {
 			bool ok = true;
@@ -419,14 +477,59 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		}
 		__syncthreads();
 		RS_T(8);
-		if(!shI[5]) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read; } continue; }
+		if(!shI[5]) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | (6 << 26); } continue; }
 		const int keep = min(K, hi);
 		if(tid == 0) seedCnt[read] = keep;
 		if(tid < keep) {
-			const int node = (int)(fin[tid] & ((1ull << HU_RS_IDBITS) - 1));
+			/* ---- trace-back: from a position of the array of level `lv` to the position in node order.  Per level: undo the partition (a place
+			 * left of the cut that held a left stopper received the right stopper of the same rank, and the other way round right of it), then
+			 * undo the pivot's swap */
+			const uint32_t tag = (uint32_t)(fin[tid] & ((1ull << HU_RS_IDBITS) - 1));
+			int P = (int)(tag & 0xffffffu);
+			for(int l = (int)(tag >> 24) - 1; l >= 0; --l) {
+				const int llo = hLo[l], o = hOff[l], mm = hM[l];
+				if(P != llo) {
+					const int q = P - (llo + 1), t = q >> 6, bit = q & 63;
+					if(P < hCut[l]) {
+						const unsigned long long mL = gML[o + t];
+						if((mL >> bit) & 1ull) {
+							const int k = (int) gPre[o + t] + __popcll(mL & rs_lane_lt(bit)) + 1;
+							if(k <= mm) {   /* j_k: in the last subtile a with sufR[a] >= k */
+								int c = 0;
+								for(int x = 1; x < hNC[l]; ++x) c = (int) cSuf[(o >> 6) + x] >= k ? x : c;
+								const uint4* blk = reinterpret_cast<const uint4*>(gSuf + o + c * 64);
+								int n = 0;
+#pragma unroll 4
+								for(int x = 0; x < 16; ++x) { const uint4 v = blk[x]; n += ((int) v.x >= k) + ((int) v.y >= k) + ((int) v.z >= k) + ((int) v.w >= k); }
+								const int a = c * 64 + n - 1;
+								P = llo + 1 + a * 64 + rs_nth_high(gMR[o + a], k - (int) gSuf[o + a + 1]);
+							}
+						}
+					}
+					else {
+						const unsigned long long mR = gMR[o + t];
+						if((mR >> bit) & 1ull) {
+							const int k = (int) gSuf[o + t + 1] + __popcll(mR & rs_lane_ge(bit));
+							if(k <= mm) {   /* i_k: in the last subtile a with preL[a] < k */
+								int c = 0;
+								for(int x = 1; x < hNC[l]; ++x) c = cPre[(o >> 6) + x] < (uint32_t) k ? x : c;
+								const uint4* blk = reinterpret_cast<const uint4*>(gPre + o + c * 64);
+								int n = 0;
+#pragma unroll 4
+								for(int x = 0; x < 16; ++x) { const uint4 v = blk[x]; n += (v.x < (uint32_t) k) + (v.y < (uint32_t) k) + (v.z < (uint32_t) k) + (v.w < (uint32_t) k); }
+								const int a = c * 64 + n - 1;
+								P = llo + 1 + a * 64 + rs_nth_low(gML[o + a], k - (int) gPre[o + a]);
+							}
+						}
+					}
+				}
+				P = P == llo ? hW[l] : (P == hW[l] ? llo : P);
+			}
+			const int node = P < db.root ? P : P + 1;
 			seedId[(size_t) read * HU_MAX_SEEDS + tid] = node;
 			seedDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[node]);
 			parDN[(size_t) read * HU_MAX_SEEDS + tid] = HuPair<PT>::canon(row[db.parent[node]]);
 		}
+		RS_T(9);
 	}
 }
