@@ -34,13 +34,9 @@
 
 #define HU_RS_SMALL 512
 #define HU_RS_THREADS 512
-#ifndef HU_RS_U
-#define HU_RS_U 4                 /* elements per thread and loop trip of the streaming passes: their loads are in flight together */
-#endif
 #ifndef HU_RS_WAVES_PER_EU
 #define HU_RS_WAVES_PER_EU 6          /* 512 threads = 2 waves per SIMD and workgroup: three workgroups per CU need <= 85 VGPRs */
 #endif
-#define HU_RS_TRIP (HU_RS_THREADS * HU_RS_U)
 #define HU_RS_FIN (HU_RS_SMALL + 96)        /* LDS array of the sequential finisher: the set-aside prefix (< 64 places) + the last range */
 #define HU_RS_MAXLEV 64                     /* partitions of one read on the device; introsort's own limit is 2 lg n (<= 48 for n < 2^24) */
 
@@ -72,18 +68,6 @@ __device__ inline int rs_nth_high(uint64_t m, int n) { return 63 - rs_nth_low(__
  * relative), so dist(a) < dist(b) <=> d_a * N_b < d_b * N_a — exact in 32-bit integers, and no division in the streaming passes.  The
  * sequential finisher works on keys (rs_key) of the at most HU_RS_FIN elements it receives. */
 __device__ inline bool rs_ltp(uint32_t pa, uint32_t pb) { return (pa >> 16) * (pb & 0xffffu) < (pb >> 16) * (pa & 0xffffu); }
-/* The streaming passes load through rs_pair: no branch between the loads of one trip (the level is a template argument, the two
- * patches of level 0 are selects), so that the loads of a thread are in flight together — behind a divergent branch each one is waited for
- * before the next is issued.  Level 0 is the row itself in node order without the root; later levels are arrays of pairs by absolute position. */
-template<bool L0, class PT>
-__device__ inline uint32_t rs_pair(const PT* __restrict__ src, const PT* __restrict__ row, int root, int p, int pA, uint32_t vA, int pB, uint32_t vB, bool& nan) {
-	if(!L0) return HuPair<PT>::canon(src[p]);
-	uint32_t pr = HuPair<PT>::canon(row[p < root ? p : p + 1]);
-	nan |= (pr & 0xffffu) == 0;
-	pr = p == pA ? vA : pr;
-	pr = p == pB ? vB : pr;
-	return pr;
-}
 /* key of an element for the finisher: floor(d * 2^32 / N) above a 31-bit tag (the level whose array the element sits in << 24 | its position
  * there; the trace-back turns it into a node).  Exact: d <= N < 2^16, so the key has 33 bits, and two different fractions differ by at least
  * 1 / (N_a N_b) > 2^-32 — their keys differ; equal fractions have equal keys.  One 64-bit division per element of the last range. */
@@ -96,12 +80,12 @@ __device__ __attribute__((noinline)) uint64_t rs_key(uint32_t pr, uint32_t tag) 
  * of them are swapped); the tables of all levels: per 64-element subtile the scanned counts (2 x 4 bytes) and the two stopper masks (2 x 8
  * bytes), tabCap subtiles in all (a level takes its subtiles + 1 rounded up to 64; levels shrink geometrically on anything but adversarial
  * rows, and a read whose tables do not fit goes to the host path) */
-static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 63) + m0 / 2 + 64 + 63) & ~(size_t) 63; }
-static inline size_t hu_refsort_tabcap(size_t m0) { const size_t nt = ((m0 + 63) / 64 + 64) & ~(size_t) 63; return 4 * nt + 2048; }
+static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 63) + m0 / 2 + 128 + 63) & ~(size_t) 63; }
+static inline size_t hu_refsort_tabcap(size_t m0) { const size_t nt = ((m0 + 63) / 64 + 64) & ~(size_t) 63; return 8 * nt + 2048; }
 static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * hu_refsort_cap(m0) * (size_t) pairBytes + 7) / 8 + 3 * hu_refsort_tabcap(m0)) + 1) & ~(size_t) 1; }
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
 static inline size_t hu_refsort_lds(int nNodes) {
-	const size_t m0 = (size_t) nNodes - 1, NT = (m0 + 63) / 64;
+	const size_t m0 = (size_t) nNodes - 1, NT = (m0 + 63) / 64 + 1;
 	return HU_RS_FIN * 8 + 64 * 4 + 2 * (NT + 2) * 4 + 2 * (hu_refsort_tabcap(m0) / 64) * 4 + (NT + 2) * 2;
 }
 
@@ -152,15 +136,77 @@ __device__ inline int rs_median3(uint32_t a, uint32_t b, uint32_t c) {
 	return 1;
 }
 
+/* ---- the streaming passes work on GROUPS: 16 bytes of keys per lane and load (8 keys of 2 bytes, 4 of 4), so that a trip of the workgroup
+ * has 16 KB in flight instead of 2 (a pass of one key per lane was bound by its round trips: 2 GB/s per workgroup).  Subtiles are aligned to
+ * ABSOLUTE positions (p >> 6), so every level — the pair row included — is read and written in aligned vectors; positions of a subtile outside
+ * (lo, hi) simply have no mask bit.  A subtile is 64 / EPL lanes; ranks inside it come from a scan over those lanes. */
+template<class PT> struct HuRsGeom { static constexpr int EPL = 16 / (int) sizeof(PT); static constexpr int LPS = 64 / EPL; };
+#ifndef HU_RS_VU
+#define HU_RS_VU 2                /* vector loads in flight per thread */
+#endif
+struct __attribute__((packed, aligned(2))) HuRsU4h { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) HuRsU4w { uint32_t x, y, z, w; };
+
+template<bool L0, class PT>
+__device__ inline void rs_load(const PT* __restrict__ src, const PT* __restrict__ row, int root, int rowLast, int p0, uint32_t (&k)[HuRsGeom<PT>::EPL]) {
+	constexpr int EPL = HuRsGeom<PT>::EPL;
+	if(!L0) { const uint4 v = *reinterpret_cast<const uint4*>(src + p0); HuPair<PT>::unpack(v, k); return; }
+	/* level 0: the row in node order without the root — from the root on, the element of place p is row[p + 1] */
+	uint32_t o[EPL + 1];
+	const uint4 v = *reinterpret_cast<const uint4*>(row + p0);
+	HuPair<PT>::unpack(v, o);
+	o[EPL] = HuPair<PT>::canon(row[min(p0 + EPL, rowLast)]);
+#pragma unroll
+	for(int e = 0; e < EPL; ++e) k[e] = (p0 + e < root) ? o[e] : o[e + 1];
+}
+/* level 0 only: the two patches of the pivot's swap; a compared-site count of zero among the valid places is a NaN distance */
+template<int EPL>
+__device__ inline void rs_fix_l0(uint32_t (&k)[EPL], int p0, int pA, uint32_t vA, int pB, uint32_t vB, uint32_t vb, bool& nan) {
+	if((unsigned)(pA - p0) < (unsigned) EPL || (unsigned)(pB - p0) < (unsigned) EPL) {
+#pragma unroll
+		for(int e = 0; e < EPL; ++e) { k[e] = p0 + e == pA ? vA : k[e]; k[e] = p0 + e == pB ? vB : k[e]; }
+	}
+	uint32_t z = 0;
+#pragma unroll
+	for(int e = 0; e < EPL; ++e) z |= (uint32_t)((k[e] & 0xffffu) == 0) << e;
+	nan |= (z & vb) != 0;
+}
+template<int EPL>
+__device__ inline uint32_t rs_valid(int q0, int qlo, int qhi) {
+	const int a = min(max(qlo - q0, 0), EPL), b = min(max(qhi - q0, 0), EPL);
+	return ((1u << b) - 1u) & ~((1u << a) - 1u);
+}
+/* stopper bits of a group against a pivot: left stopper = !(k < piv), right stopper = !(piv < k), both through the cross products */
+template<int EPL>
+__device__ inline void rs_classify(const uint32_t (&k)[EPL], uint32_t piv, uint32_t vb, uint32_t& mLb, uint32_t& mRb) {
+	const uint32_t dp = piv >> 16, Np = piv & 0xffffu;
+	uint32_t l = 0, r = 0;
+#pragma unroll
+	for(int e = 0; e < EPL; ++e) { const uint32_t a = (k[e] >> 16) * Np, b = dp * (k[e] & 0xffffu); l |= (uint32_t)(a >= b) << e; r |= (uint32_t)(b >= a) << e; }
+	mLb = l & vb; mRb = r & vb;
+}
+/* a group's bits into the level's mask arrays (as bytes: the arrays are bit arrays over the positions) and its subtile's counts */
+template<int EPL>
+__device__ inline void rs_emit(uint32_t mLb, uint32_t mRb, int g, bool store, int lane, unsigned char* bL, unsigned char* bR, uint16_t* cnt16) {
+	constexpr int LPS = 64 / EPL;
+	if(EPL == 8) { if(store) { bL[g] = (unsigned char) mLb; bR[g] = (unsigned char) mRb; } }
+	else { const uint32_t o = __shfl_down(mLb | (mRb << 4), 1); if(store && !(lane & 1)) { bL[g >> 1] = (unsigned char)(mLb | ((o & 15u) << 4)); bR[g >> 1] = (unsigned char)(mRb | ((o >> 4) << 4)); } }
+	uint32_t c = __popc(mLb) | (__popc(mRb) << 16);
+#pragma unroll
+	for(int o = 1; o < LPS; o <<= 1) c += __shfl_xor(c, o);
+	if(store && (lane & (LPS - 1)) == 0) cnt16[g / LPS] = (uint16_t)((c & 0xffu) | ((c >> 16) << 8));
+}
+
 template<class PT>
 __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K,
 		unsigned long long* __restrict__ scratch, size_t wgWords, size_t cap, int rsOff, int tabCap,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
 		int32_t* __restrict__ bail) {
+	constexpr int EPL = HuRsGeom<PT>::EPL, LPS = HuRsGeom<PT>::LPS, VU = HU_RS_VU;
 	extern __shared__ unsigned char rs_smem[];
 	const int m0 = db.nNodes - 1;
-	const int NT = (m0 + 63) >> 6;
+	const int NT = ((m0 + 63) >> 6) + 1;
 	const int NC = tabCap >> 6;
 	uint64_t* fin = reinterpret_cast<uint64_t*>(rs_smem);                  /* [HU_RS_FIN]: the sequential finisher's array, by absolute position */
 	uint32_t* lsb = reinterpret_cast<uint32_t*>(fin + HU_RS_FIN);          /* [64]: left stoppers of a tiny left part */
@@ -174,8 +220,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	__shared__ int shI[12];                  /* broadcast slots */
 	__shared__ HuRsRange stash[12];
 	__shared__ int seqStack[72];
-	__shared__ int hLo[HU_RS_MAXLEV], hW[HU_RS_MAXLEV], hCut[HU_RS_MAXLEV], hM[HU_RS_MAXLEV], hOff[HU_RS_MAXLEV], hNC[HU_RS_MAXLEV];
+	__shared__ int hLo[HU_RS_MAXLEV], hQB[HU_RS_MAXLEV], hW[HU_RS_MAXLEV], hCut[HU_RS_MAXLEV], hM[HU_RS_MAXLEV], hOff[HU_RS_MAXLEV], hNC[HU_RS_MAXLEV];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int rowLast = db.nNodesPad - 1;
 	/* this workgroup's scratch */
 	PT* bufA; PT* bufB; uint32_t* gPre; uint32_t* gSuf; unsigned long long* gML; unsigned long long* gMR;
 	{
@@ -207,15 +254,20 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		bool failed = false, nan = false; int why = 0;        /* why a read is left to the host (bits 26.. of its entry in the list) */
 		bool counted = false;                            /* this level's pivot, swap, masks and counts were made by the pass that wrote it */
 		uint32_t pivP = 0; int wAbs = -1, off = 0;
-		auto E = [&](int p) -> uint32_t {                /* any element, off the streaming passes */
+		auto E = [&](int p) -> uint32_t {                /* any one element, off the streaming passes */
 			if(!level0) return HuPair<PT>::canon(src[p]);
-			return rs_pair<true, PT>(src, row, db.root, p, pA, vA, pB, vB, nan);
+			uint32_t pr = HuPair<PT>::canon(row[p < db.root ? p : p + 1]);
+			nan |= (pr & 0xffffu) == 0;
+			pr = p == pA ? vA : pr;
+			return p == pB ? vB : pr;
 		};
 		while(hi - lo > HU_RS_SMALL) {
 			if(depth == 0 || level >= HU_RS_MAXLEV) { failed = true; why = 1; break; }
 			--depth;
-			const int M = hi - lo - 1, NTl = (M + 63) >> 6;
+			/* valid places lo + 1 .. hi - 1; q = p - qBase on the grid of absolute subtiles, valid for o0 <= q < qEnd */
+			const int M = hi - lo - 1, qBase = (lo + 1) & ~63, o0 = (lo + 1) & 63, qEnd = o0 + M, NTl = (qEnd + 63) >> 6;
 			const int R = (NTl + 1 + 63) & ~63;             /* table entries of this level: 0 .. NTl, padded */
+			const int gEnd = NTl * LPS;
 			if(!counted) {
 				off = tabNext;
 				if(off + R > tabCap) { failed = true; why = 2; break; }
@@ -235,23 +287,22 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				RS_T(1);
 				pivP = shP[0]; wAbs = shI[0];
 				if(level0) { pA = lo; vA = pivP; pB = wAbs; vB = shP[1]; }
-				/* ---- pass A: stopper masks per subtile of 64 positions q = p - (lo + 1) */
+				/* ---- pass A: stopper masks and counts per subtile */
 				auto passA = [&](auto l0) {
 					constexpr bool L0 = decltype(l0)::value;
-					for(int base = 0; base < M; base += HU_RS_TRIP) {
-						uint32_t kv[HU_RS_U];
+					unsigned char* bL = reinterpret_cast<unsigned char*>(gML + off); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + off);
+					for(int gb = 0; gb < gEnd; gb += HU_RS_THREADS * VU) {
+						uint32_t k[VU][EPL];
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+						for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd - 1) * EPL, k[u]);
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {
-							const int qb = base + u * HU_RS_THREADS, q = qb + tid;
-							const bool valid = q < M;
-							const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], pivP)), mR = __ballot(valid && !rs_ltp(pivP, kv[u]));
-							if(lane == 0 && qb + wave * 64 < M) {
-								const int t = (qb >> 6) + wave;
-								cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
-								gML[off + t] = mL; gMR[off + t] = mR;
-							}
+						for(int u = 0; u < VU; ++u) {
+							const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
+							const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
+							if(L0) rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, vb, nan);
+							uint32_t mLb, mRb;
+							rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+							rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
 						}
 					}
 				};
@@ -298,10 +349,11 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				unsigned long long mL = gML[off + t0], mR = gMR[off + t0];
 				int c0;
 				{
+					const int q = t0 * 64 + lane;
 					const int Lq = (int) preL[t0] + __popcll(mL & rs_lane_lt(lane));
 					const int Rq = (int) sufR[t0 + 1] + __popcll(mR & rs_lane_ge(lane) & ~(1ull << lane));
-					const unsigned long long ok = __ballot(t0 * 64 + lane < M && Lq - Rq >= 0);
-					c0 = ok ? t0 * 64 + (__ffsll((long long) ok) - 1) : (t0 + 1) * 64;
+					const unsigned long long ok = __ballot(q >= o0 && q < qEnd && Lq - Rq >= 0);
+					c0 = ok ? t0 * 64 + (__ffsll((long long) ok) - 1) : min((t0 + 1) * 64, qEnd);
 				}
 				int tc = c0 >> 6, m, iNext = -1;                     /* iNext: i_(m+1), the first left stopper at or after c0 (-1: none) */
 				if(tc < NTl) {
@@ -325,23 +377,31 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			__syncthreads();
 			RS_T(4);
 			const int cutq = shI[2], m = shI[3], jm = shI[4];
-			if(cutq < 0) { failed = true; why = 4; break; }                  /* no stopper where the sentinels guarantee one: not reached on consistent data */
-			const int cutAbs = lo + 1 + cutq;
+			if(cutq < 0) { failed = true; why = 4; break; }         /* no stopper where the sentinels guarantee one: not reached on consistent data */
+			const int cutAbs = qBase + cutq;
 			PT* RS = dst + rsOff;                                   /* right stoppers by rank, beyond the positions */
-			if(tid == 0) { hLo[level] = lo; hW[level] = wAbs; hCut[level] = cutAbs; hM[level] = m; hOff[level] = off; hNC[level] = R >> 6; }
+			if(tid == 0) { hLo[level] = lo; hQB[level] = qBase; hW[level] = wAbs; hCut[level] = cutAbs; hM[level] = m; hOff[level] = off; hNC[level] = R >> 6; }
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
-				for(int base = (jm >> 6) * 64 / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_TRIP) {
-					uint32_t kv[HU_RS_U];
+				for(int gb = (jm >> 6) * LPS; gb < gEnd; gb += HU_RS_THREADS * VU) {
+					uint32_t k[VU][EPL];
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+					for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd - 1) * EPL, k[u]);
 #pragma unroll
-					for(int u = 0; u < HU_RS_U; ++u) {
-						const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-						const bool rs = q < M && !rs_ltp(pivP, kv[u]);
-						const unsigned long long mR = __ballot(rs);
-						if(rs) { const int rk = (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)); if(rk <= m) RS[rk - 1] = HuPair<PT>::pack(kv[u]); }
+					for(int u = 0; u < VU; ++u) {
+						const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
+						const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
+						if(L0) { bool dummy = false; rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, 0u, dummy); }
+						uint32_t mLb, mRb;
+						rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+						const int c = __popc(mRb);
+						int s = c;                                     /* right stoppers of this lane and the higher lanes of its subtile */
+#pragma unroll
+						for(int o = 1; o < LPS; o <<= 1) { const int v = __shfl_down(s, o); if((lane & (LPS - 1)) + o < LPS) s += v; }
+						const int above = (int) sufR[min(g / LPS, NTl - 1) + 1] + s - c;
+#pragma unroll
+						for(int e = 0; e < EPL; ++e) if((mRb >> e) & 1u) { const int rk = above + __popc(mRb >> e); if(rk <= m) RS[rk - 1] = HuPair<PT>::pack(k[u][e]); }
 					}
 				}
 			};
@@ -354,7 +414,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				/* ---- the next level is [lo, cut).  While it is still a streaming level its pivot is chosen NOW — the median of the elements that
 				 * WILL stand at lo + 1, mid and cut - 1: each is the element there, or the right stopper of its rank if that one is a left stopper —
 				 * and pass B2 classifies what it writes against it */
-				const int nM = cutq, nNTl = (nM + 63) >> 6, nR = (nNTl + 1 + 63) & ~63;
+				const int nNTl = (cutq + 63) >> 6, nR = (nNTl + 1 + 63) & ~63, gEnd2 = nNTl * LPS;
 				const bool fuse = cutAbs - lo > HU_RS_SMALL && depth > 0 && level + 1 < HU_RS_MAXLEV && tabNext + nR <= tabCap;
 				if(fuse && wave == 0) {
 					const int mid = lo + (cutAbs - lo) / 2;
@@ -362,7 +422,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					uint32_t pr = 0;
 					if(lane < 3) {
 						pr = E(P);
-						if(!rs_ltp(pr, pivP)) { const int q = P - (lo + 1); pr = HuPair<PT>::canon(RS[(int) preL[q >> 6] + __popcll(gML[off + (q >> 6)] & rs_lane_lt(q & 63))]); }
+						if(!rs_ltp(pr, pivP)) { const int q = P - qBase; pr = HuPair<PT>::canon(RS[(int) preL[q >> 6] + __popcll(gML[off + (q >> 6)] & rs_lane_lt(q & 63))]); }
 					}
 					const uint32_t ea = __shfl(pr, 0), eb = __shfl(pr, 1), ec = __shfl(pr, 2);
 					if(lane == 0) {
@@ -373,39 +433,61 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				}
 				__syncthreads();
 				const uint32_t nPiv = fuse ? shP[2] : 0u; const int nW = fuse ? shI[7] : -1, nOff = tabNext;
+				const uint32_t loVal = fuse ? nPiv : pivP;      /* what stands at lo in the array written: this level's pivot, or the next one after its swap */
 				/* ---- pass B2: the left part [lo, cut) of the next level — after the next pivot's swap when that is known */
-				if(tid == 0) dst[lo] = HuPair<PT>::pack(fuse ? nPiv : pivP);
+				if(tid == 0) dst[lo] = HuPair<PT>::pack(loVal);
 				auto passB2 = [&](auto l0) {
 					constexpr bool L0 = decltype(l0)::value;
-					for(int base = 0; base < cutq; base += HU_RS_TRIP) {
-						uint32_t kv[HU_RS_U]; int rr[HU_RS_U];
+					unsigned char* bL = reinterpret_cast<unsigned char*>(gML + nOff); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + nOff);
+					for(int gb = 0; gb < gEnd2; gb += HU_RS_THREADS * VU) {
+						uint32_t k[VU][EPL];
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) kv[u] = rs_pair<L0, PT>(src, row, db.root, lo + 1 + min(base + u * HU_RS_THREADS + tid, M - 1), pA, vA, pB, vB, nan);
+						for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd2 - 1) * EPL, k[u]);
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {       /* a left stopper takes the right stopper of its rank */
-							const int q = base + u * HU_RS_THREADS + tid, t = q >> 6;
-							const bool ls = q < cutq && !rs_ltp(kv[u], pivP);
-							const unsigned long long mL = __ballot(ls);
-							rr[u] = ls ? (int) preL[min(t, NTl)] + __popcll(mL & rs_lane_lt(lane)) : -1;
-						}
+						for(int u = 0; u < VU; ++u) {
+							const int g = gb + u * HU_RS_THREADS + tid, p0 = qBase + g * EPL; const bool in = g < gEnd2;
+							const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, cutq) : 0u;
+							if(L0) { bool dummy = false; rs_fix_l0<EPL>(k[u], p0, pA, vA, pB, vB, 0u, dummy); }
+							uint32_t mLb, mRb;
+							rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+							/* the left stoppers of a group have consecutive ranks: one (unaligned) vector of right stoppers, dealt out in order */
+							const int c = __popc(mLb);
+							int s = c;
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {       /* the others read RS[0] (one address) and keep their own: no branch around the loads */
-							const uint32_t rk = HuPair<PT>::canon(RS[max(rr[u], 0)]);
-							kv[u] = rr[u] >= 0 ? rk : kv[u];
-						}
+							for(int o = 1; o < LPS; o <<= 1) { const int v = __shfl_up(s, o); if((lane & (LPS - 1)) >= o) s += v; }
+							const int r0 = min((int) preL[min(g / LPS, NTl)] + s - c, max(m - 1, 0));
+							uint32_t rx, ry, rz, rw;
+							if(sizeof(PT) == 2) { const HuRsU4h v = *reinterpret_cast<const HuRsU4h*>(RS + r0); rx = v.x; ry = v.y; rz = v.z; rw = v.w; }
+							else { const HuRsU4w v = *reinterpret_cast<const HuRsU4w*>(RS + r0); rx = v.x; ry = v.y; rz = v.z; rw = v.w; }
 #pragma unroll
-						for(int u = 0; u < HU_RS_U; ++u) {
-							const int qb = base + u * HU_RS_THREADS, q = qb + tid;
-							if(lo + 1 + q == nW) kv[u] = pivP;         /* the next pivot's swap: the element of lo — this level's pivot — goes where it stood */
-							if(q < cutq) dst[lo + 1 + q] = HuPair<PT>::pack(kv[u]);
-							if(fuse) {
-								const bool valid = q < cutq;
-								const unsigned long long mL = __ballot(valid && !rs_ltp(kv[u], nPiv)), mR = __ballot(valid && !rs_ltp(nPiv, kv[u]));
-								if(lane == 0 && qb + wave * 64 < cutq) {
-									const int t = (qb >> 6) + wave;
-									cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
-									gML[nOff + t] = mL; gMR[nOff + t] = mR;
+							for(int e = 0; e < EPL; ++e) {
+								const bool bit = (mLb >> e) & 1u;
+								if(sizeof(PT) == 2) {
+									k[u][e] = bit ? HuPair<PT>::canon(rx & 0xffffu) : k[u][e];
+									const uint32_t sx = (rx >> 16) | (ry << 16), sy = (ry >> 16) | (rz << 16), sz = (rz >> 16) | (rw << 16), sw = rw >> 16;
+									rx = bit ? sx : rx; ry = bit ? sy : ry; rz = bit ? sz : rz; rw = bit ? sw : rw;
 								}
+								else {
+									k[u][e] = bit ? rx : k[u][e];
+									rx = bit ? ry : rx; ry = bit ? rz : ry; rz = bit ? rw : rz;
+								}
+							}
+							if((unsigned)(lo - p0) < (unsigned) EPL || (unsigned)(nW - p0) < (unsigned) EPL) {
+#pragma unroll
+								for(int e = 0; e < EPL; ++e) { k[u][e] = p0 + e == lo ? loVal : k[u][e]; k[u][e] = p0 + e == nW ? pivP : k[u][e]; }   /* the next pivot's swap: this level's pivot goes where that one stood */
+							}
+							if(in) {
+								uint4 v;
+								if(sizeof(PT) == 2) {
+									v.x = HuPair<PT>::pack(k[u][0]) | ((uint32_t) HuPair<PT>::pack(k[u][1]) << 16); v.y = HuPair<PT>::pack(k[u][2]) | ((uint32_t) HuPair<PT>::pack(k[u][3]) << 16);
+									v.z = HuPair<PT>::pack(k[u][4 % EPL]) | ((uint32_t) HuPair<PT>::pack(k[u][5 % EPL]) << 16); v.w = HuPair<PT>::pack(k[u][6 % EPL]) | ((uint32_t) HuPair<PT>::pack(k[u][7 % EPL]) << 16);
+								}
+								else { v.x = k[u][0]; v.y = k[u][1]; v.z = k[u][2]; v.w = k[u][3]; }
+								*reinterpret_cast<uint4*>(dst + p0) = v;
+							}
+							if(fuse) {
+								rs_classify<EPL>(k[u], nPiv, vb, mLb, mRb);
+								rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
 							}
 						}
 					}
@@ -418,29 +500,29 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				/* the tiny left part goes to the finisher's array as it is after this partition (positions of the array of level + 1); its left
 				 * stoppers are kept for the right part */
 				if(tid < 64) {
-					const int q = tid; const bool valid = q < cutq;
-					const uint32_t e = valid ? E(lo + 1 + q) : 0;
+					const int i = tid; const bool valid = lo + 1 + i < cutAbs;
+					const uint32_t e = valid ? E(lo + 1 + i) : 0;
 					const bool ls = valid && !rs_ltp(e, pivP);
 					const unsigned long long mL = __ballot(ls);
 					const int k = __popcll(mL & rs_lane_lt(lane));
 					if(ls) lsb[k] = e;
 					const uint32_t tag = ((uint32_t)(level + 1) << 24);
-					if(valid) fin[lo + 1 + q] = rs_key(ls ? HuPair<PT>::canon(RS[k]) : e, tag | (uint32_t)(lo + 1 + q));
+					if(valid) fin[lo + 1 + i] = rs_key(ls ? HuPair<PT>::canon(RS[k]) : e, tag | (uint32_t)(lo + 1 + i));
 					if(tid == 0) { fin[lo] = rs_key(pivP, tag | (uint32_t) lo); if(nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; } }
 				}
 				__syncthreads();
 				if(nStash >= 12) { failed = true; why = 5; break; }
 				++nStash;
 				/* the right part [cut, hi): a right stopper of rank k <= m receives the k-th left stopper (the element that sat at i_k) */
-				for(int base = cutq / HU_RS_THREADS * HU_RS_THREADS; base < M; base += HU_RS_THREADS) {
+				for(int base = cutq / HU_RS_THREADS * HU_RS_THREADS; base < qEnd; base += HU_RS_THREADS) {
 					const int q = base + tid, t = q >> 6;
-					const bool valid = q < M;
-					const uint32_t e = valid ? E(lo + 1 + q) : 0;
+					const bool valid = q >= o0 && q < qEnd;
+					const uint32_t e = valid ? E(qBase + q) : 0;
 					const bool rs = valid && !rs_ltp(pivP, e);
 					const unsigned long long mR = __ballot(rs);
 					if(valid && q >= cutq) {
 						const int rk = rs ? (int) sufR[t + 1] + __popcll(mR & rs_lane_ge(lane)) : 0;
-						dst[lo + 1 + q] = HuPair<PT>::pack((rs && rk <= m) ? lsb[rk - 1] : e);
+						dst[qBase + q] = HuPair<PT>::pack((rs && rk <= m) ? lsb[rk - 1] : e);
 					}
 				}
 				lo = cutAbs;
@@ -487,9 +569,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			const uint32_t tag = (uint32_t)(fin[tid] & ((1ull << HU_RS_IDBITS) - 1));
 			int P = (int)(tag & 0xffffffu);
 			for(int l = (int)(tag >> 24) - 1; l >= 0; --l) {
-				const int llo = hLo[l], o = hOff[l], mm = hM[l];
+				const int llo = hLo[l], qb = hQB[l], o = hOff[l], mm = hM[l];
 				if(P != llo) {
-					const int q = P - (llo + 1), t = q >> 6, bit = q & 63;
+					const int q = P - qb, t = q >> 6, bit = q & 63;
 					if(P < hCut[l]) {
 						const unsigned long long mL = gML[o + t];
 						if((mL >> bit) & 1ull) {
@@ -502,7 +584,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 #pragma unroll 4
 								for(int x = 0; x < 16; ++x) { const uint4 v = blk[x]; n += ((int) v.x >= k) + ((int) v.y >= k) + ((int) v.z >= k) + ((int) v.w >= k); }
 								const int a = c * 64 + n - 1;
-								P = llo + 1 + a * 64 + rs_nth_high(gMR[o + a], k - (int) gSuf[o + a + 1]);
+								P = qb + a * 64 + rs_nth_high(gMR[o + a], k - (int) gSuf[o + a + 1]);
 							}
 						}
 					}
@@ -518,7 +600,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 #pragma unroll 4
 								for(int x = 0; x < 16; ++x) { const uint4 v = blk[x]; n += (v.x < (uint32_t) k) + (v.y < (uint32_t) k) + (v.z < (uint32_t) k) + (v.w < (uint32_t) k); }
 								const int a = c * 64 + n - 1;
-								P = llo + 1 + a * 64 + rs_nth_low(gML[o + a], k - (int) gPre[o + a]);
+								P = qb + a * 64 + rs_nth_low(gML[o + a], k - (int) gPre[o + a]);
 							}
 						}
 					}
