@@ -32,7 +32,7 @@
 #include "hu_common.h"
 #include "hu_kern_sep.h"
 
-#define HU_RS_SMALL 512
+#define HU_RS_SMALL 128
 #define HU_RS_THREADS 512
 #ifndef HU_RS_WAVES_PER_EU
 #define HU_RS_WAVES_PER_EU 6          /* 512 threads = 2 waves per SIMD and workgroup: three workgroups per CU need <= 85 VGPRs */
@@ -84,9 +84,13 @@ static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 
 static inline size_t hu_refsort_tabcap(size_t m0) { const size_t nt = ((m0 + 63) / 64 + 64) & ~(size_t) 63; return 8 * nt + 2048; }
 static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * hu_refsort_cap(m0) * (size_t) pairBytes + 7) / 8 + 3 * hu_refsort_tabcap(m0)) + 1) & ~(size_t) 1; }
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
+/* the region that holds the scanned counts of a streaming level (10 bytes per subtile) — or, once a range fits, the range itself and its tables */
+#define HU_RS_LTAB 260                 /* subtiles of a range held in LDS, + 1 */
+#define HU_RS_LHEAD (HU_RS_LTAB * (4 + 4 + 8 + 8 + 2) + 24)     /* = 6784: scanned counts, masks, counts of such a range; the keys follow */
+__host__ __device__ static inline size_t hu_refsort_big(size_t m0) { const size_t NT = (m0 + 63) / 64 + 1, b = (10 * (NT + 2) + 15) & ~(size_t) 15; return b > 36864 ? b : 36864; }
 static inline size_t hu_refsort_lds(int nNodes) {
-	const size_t m0 = (size_t) nNodes - 1, NT = (m0 + 63) / 64 + 1;
-	return HU_RS_FIN * 8 + 64 * 4 + 2 * (NT + 2) * 4 + 2 * (hu_refsort_tabcap(m0) / 64) * 4 + (NT + 2) * 2;
+	const size_t m0 = (size_t) nNodes - 1;
+	return HU_RS_FIN * 8 + 64 * 4 + 2 * (hu_refsort_tabcap(m0) / 64) * 4 + hu_refsort_big(m0);
 }
 
 /* the literal sequential algorithm on an LDS array, for one thread: introsort loop restricted to ranges that start before place K */
@@ -210,11 +214,19 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	const int NC = tabCap >> 6;
 	uint64_t* fin = reinterpret_cast<uint64_t*>(rs_smem);                  /* [HU_RS_FIN]: the sequential finisher's array, by absolute position */
 	uint32_t* lsb = reinterpret_cast<uint32_t*>(fin + HU_RS_FIN);          /* [64]: left stoppers of a tiny left part */
-	uint32_t* preL = lsb + 64;                                             /* [NT + 2] */
-	uint32_t* sufR = preL + (NT + 2);                                      /* [NT + 2] */
-	uint32_t* cPre = sufR + (NT + 2);                                      /* [NC]: every 64th entry of every level's scanned counts (trace-back) */
+	uint32_t* cPre = lsb + 64;                                             /* [NC]: every 64th entry of every level's scanned counts (trace-back) */
 	uint32_t* cSuf = cPre + NC;                                            /* [NC] */
-	uint16_t* cnt16 = reinterpret_cast<uint16_t*>(cSuf + NC);              /* [NT + 2]: stoppers per subtile, left | right << 8, before the scan */
+	unsigned char* big = reinterpret_cast<unsigned char*>(cSuf + NC);      /* hu_refsort_big bytes, 16-byte aligned */
+	/* streaming levels: */
+	uint32_t* const preLg = reinterpret_cast<uint32_t*>(big);              /* [NT + 2] */
+	uint32_t* const sufRg = preLg + (NT + 2);                              /* [NT + 2] */
+	uint16_t* const cnt16g = reinterpret_cast<uint16_t*>(sufRg + (NT + 2));/* [NT + 2]: stoppers per subtile, left | right << 8, before the scan */
+	/* a range that fits (at most LCAP places): its tables, its masks and the range itself, partitioned in place */
+	uint32_t* const preLs = reinterpret_cast<uint32_t*>(big); uint32_t* const sufRs = preLs + HU_RS_LTAB;
+	unsigned long long* const mLs = reinterpret_cast<unsigned long long*>(sufRs + HU_RS_LTAB); unsigned long long* const mRs = mLs + HU_RS_LTAB;
+	uint16_t* const cnt16s = reinterpret_cast<uint16_t*>(mRs + HU_RS_LTAB);
+	PT* const lk = reinterpret_cast<PT*>(big + HU_RS_LHEAD);               /* place p at lk[p - lbase + 64] */
+	const int LCAP = min(16384 - 192, ((((int) hu_refsort_big((size_t) m0) - HU_RS_LHEAD) / (int) sizeof(PT)) - 128) & ~63);
 	__shared__ unsigned long long wtot[HU_RS_THREADS / 64];
 	__shared__ uint32_t shP[4];              /* pivot pair, the pair it displaced, next pivot pair */
 	__shared__ int shI[12];                  /* broadcast slots */
@@ -254,14 +266,26 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		bool failed = false, nan = false; int why = 0;        /* why a read is left to the host (bits 26.. of its entry in the list) */
 		bool counted = false;                            /* this level's pivot, swap, masks and counts were made by the pass that wrote it */
 		uint32_t pivP = 0; int wAbs = -1, off = 0;
+		bool inLds = false; int lbase = 0;               /* the range lives in LDS from now on */
+		uint32_t* preL = preLg; uint32_t* sufR = sufRg; uint16_t* cnt16 = cnt16g;
 		auto E = [&](int p) -> uint32_t {                /* any one element, off the streaming passes */
+			if(inLds) return HuPair<PT>::canon(lk[p - lbase + 64]);
 			if(!level0) return HuPair<PT>::canon(src[p]);
 			uint32_t pr = HuPair<PT>::canon(row[p < db.root ? p : p + 1]);
 			nan |= (pr & 0xffffu) == 0;
 			pr = p == pA ? vA : pr;
 			return p == pB ? vB : pr;
 		};
-		while(hi - lo > HU_RS_SMALL) {
+		for(;;) {
+			if(!inLds && hi - lo <= LCAP) {
+				/* ---- the range fits: into LDS, where the remaining partitions run in place without a round trip to memory */
+				lbase = (lo + 1) & ~63;
+				for(int p = lo + tid; p < hi; p += HU_RS_THREADS) lk[p - lbase + 64] = HuPair<PT>::pack(E(p));
+				if(__syncthreads_or(nan ? 1 : 0)) { failed = true; why = 3; break; }
+				inLds = true; level0 = false; pA = pB = -1;
+				preL = preLs; sufR = sufRs; cnt16 = cnt16s;
+			}
+			if(inLds && hi - lo <= HU_RS_SMALL) break;
 			if(depth == 0 || level >= HU_RS_MAXLEV) { failed = true; why = 1; break; }
 			--depth;
 			/* valid places lo + 1 .. hi - 1; q = p - qBase on the grid of absolute subtiles, valid for o0 <= q < qEnd */
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const int w = c == 0 ? lo + 1 : (c == 1 ? mid : hi - 1);
 					const uint32_t ew = c == 0 ? ea : (c == 1 ? eb : ec);
 					shP[0] = ew; shP[1] = ef; shI[0] = w;
-					if(!level0) { PT* s = const_cast<PT*>(src); s[lo] = HuPair<PT>::pack(ew); s[w] = HuPair<PT>::pack(ef); }
+					if(inLds) { lk[lo - lbase + 64] = HuPair<PT>::pack(ew); lk[w - lbase + 64] = HuPair<PT>::pack(ef); }
+					else if(!level0) { PT* s = const_cast<PT*>(src); s[lo] = HuPair<PT>::pack(ew); s[w] = HuPair<PT>::pack(ef); }
 				}
 				__threadfence_block();
 				__syncthreads();
@@ -306,7 +331,15 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 						}
 					}
 				};
-				if(level0) passA(std::true_type{}); else passA(std::false_type{});
+				if(inLds) {
+					for(int qb = wave * 64; qb < NTl * 64; qb += HU_RS_THREADS) {
+						const int q = qb + lane, t = qb >> 6; const bool valid = q >= o0 && q < qEnd;
+						const uint32_t e = valid ? HuPair<PT>::canon(lk[qBase + q - lbase + 64]) : 0u;
+						const unsigned long long mL = __ballot(valid && !rs_ltp(e, pivP)), mR = __ballot(valid && !rs_ltp(pivP, e));
+						if(lane == 0) { cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8)); mLs[t] = mL; mRs[t] = mR; gML[off + t] = mL; gMR[off + t] = mR; }
+					}
+				}
+				else if(level0) passA(std::true_type{}); else passA(std::false_type{});
 				if(__syncthreads_or(nan ? 1 : 0)) { failed = true; why = 3; break; }
 				RS_T(2);
 			}
@@ -342,11 +375,13 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			RS_T(3);
 			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
 			 * the swapped pairs are the left stoppers with g < 0; c0 = the first position with g >= 0 */
+			auto ML = [&](int t) -> unsigned long long { return inLds ? mLs[t] : gML[off + t]; };
+			auto MR = [&](int t) -> unsigned long long { return inLds ? mRs[t] : gMR[off + t]; };
 			if(wave == 0) {
 				/* first subtile t0 with preL[t0 + 1] >= sufR[t0 + 1] (positions of earlier subtiles all have g < 0) */
 				int t0;
 				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
-				unsigned long long mL = gML[off + t0], mR = gMR[off + t0];
+				unsigned long long mL = ML(t0), mR = MR(t0);
 				int c0;
 				{
 					const int q = t0 * 64 + lane;
@@ -357,11 +392,11 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				}
 				int tc = c0 >> 6, m, iNext = -1;                     /* iNext: i_(m+1), the first left stopper at or after c0 (-1: none) */
 				if(tc < NTl) {
-					if(tc != t0) mL = gML[off + tc];
+					if(tc != t0) mL = ML(tc);
 					m = (int) preL[tc] + __popcll(mL & rs_lane_lt(c0 & 63));
 					unsigned long long cand = mL & rs_lane_ge(c0 & 63);
 					int t = tc;
-					while(!cand && ++t < NTl) { if(preL[t + 1] > preL[t]) cand = gML[off + t]; }
+					while(!cand && ++t < NTl) { if(preL[t + 1] > preL[t]) cand = ML(t); }
 					if(cand) iNext = t * 64 + (__ffsll((long long) cand) - 1);
 				}
 				else m = (int) preL[NTl];
@@ -369,7 +404,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				if(m >= 1) {
 					int a = 0, b = NTl - 1;                           /* last subtile t with sufR[t] >= m */
 					while(a < b) { const int md = (a + b + 1) >> 1; if((int) sufR[md] >= m) a = md; else b = md - 1; }
-					jm = a * 64 + rs_nth_high(gMR[off + a], m - (int) sufR[a + 1]);
+					jm = a * 64 + rs_nth_high(MR(a), m - (int) sufR[a + 1]);
 				}
 				const int cutq = (m >= 1 && (iNext < 0 || iNext > jm)) ? jm : iNext;
 				if(lane == 0) { shI[2] = cutq; shI[3] = m; shI[4] = jm; }
@@ -381,6 +416,37 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			const int cutAbs = qBase + cutq;
 			PT* RS = dst + rsOff;                                   /* right stoppers by rank, beyond the positions */
 			if(tid == 0) { hLo[level] = lo; hQB[level] = qBase; hW[level] = wAbs; hCut[level] = cutAbs; hM[level] = m; hOff[level] = off; hNC[level] = R >> 6; }
+			if(inLds) {
+				/* ---- the m swaps in place: the left stopper of rank k <= m (all of them lie before the cut) finds j_k by a search on the scanned counts */
+				for(int q = o0 + tid; q < cutq; q += HU_RS_THREADS) {
+					const int t = q >> 6, bit = q & 63;
+					const unsigned long long mL = mLs[t];
+					if((mL >> bit) & 1ull) {
+						const int k = (int) preL[t] + __popcll(mL & rs_lane_lt(bit)) + 1;
+						if(k <= m) {
+							int a = 0, b = NTl - 1;
+							while(a < b) { const int md = (a + b + 1) >> 1; if((int) sufR[md] >= k) a = md; else b = md - 1; }
+							const int j = a * 64 + rs_nth_high(mRs[a], k - (int) sufR[a + 1]);
+							const PT x = lk[qBase + q - lbase + 64], y = lk[qBase + j - lbase + 64];
+							lk[qBase + q - lbase + 64] = y; lk[qBase + j - lbase + 64] = x;
+						}
+					}
+				}
+				__syncthreads();
+				RS_T(5);
+				if(cutAbs < K) {       /* the left part ends inside the first K places: set aside as it stands, the right part goes on */
+					for(int p = lo + tid; p < cutAbs; p += HU_RS_THREADS) fin[p] = rs_key(HuPair<PT>::canon(lk[p - lbase + 64]), ((uint32_t)(level + 1) << 24) | (uint32_t) p);
+					if(tid == 0 && nStash < 12) { stash[nStash].lo = lo; stash[nStash].hi = cutAbs; stash[nStash].depth = depth; }
+					if(nStash >= 12) { failed = true; why = 5; break; }
+					++nStash;
+					lo = cutAbs;
+				}
+				else hi = cutAbs;
+				++level;
+				__syncthreads();
+				RS_T(6);
+				continue;
+			}
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
@@ -415,7 +481,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				 * WILL stand at lo + 1, mid and cut - 1: each is the element there, or the right stopper of its rank if that one is a left stopper —
 				 * and pass B2 classifies what it writes against it */
 				const int nNTl = (cutq + 63) >> 6, nR = (nNTl + 1 + 63) & ~63, gEnd2 = nNTl * LPS;
-				const bool fuse = cutAbs - lo > HU_RS_SMALL && depth > 0 && level + 1 < HU_RS_MAXLEV && tabNext + nR <= tabCap;
+				const bool fuse = cutAbs - lo > LCAP && depth > 0 && level + 1 < HU_RS_MAXLEV && tabNext + nR <= tabCap;
 				if(fuse && wave == 0) {
 					const int mid = lo + (cutAbs - lo) / 2;
 					const int P = lane == 0 ? lo + 1 : (lane == 1 ? mid : cutAbs - 1);
