@@ -456,10 +456,10 @@ def main():
     if rank == 0 and world == 1 and args.seed_order == "stable":
         try:
             opts_ref = E.default_opts(seed_order=1)
-            # per batch in this mode: the (d, N) pair matrix (batch x nodes x <= 4 bytes) + the sort's scratch (<= 5 GB): as many in flight as fit beside the database
+            # per batch in this mode: the (d, N) pair matrix (batch x nodes x <= 4 bytes) + the sort's scratch (keys + level tables of 768 workgroups, <= 5 GB): as many in flight as fit beside the database
             free_ref, _ = torch.cuda.mem_get_info(local)
             need_ref = args.batch * int(D.n_nodes) * 4 + (5 << 30)
-            nbr = max(1, min(nb, 4, int(free_ref * 0.9) // need_ref)); steps_ref = 4 * nbr
+            nbr = max(1, min(nb, int(free_ref * 0.9) // need_ref)); steps_ref = 4 * nbr
             for i in range(nbr):
                 batches[i].assign(opts_ref)                     # setup: the mode's buffers (pair matrix, sort scratch) exist before the clock starts
             def ref_steps(i):

@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32
 	}
 }
 
+/* Measured and not kept (round 3): the PAIR scan in the form of k_seed_dscan4 — two nodes per lane (64 + 64 counters), the reads' planes broadcast
+ * from LDS, every operation on vector registers: xor, bitop3, and, and + two population counts = 16 cycles per (node, read, 32 sites) step
+ * against the 22 of k_seed_pdist2.  134 VGPRs, bit-identical pairs, 3.93 ms against 3.52: with two nodes per lane the 48 broadcast reads per
+ * wave and quad stand against 2,048 cycles of arithmetic instead of 2,560 for four, and the LDS becomes the bound; four nodes per lane with
+ * both counters do not fit the register file. */
 /* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
  * fractions differ by more than 2^-32, so floor(d * 2^39 / N) separates them; N == 0 (the
  * reference's 0/0 = NaN) sorts last.  Ties are broken by node id in the low 24 bits. */
