@@ -1411,7 +1411,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	const size_t m0 = (size_t) d.nNodes - 1;
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
-	if(lds > 150 * 1024) return seed_order_libstdcxx(b, o);
+	if(lds > 150 * 1024 || m0 >= ((size_t) 1 << 24)) return seed_order_libstdcxx(b, o);      /* a place must fit the 24 bits of the trace-back's tag */
 	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
 	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
 	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
