@@ -750,6 +750,7 @@ struct HuKnobs {
 	int scan_lds_pad = 0;        /* the same for the distance-only scan                                               */
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 	int width_split = 1;         /* 0: one launch of the estimate / placement kernels for the whole batch, shaped by its widest region (rounds 1-2) */
+	int sort_seq = 0;            /* filterPlacements / the final sort by the restated std::sort for every read (else only where keys tie) */
 	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
 	                              * host pool, 2 = std::length_error on the calling thread of the finish stage, 3 = std::runtime_error in a pool worker
@@ -762,7 +763,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit}, {"width_split", &HuKnobs::width_split},
-	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host},
+	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host}, {"sort_seq", &HuKnobs::sort_seq},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -1858,7 +1859,7 @@ extern "C" int hu_filter_batch(hu_batch* b, const hu_opts* o) try {
 	if(n) {
 		/* filterPlacements (src/HmmUFOtu_main.cpp:162-173) per read on the device: libstdc++'s std::sort(rbegin, rend, compareByLoglik) restated (hu_kern_rank.h).
 		 * A read that is not placed has no seeds (k_seed_drop_empty), hence no candidates */
-		k_filter<<<(unsigned)((n + 63) / 64), 64, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dEst.p, o->max_error, b->dCandCnt.p, b->dFiltSlot.p, 0);
+		k_filter<<<(unsigned)((n + 3) / 4), 256, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dEst.p, o->max_error, b->dCandCnt.p, b->dFiltSlot.p, b->knob.sort_seq);
 		HIPCHK(hipGetLastError());
 		if((rc = scan_cands(b, true)) != HU_OK) return rc;
 		if((rc = b->dCands.ensure(std::max<size_t>(b->nc, 1))) != HU_OK || (rc = b->dPlaces.ensure(std::max<size_t>(b->nc, 1))) != HU_OK) return rc;
@@ -2062,6 +2063,20 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 } catch(...) { return hu_catch_all("hu_place_batch"); }
 
 
+/* g_alleq_first (hu_kern_rank.h) once per device and process */
+static int hu_alleq_table(int device) {
+	static std::mutex mu; static bool done[64] = {false};
+	std::lock_guard<std::mutex> lk(mu);
+	if(device < 0 || device >= 64) { hu_set_error("device %d out of range", device); return HU_ERR_ARG; }
+	if(done[device]) return HU_OK;
+	(void) hipGetLastError();
+	k_alleq_init<<<1, 128>>>();
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipDeviceSynchronize());
+	done[device] = true;
+	return HU_OK;
+}
+
 extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 	if(!b || !o) return HU_ERR_ARG;
 	if(b->state < ST_PLACED) { hu_set_error("hu_finish_batch: candidates are not placed"); return HU_ERR_STATE; }
@@ -2076,8 +2091,9 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 	if(n) {
 		/* PTPlacement after placeSeq (the F4 constant as loglik), calcQValues, the final std::sort and bestPlace: one thread per read
 		 * on the device (hu_kern_rank.h); only the best record of every read comes back — the candidates' records stay until somebody asks */
+		if((rc = hu_alleq_table(db->device)) != HU_OK) return rc;
 		k_finish<<<(unsigned)((n + 63) / 64), 64, 0, b->stream>>>(db->dev, b->n, b->dStart.p, b->dEnd.p, b->dCandOff.p, b->dPlaces.p, b->dPlaceOut.p,
-				b->fixedRoot ? b->dRootLL.p : nullptr, db->dLlTab, db->dAnnoId, o->max_height, o->only_ml, o->prior, b->placesGiven ? 1 : 0, b->dBest.p);
+				b->fixedRoot ? b->dRootLL.p : nullptr, db->dLlTab, db->dAnnoId, o->max_height, o->only_ml, o->prior, b->placesGiven ? 1 : 0, b->dBest.p, b->knob.sort_seq);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->best.data(), b->dBest.p, n * sizeof(hu_place_rec), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));

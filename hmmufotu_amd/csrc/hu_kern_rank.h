@@ -111,12 +111,13 @@ __global__ __launch_bounds__(64) void k_sort_desc_test(int rows, int n, const do
 	for(int i = 0; i < n; ++i) order[(size_t) r * n + i] = o[i];
 }
 
-/* filterPlacements: per read the seed slots in descending order of the estimated loglik, cut at maxError below the best */
-__global__ __launch_bounds__(64) void k_filter(int n, const int32_t* __restrict__ seedCnt, const HuEstOut* __restrict__ est, double maxError,
-		int32_t* __restrict__ candCnt, uint8_t* __restrict__ filtSlot, int fault) {
-	const int r = blockIdx.x * 64 + threadIdx.x;
-	if(r >= n) return;
-	const int cnt = min(seedCnt[r], (int) HU_MAX_SEEDS);
+/* filterPlacements: per read the seed slots in descending order of the estimated loglik, cut at maxError below the best.
+ * One WAVE per read.  While a read's keys are pairwise different (and none is a NaN) the sorted order is a fact of the keys, not of the sort:
+ * the place of a seed is the number of greater keys — sixty-four broadcasts and compares — and the kept seeds are those within maxError of the
+ * best (what the reference's loop over the sorted list keeps: the gap to the best only grows along it).  A read with two equal keys (the two
+ * writings of an attachment at a node, or -inf) or a NaN gets libstdc++'s own order from one lane running the restated std::sort.
+ * (One thread per read sorting in private memory took 0.55 ms per 8,192 reads.) */
+__device__ __attribute__((noinline)) void hu_filter_seq(int r, int cnt, const HuEstOut* __restrict__ est, double maxError, int32_t* __restrict__ candCnt, uint8_t* __restrict__ filtSlot) {
 	double k[64]; uint8_t o[64];
 	for(int s = 0; s < cnt; ++s) k[s] = est[(size_t) r * HU_MAX_SEEDS + s].loglik;
 	hu_sort_desc64(k, cnt, o);
@@ -126,7 +127,27 @@ __global__ __launch_bounds__(64) void k_filter(int n, const int32_t* __restrict_
 		for(; g < cnt; ++g) { if(best - k[o[g]] > maxError) break; filtSlot[(size_t) r * HU_MAX_SEEDS + g] = o[g]; }
 	}
 	candCnt[r] = g;
-	(void) fault;
+}
+__global__ __launch_bounds__(256) void k_filter(int n, const int32_t* __restrict__ seedCnt, const HuEstOut* __restrict__ est, double maxError,
+		int32_t* __restrict__ candCnt, uint8_t* __restrict__ filtSlot, int forceSeq) {
+	const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if(r >= n) return;
+	const int cnt = min(seedCnt[r], (int) HU_MAX_SEEDS);
+	if(cnt <= 0) { if(lane == 0) candCnt[r] = 0; return; }
+	const double key = lane < cnt ? est[(size_t) r * HU_MAX_SEEDS + lane].loglik : 0.0;
+	int gt = 0, eq = 0;
+	for(int j = 0; j < cnt; ++j) {
+		const double kj = __shfl(key, j);
+		gt += kj > key ? 1 : 0; eq += kj == key ? 1 : 0;
+	}
+	const bool odd = lane < cnt && eq != 1;          /* a tie (eq > 1) or a NaN (eq == 0) */
+	if(__ballot(odd) || forceSeq) { if(lane == 0) hu_filter_seq(r, cnt, est, maxError, candCnt, filtSlot); return; }
+	const unsigned long long top = __ballot(lane < cnt && gt == 0);
+	const double best = __shfl(key, __ffsll((long long) top) - 1);
+	const bool keep = lane < cnt && !(best - key > maxError);
+	const unsigned long long kept = __ballot(keep);
+	if(keep) filtSlot[(size_t) r * HU_MAX_SEEDS + gt] = (uint8_t) lane;
+	if(lane == 0) candCnt[r] = __popcll(kept);
 }
 
 /* candidate offsets (exclusive scan of the counts, total at [n]) and what the placement launch needs to know of the batch: the number of
@@ -163,6 +184,18 @@ __global__ void k_build_cands(HuDbDev db, int n, const int32_t* __restrict__ can
 	places[at] = p;
 }
 
+/* what std::sort(rbegin, rend) leaves in the first place when all n keys are equal: g_alleq_first[n], filled once per process by k_alleq_init */
+__device__ uint8_t g_alleq_first[HU_MAX_SEEDS + 1];
+__global__ __launch_bounds__(128) void k_alleq_init() {
+	const int n = threadIdx.x;
+	if(n > (int) HU_MAX_SEEDS) return;
+	double k[64]; uint8_t o[64];
+	for(int i = 0; i < n; ++i) k[i] = 0.0;
+	o[0] = 0;
+	hu_sort_desc64(k, n, o);
+	g_alleq_first[n] = n ? o[0] : 0;
+}
+
 __device__ inline double hu_add_scaled(double a, double c) { const double s = fmax(a, c); return log(exp(a - s) + exp(c - s)) + s; }   /* src/math/Stats.h:233-239 */
 __device__ inline double hu_p2q(double p) { return -10 * log(p) / log(10.0); }                                                       /* :240-241 */
 
@@ -170,7 +203,7 @@ __device__ inline double hu_p2q(double p) { return -10 * log(p) / log(10.0); }  
  * llTab[k] = the F4 constant of a region of k columns (k sequential additions of log(sum_i pi_i e), as treeLoglik adds them) */
 __global__ __launch_bounds__(64) void k_finish(HuDbDev db, int n, const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend,
 		const int32_t* __restrict__ candOff, HuPlaceRec* __restrict__ places, const HuPlaceOut* __restrict__ placeOut, const double* __restrict__ rootLL,
-		const double* __restrict__ llTab, const int32_t* __restrict__ annoId, double maxHeight, int onlyML, int prior, int given, hu_place_rec* __restrict__ best) {
+		const double* __restrict__ llTab, const int32_t* __restrict__ annoId, double maxHeight, int onlyML, int prior, int given, hu_place_rec* __restrict__ best, int forceSort) {
 	const int r = blockIdx.x * 64 + threadIdx.x;
 	if(r >= n) return;
 	hu_place_rec br;
@@ -225,8 +258,19 @@ __global__ __launch_bounds__(64) void k_finish(HuDbDev db, int n, const int32_t*
 			key[c] = p.qPlace;
 		}
 	}
-	hu_sort_desc64(key, cnt, ord);         /* std::sort(places.rbegin(), places.rend(), compareByQPlace | compareByLoglik) (src/hmmufotu.cpp:726, 730) */
-	const HuPlaceRec p = places[lo + ord[0]];
+	/* std::sort(places.rbegin(), places.rend(), compareByQPlace | compareByLoglik) (src/hmmufotu.cpp:726, 730), of which bestPlace takes the first
+	 * element.  A unique maximum is first whatever the sort does with the rest; when ALL keys tie (the rule: SURVEY.md F4 gives every candidate
+	 * the same loglik) the first place is a function of the count alone (g_alleq_first, from the same restated std::sort); only a maximum shared
+	 * by some candidates needs the sort itself */
+	int first;
+	{
+		double mx = key[0]; int am = 0, nmx = 1; bool nanKey = key[0] != key[0];
+		for(int c = 1; c < cnt; ++c) { nanKey |= key[c] != key[c]; if(key[c] > mx) { mx = key[c]; am = c; nmx = 1; } else if(key[c] == mx) ++nmx; }
+		if(!nanKey && nmx == 1 && !forceSort) first = am;
+		else if(!nanKey && nmx == cnt && !forceSort) first = g_alleq_first[cnt];
+		else { hu_sort_desc64(key, cnt, ord); first = ord[0]; }
+	}
+	const HuPlaceRec p = places[lo + first];
 	br.c_node = p.cNode; br.p_node = p.pNode; br.a_node = p.aNode; br.n_cand = hi - lo;
 	br.wuv = p.wuv; br.ratio = p.ratio; br.wnr = p.wnr; br.loglik = p.loglik; br.height = p.height;
 	br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik; br.root_loglik = p.rootLoglik;

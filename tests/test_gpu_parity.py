@@ -1578,3 +1578,34 @@ def test_width_split_of_a_batch(capfd):
     assert np.abs(c1["ratio"] - c0["ratio"]).max() < 1e-11 and np.abs(c1["wnr"] - c0["wnr"]).max() < 1e-11
     assert np.array_equal(best["c_node"], b0["c_node"])
     B.close(); D.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,pi,prior", [("GTR", None, 0), ("JC69", None, 0), ("HKY85", (0.3, 0.2, 0.3, 0.2), 1)])
+def test_filter_and_final_sort_fast_paths(model, pi, prior):
+    """filterPlacements on a wave per read (place = number of greater keys while a read's keys are pairwise different) and bestPlace without the
+    sort (a unique maximum; the all-equal table of SURVEY.md F4) against the same stages with the restated std::sort forced for every read
+    (knob sort_seq): identical candidate lists, order and best records — on databases with exact ties among the estimated logliks too
+    (JC69 / equal base frequencies: the two writings of an attachment at a node), with a uniform and a non-uniform prior."""
+    E = _engine()
+    kw = dict(pi=pi) if pi is not None else {}
+    db = get_db(90, 700, model, dg_k=0 if model == "JC69" else 4, seed=9, **kw)
+    reads, vps = sim_reads(db, 48, 150)
+    opts = E.default_opts(max_nseed=50, prior=prior)
+    D, B = _run_stages(E, db, reads, vps, opts)
+    B.get_seed(opts); B.estimate_seq(opts)
+    out = []
+    for seq in (0, 1):
+        B.set_knob("sort_seq", seq)
+        B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
+        c = B.candidates(); offs, recs = B.candidate_places()
+        out.append(({k: np.array(v, copy=True) for k, v in c.items()}, recs.copy(), B.placements().copy()))
+    (fast, rf, bf), (slow, rs, bs) = out
+    assert np.array_equal(fast["offs"], slow["offs"]) and fast["offs"][-1] > len(reads)
+    for k in ("c_node", "iters"):
+        assert np.array_equal(fast[k], slow[k]), k
+    for k in ("ratio", "wnr", "est_loglik"):
+        assert np.array_equal(fast[k], slow[k], equal_nan=True), k
+    assert rf.tobytes() == rs.tobytes()             # every candidate's record: nodes, q-values, heights
+    assert bf.tobytes() == bs.tobytes()             # bestPlace of every read
+    B.close(); D.close()
