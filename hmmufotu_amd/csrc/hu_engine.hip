@@ -1332,13 +1332,19 @@ extern "C" int hu_sort_desc_device(int device, const double* keys, int rows, int
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_sort_desc_device"); }
 
-extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt) try {
+extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int64_t root_place, int32_t* out_idx, int32_t* out_cnt);
+extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt) {
+	return hu_sort_prefix_device_at(device, pairs, rows, n, k, pair16, n, out_idx, out_cnt);
+}
+extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int64_t root_place, int32_t* out_idx, int32_t* out_cnt) try {
+	if(root_place < 0 || root_place > n) { hu_set_error("hu_sort_prefix_device_at: the root's place must be in 0 .. n"); return HU_ERR_ARG; }
 	if(!pairs || rows < 1 || n < 1 || n >= (1 << 24) - 1 || k < 1 || k > HU_MAX_SEEDS || !out_idx || !out_cnt) { hu_set_error("hu_sort_prefix_device: bad argument"); return HU_ERR_ARG; }
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
 	HIPCHK(hipSetDevice(device));
-	/* a tree of n + 1 nodes whose LAST node is the root: position p of the sort is node p */
+	/* a tree of n + 1 nodes with node `root_place` as the root: position p of the sort is node p before it, node p + 1 from it on */
 	HuDbDev d; memset(&d, 0, sizeof(d));
-	d.nNodes = (int32_t) n + 1; d.nNodesPad = (d.nNodes + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD; d.root = (int32_t) n;
+	d.nNodes = (int32_t) n + 1; d.nNodesPad = (d.nNodes + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD; d.root = (int32_t) root_place;
+	auto nodeOf = [&](int64_t i) -> size_t { return (size_t)(i < root_place ? i : i + 1); };
 	if(hu_refsort_lds(d.nNodes) > 150 * 1024) { hu_set_error("hu_sort_prefix_device: %lld elements are more than the kernel takes", (long long) n); return HU_ERR_ARG; }
 	for(size_t i = 0, e = (size_t) rows * (size_t) n; i < e; ++i) /* a p-distance: d differing sites of N compared ones (N = 0: NaN, left to the host path) */
 		if((pairs[i] >> 16) > (pairs[i] & 0xffffu) && (pairs[i] & 0xffffu)) { hu_set_error("hu_sort_prefix_device: pair %zu has d > N", i); return HU_ERR_ARG; }
@@ -1353,13 +1359,13 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	std::vector<uint32_t> h32; std::vector<uint16_t> h16;
 	if(pair16) {
 		h16.assign((size_t) rows * np, 0x0001);
-		for(int r = 0; r < rows; ++r) for(int64_t i = 0; i < n; ++i) { const uint32_t v = pairs[(size_t) r * n + i]; h16[(size_t) r * np + i] = (uint16_t)(((v >> 16) << 8) | (v & 0xffu)); }
+		for(int r = 0; r < rows; ++r) for(int64_t i = 0; i < n; ++i) { const uint32_t v = pairs[(size_t) r * n + i]; h16[(size_t) r * np + nodeOf(i)] = (uint16_t)(((v >> 16) << 8) | (v & 0xffu)); }
 		if((rc = dP16.ensure(h16.size())) != HU_OK) return rc;
 		HIPCHK(hipMemcpy(dP16.p, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
 	}
 	else {
 		h32.assign((size_t) rows * np, 1);
-		for(int r = 0; r < rows; ++r) memcpy(&h32[(size_t) r * np], pairs + (size_t) r * n, (size_t) n * 4);
+		for(int r = 0; r < rows; ++r) for(int64_t i = 0; i < n; ++i) h32[(size_t) r * np + nodeOf(i)] = pairs[(size_t) r * n + i];
 		if((rc = dP32.ensure(h32.size())) != HU_OK) return rc;
 		HIPCHK(hipMemcpy(dP32.p, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
 	}
@@ -1393,7 +1399,7 @@ extern "C" int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows
 	HIPCHK(hipMemcpy(cnt.data(), dCnt.p, (size_t) rows * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(ids.data(), dId.p, ids.size() * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(hb.data(), dBail.p, hb.size() * 4, hipMemcpyDeviceToHost));
-	for(int r = 0; r < rows; ++r) { out_cnt[r] = cnt[r]; for(int s = 0; s < k; ++s) out_idx[(size_t) r * k + s] = s < cnt[r] ? ids[(size_t) r * HU_MAX_SEEDS + s] : -1; }
+	for(int r = 0; r < rows; ++r) { out_cnt[r] = cnt[r]; for(int s = 0; s < k; ++s) { const int32_t nd = ids[(size_t) r * HU_MAX_SEEDS + s]; out_idx[(size_t) r * k + s] = s < cnt[r] ? (nd > root_place ? nd - 1 : nd) : -1; } }
 	for(int i = 0; i < hb[0]; ++i) {
 		out_cnt[hb[2 + i] & 0x3ffffff] = -1;
 		if(getenv("HU_RS_TIMING")) fprintf(stderr, "[hu]   row %d left to the host: reason %d (1 depth, 2 tables, 3 NaN, 4 no stopper, 5 stash, 6 finisher)\n", hb[2 + i] & 0x3ffffff, hb[2 + i] >> 26);

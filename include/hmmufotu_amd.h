@@ -249,6 +249,9 @@ int hu_sort_prefix_libstdcxx(const double* dist, int64_t n, int64_t k, int32_t* 
  * (d << 16 | N, d <= N, N >= 1; pair16 != 0: held as 16-bit pairs, d, N <= 255), one sort per row.  out_idx [rows][k]; out_cnt [rows] =
  * min(k, n), or -1 for a row the kernel left to the host path (heap-sort branch of introsort). */
 int hu_sort_prefix_device(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int32_t* out_idx, int32_t* out_cnt);
+/* The same with the root of the test tree at place root_place (0 .. n) of node order instead of behind the last node: the kernel's level 0 is
+ * the pair row WITHOUT the root's entry, read in aligned vectors that are one element off from the root on. */
+int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int rows, int64_t n, int k, int pair16, int64_t root_place, int32_t* out_idx, int32_t* out_cnt);
 /* The device routine behind filterPlacements and the final sort (hu_kern_rank.h), exposed for its parity test: rows x n doubles (n <= HU_MAX_SEEDS),
  * order [rows][n] = for every place the index of the element that std::sort(rbegin, rend, less) — libstdc++'s introsort incl. its heap-sort
  * branch — leaves there (descending; equal keys as the library leaves them). */

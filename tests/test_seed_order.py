@@ -168,6 +168,21 @@ def test_device_sort_prefix_against_the_host_restatement():
     for r in range(rows):
         want = _prefix(dm[r] / Nm[r], 50)
         assert cnt[r] == 50 and np.array_equal(got[r], want), (n, r, got[r, :12], want[:12])
+    # the root anywhere in node order (the engine's trees have it at node 0, the rows above behind the last node): level 0 skips its entry, and the
+    # aligned vectors of the row are one element off from there on — at the start, inside a vector, on a vector / subtile boundary, at the end
+    for n in (40000, 198642):
+        rows = 4
+        Nm = np.where(rng.random((rows, n)) < 0.5, 250, 250 - rng.integers(0, 6, (rows, n))); dm = np.minimum(Nm, rng.binomial(250, 0.08, (rows, n)))
+        pairs = np.ascontiguousarray((dm.astype(np.uint32) << 16) | Nm.astype(np.uint32))
+        want = [_prefix(dm[r] / Nm[r], 50) for r in range(rows)]
+        for root in (0, 1, 5, 8, 63, 64, 1000, n // 2 + 3, n - 1, n):
+            for p16 in (True, False):
+                out = np.zeros((rows, 50), np.int32); cnt = np.zeros(rows, np.int32)
+                rc = lib.hu_sort_prefix_device_at(C.c_int(0), pairs.ctypes.data_as(C.c_void_p), C.c_int(rows), C.c_int64(n), C.c_int(50), C.c_int(int(p16)),
+                                                  C.c_int64(root), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+                assert rc == 0, lib.hu_last_error()
+                for r in range(rows):
+                    assert cnt[r] == 50 and np.array_equal(out[r], want[r]), (n, root, p16, r, out[r, :12], want[r][:12])
     # d > N is not a p-distance: refused
     assert lib.hu_sort_prefix_device(C.c_int(0), np.array([(5 << 16) | 3] * 8, np.uint32).ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int64(8), C.c_int(4), C.c_int(0),
                                      np.zeros(4, np.int32).ctypes.data_as(C.c_void_p), np.zeros(1, np.int32).ctypes.data_as(C.c_void_p)) != 0
