@@ -307,3 +307,40 @@ def test_reference_seed_order_paths_agree_and_fall_back_where_the_reference_is_u
     for i in range(len(rd)):
         oid, _, _, _ = Tp.get_seed(cd3[i], int(st3[i]), int(en3[i]), tie=1, max_n=20)
         assert cnt3[i] == len(oid) and (ids3[i, :cnt3[i]] == oid).all(), i
+
+
+@pytest.mark.gpu
+def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
+    """A tree of ~24,000 nodes: the device sort runs its streaming levels on the pair row (count pass, right stoppers by rank, fused counts of the
+    next level), moves into LDS below ~14 K places, finishes sequentially and traces the survivors back through every level to their nodes —
+    the root being node 0, so every aligned vector of the row is one element off.  Against the host restatement on the same pair rows
+    (knob refsort_host), all reads, 16-bit and 32-bit pairs."""
+    import re
+    from conftest import get_db, sim_reads
+    from hmmufotu_amd import engine as E
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    db = get_db(12000, 260, "JC69", dg_k=0, seed=3, n_match=180)
+    reads, vps = sim_reads(db, 96, 100)
+    rd = [r.seq for r in reads]
+    D = E.Database.from_synth(db)
+    for wide in (0, 1):
+        lists = []
+        for host in (0, 1):
+            B = E.Batch(D, len(rd))
+            B.set_knob("pairs32", wide); B.set_knob("refsort_host", host); B.set_knob("trace", 1)
+            opts = E.default_opts(seed_order=1)
+            capfd.readouterr()
+            B.set_reads(rd, vps); B.align(opts); B.get_seed(opts)
+            err = capfd.readouterr().err
+            if not host:
+                assert re.search(r"k_seed_refsort: 96 reads.* %s pairs.* 0 reads left to the host" % ("32-bit" if wide else "16-bit"), err), err
+            else:
+                assert "k_seed_refsort" not in err
+            cnt, ids, sd, sN = B.seeds()
+            lists.append((cnt.copy(), ids.copy(), sd.copy(), sN.copy()))
+            B.close()
+        (c0, i0, d0, n0), (c1, i1, d1, n1) = lists
+        assert (c0 == c1).all() and (c0 == 50).all()
+        assert (i0 == i1).all() and (d0 == d1).all() and (n0 == n1).all()
+    D.close()
