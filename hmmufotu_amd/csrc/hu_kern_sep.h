@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256, 3) void k_seed_dscan4(HuDbDev db, const uint32
  * from LDS, every operation on vector registers: xor, bitop3, and, and + two population counts = 16 cycles per (node, read, 32 sites) step
  * against the 22 of k_seed_pdist2.  134 VGPRs, bit-identical pairs, 3.93 ms against 3.52: with two nodes per lane the 48 broadcast reads per
  * wave and quad stand against 2,048 cycles of arithmetic instead of 2,560 for four, and the LDS becomes the bound; four nodes per lane with
- * both counters do not fit the register file. */
+ * both counters do not fit the register file — and taking the tile's sixteen reads in two passes of eight to make them fit (167 VGPRs, the node
+ * planes loaded twice) measured 4.36 ms.  One node per lane with scalar read planes stays: 99 % of its issue slots. */
 /* exact order-preserving integer image of dist = d/N for d <= N < 2^16: two different
  * fractions differ by more than 2^-32, so floor(d * 2^39 / N) separates them; N == 0 (the
  * reference's 0/0 = NaN) sorts last.  Ties are broken by node id in the low 24 bits. */
