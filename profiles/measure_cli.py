@@ -37,6 +37,7 @@ cli = os.path.join(ROOT, "hmmufotu_amd", "bin", "hmmufotu-amd")
 res = {}
 flights = os.environ.get("HU_CLI_INFLIGHT", "6").split(",")          # several values: the /dev/null run is repeated for each
 runs = [("shm_file", ["-o", os.path.join(tmp, "out.tsv")], flights[0])] + [("devnull" if f == flights[0] else "devnull_inflight%s" % f, ["-o", "/dev/null"], f) for f in flights]
+runs.append(("devnull_reference_seed_order", ["-o", "/dev/null", "--seed-order", "reference"], flights[0]))      # the reference binary's own seed order (k_seed_refsort)
 for name, extra, fl in runs:
     t1 = time.time()
     p = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--inflight", fl] + extra + os.environ.get("HU_CLI_EXTRA", "").split(), capture_output=True, text=True)
