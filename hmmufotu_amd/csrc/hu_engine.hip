@@ -811,7 +811,7 @@ struct hu_batch {
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<unsigned long long> dRefScratch;      /* k_seed_refsort: two key arrays + the level tables per resident workgroup */
-	DBuf<int32_t> dBail;
+	DBuf<int32_t> dBail, dNanCnt, dNanId; DBuf<uint32_t> dNanDN;      /* dNan*: the (dist, node id) selection of a batch whose reads met NaN distances in the reference-order mode */
 	int nRefBail = 0;                            /* reads of the last seed stage that the device sort left to the host */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
 	DBuf<uint32_t> dSortK, dSortV;
@@ -1407,6 +1407,25 @@ extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int r
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_sort_prefix_device"); }
 
+/* the reads the device sort listed for a NaN distance (entry = read | 3 << 26) take their seeds from the (dist, node id) selection with NaN last —
+ * what the reference-order rule falls back to where std::sort is undefined — computed for the whole batch by k_seed_topk into spare arrays */
+__global__ __launch_bounds__(64) void k_take_nan_rows(HuDbDev db, const int32_t* __restrict__ bail, const void* __restrict__ pairs, int p16,
+		const int32_t* __restrict__ tCnt, const int32_t* __restrict__ tId, const uint32_t* __restrict__ tDN,
+		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN) {
+	if((int) blockIdx.x >= bail[0]) return;
+	const int ent = bail[2 + blockIdx.x];
+	if((ent >> 26) != 3) return;
+	const int r = ent & 0x3ffffff, s = threadIdx.x;
+	const int cnt = tCnt[r];
+	if(s == 0) seedCnt[r] = cnt;
+	if(s < cnt) {
+		const int node = tId[(size_t) r * HU_MAX_SEEDS + s];
+		seedId[(size_t) r * HU_MAX_SEEDS + s] = node;
+		seedDN[(size_t) r * HU_MAX_SEEDS + s] = tDN[(size_t) r * HU_MAX_SEEDS + s];
+		parDN[(size_t) r * HU_MAX_SEEDS + s] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + db.parent[node], p16);
+	}
+}
+
 static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector<int32_t>* only = nullptr);
 
 /* the same on the device (k_seed_refsort: data-parallel Hoare partitions, hu_kern_refsort.h); the reads it lists — a NaN distance, the
@@ -1445,7 +1464,23 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	HIPCHK(hipStreamSynchronize(b->stream));
 	b->nRefBail = hb[0];
 	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", ms, hb[0]); }
-	if(hb[0] > 0) { std::vector<int32_t> only(hb.begin() + 2, hb.begin() + 2 + hb[0]); for(int32_t& x : only) x &= 0x3ffffff; std::sort(only.begin(), only.end()); return seed_order_libstdcxx(b, o, &only); }
+	if(hb[0] > 0) {
+		std::vector<int32_t> only;
+		int nNan = 0;
+		for(int i = 0; i < hb[0]; ++i) nNan += (hb[2 + i] >> 26) == 3;
+		const bool nanOnDevice = nNan > 16;       /* a database with partial sequences: nearly every read meets a node it shares no column with */
+		if(nanOnDevice) {
+			if((rc = b->dNanCnt.ensure((size_t) n)) != HU_OK || (rc = b->dNanId.ensure((size_t) n * HU_MAX_SEEDS)) != HU_OK || (rc = b->dNanDN.ensure((size_t) n * HU_MAX_SEEDS)) != HU_OK) return rc;
+			if(b->pair16) k_seed_topk<uint16_t><<<n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
+			else k_seed_topk<uint32_t><<<n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
+			k_take_nan_rows<<<hb[0], 64, 0, b->stream>>>(d, b->dBail.p, b->dPairs.p, b->pair16 ? 1 : 0, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p);
+			HIPCHK(hipGetLastError());
+			if(b->knob.trace) fprintf(stderr, "[hu] reference seed order: %d reads with a NaN distance take the (dist, node id) selection on the device\n", nNan);
+		}
+		for(int i = 0; i < hb[0]; ++i) if(!(nanOnDevice && (hb[2 + i] >> 26) == 3)) only.push_back(hb[2 + i] & 0x3ffffff);
+		std::sort(only.begin(), only.end());
+		if(!only.empty()) return seed_order_libstdcxx(b, o, &only);
+	}
 	return HU_OK;
 }
 

@@ -302,8 +302,11 @@ def test_reference_seed_order_paths_agree_and_fall_back_where_the_reference_is_u
     _, Hp, Tp = oracle_objects(dbp)
     capfd.readouterr()
     cnt3, ids3, cd3, st3, en3 = engine_lists(dbp, opts)
-    m = re.search(r"k_seed_refsort: 24 reads.* (\d+) reads left to the host", capfd.readouterr().err)
+    err3 = capfd.readouterr().err
+    m = re.search(r"k_seed_refsort: 24 reads.* (\d+) reads left to the host", err3)
     assert m and int(m.group(1)) > 0
+    # more than a handful of them (a database with partial sequences: nearly every read): the fallback rule runs on the device as well
+    assert int(m.group(1)) <= 16 or "take the (dist, node id) selection on the device" in err3, err3
     for i in range(len(rd)):
         oid, _, _, _ = Tp.get_seed(cd3[i], int(st3[i]), int(en3[i]), tie=1, max_n=20)
         assert cnt3[i] == len(oid) and (ids3[i, :cnt3[i]] == oid).all(), i
