@@ -811,6 +811,7 @@ struct hu_batch {
 	DBuf<int32_t> dTileQ, dSlotRead, dReadSlot;
 	DBuf<uint32_t> dRq;
 	DBuf<unsigned long long> dRefScratch;      /* k_seed_refsort: two key arrays + the level tables per resident workgroup */
+	DBuf<int32_t> dHv, dZeroPar; DBuf<unsigned long long> dPairsC; int refHvCount = 0; double refHvHeight = NAN;      /* the reference-order mode under a height filter: the nodes that pass, the compacted pair rows */
 	DBuf<int32_t> dBail, dNanCnt, dNanId; DBuf<uint32_t> dNanDN;      /* dNan*: the (dist, node id) selection of a batch whose reads met NaN distances in the reference-order mode */
 	int nRefBail = 0;                            /* reads of the last seed stage that the device sort left to the host */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
@@ -1426,14 +1427,58 @@ __global__ __launch_bounds__(64) void k_take_nan_rows(HuDbDev db, const int32_t*
 	}
 }
 
+/* the reference-order mode under a height filter (-H): std::sort runs over the nodes that pass it, in node order — the pair rows compacted to
+ * those nodes (k_compact_rows), sorted as the rows of a tree whose root stands behind the last of them, the places mapped back (k_map_seeds) */
+template<class PT>
+__global__ __launch_bounds__(256) void k_compact_rows(const PT* __restrict__ pairs, size_t np, const int32_t* __restrict__ hv, int m, PT* __restrict__ out, size_t npC) {
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if(p >= (int) npC) return;
+	out[(size_t) blockIdx.y * npC + p] = p < m ? pairs[(size_t) blockIdx.y * np + hv[p]] : HuPair<PT>::pack(1u);
+}
+__global__ __launch_bounds__(64) void k_map_seeds(HuDbDev db, const int32_t* __restrict__ hv, const void* __restrict__ pairs, int p16,
+		const int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN) {
+	const int r = blockIdx.x, s = threadIdx.x;
+	if(s >= seedCnt[r]) return;
+	const int node = hv[seedId[(size_t) r * HU_MAX_SEEDS + s]];
+	seedId[(size_t) r * HU_MAX_SEEDS + s] = node;
+	seedDN[(size_t) r * HU_MAX_SEEDS + s] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + node, p16);
+	parDN[(size_t) r * HU_MAX_SEEDS + s] = hu_pair_load(pairs, (size_t) r * db.nNodesPad + db.parent[node], p16);
+}
+
 static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector<int32_t>* only = nullptr);
 
 /* the same on the device (k_seed_refsort: data-parallel Hoare partitions, hu_kern_refsort.h); the reads it lists — a NaN distance, the
  * heap-sort branch of introsort — are finished by the host function */
 static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
-	const HuDbDev& d = b->db->dev;
+	const HuDbDev& d0 = b->db->dev;
 	const int n = b->n;
-	if(b->knob.refsort_host || o->max_height != INFINITY || d.nNodes < 3) return seed_order_libstdcxx(b, o);
+	if(b->knob.refsort_host || d0.nNodes < 3) return seed_order_libstdcxx(b, o);
+	int rc;
+	/* a height filter: the rows compacted to the nodes that pass it, sorted as a tree of those nodes + a root behind them */
+	const bool filtered = o->max_height != INFINITY;
+	HuDbDev d = d0;
+	const void* pairsIn = b->dPairs.p;
+	if(filtered) {
+		if(b->refHvHeight != o->max_height || !b->dHv.p) {
+			std::vector<int32_t> hv;
+			for(int i = 0; i < d0.nNodes; ++i) if(i != d0.root && b->db->height[i] <= o->max_height) hv.push_back(i);
+			if((rc = b->dHv.ensure(std::max<size_t>(hv.size(), 1))) != HU_OK) return rc;
+			if(!hv.empty()) HIPCHK(hipMemcpyAsync(b->dHv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, b->stream));
+			HIPCHK(hipStreamSynchronize(b->stream));      /* hv is a local */
+			b->refHvCount = (int) hv.size(); b->refHvHeight = o->max_height;
+		}
+		const int m = b->refHvCount;
+		if(m < 2 || n < 1) return seed_order_libstdcxx(b, o);
+		const size_t npC = ((size_t) m + 1 + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD, pb = b->pair16 ? 2 : 4;
+		if((rc = b->dPairsC.ensure(((size_t) n * npC * pb + 7) / 8)) != HU_OK || (rc = b->dZeroPar.ensure(npC)) != HU_OK) return rc;
+		HIPCHK(hipMemsetAsync(b->dZeroPar.p, 0, npC * 4, b->stream));
+		const dim3 gc((unsigned)((npC + 255) / 256), (unsigned) n);
+		if(b->pair16) k_compact_rows<uint16_t><<<gc, 256, 0, b->stream>>>((const uint16_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint16_t*) b->dPairsC.p, npC);
+		else k_compact_rows<uint32_t><<<gc, 256, 0, b->stream>>>((const uint32_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint32_t*) b->dPairsC.p, npC);
+		HIPCHK(hipGetLastError());
+		d.nNodes = m + 1; d.nNodesPad = (int32_t) npC; d.root = m; d.parent = b->dZeroPar.p;      /* (the kernel's own parent pairs are overwritten by k_map_seeds) */
+		pairsIn = b->dPairsC.p;
+	}
 	const size_t m0 = (size_t) d.nNodes - 1;
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
@@ -1441,7 +1486,6 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
 	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
 	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
-	int rc;
 	if((rc = b->dRefScratch.ensure((size_t) G * perWg)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;
 	HIPCHK(hipMemsetAsync(b->dBail.p, 0, 8, b->stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1449,15 +1493,16 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	if(b->knob.trace) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, b->stream)); }
 	if(b->pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
+		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) pairsIn, n, b->dStart.p, b->dEnd.p, o->max_nseed,
 				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) b->dPairs.p, n, b->dStart.p, b->dEnd.p, o->max_nseed,
+		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) pairsIn, n, b->dStart.p, b->dEnd.p, o->max_nseed,
 				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
 	}
 	HIPCHK(hipGetLastError());
+	if(filtered) { k_map_seeds<<<n, 64, 0, b->stream>>>(d0, b->dHv.p, b->dPairs.p, b->pair16 ? 1 : 0, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p); HIPCHK(hipGetLastError()); }
 	if(e1) HIPCHK(hipEventRecord(e1, b->stream));
 	std::vector<int32_t> hb((size_t) n + 2);
 	HIPCHK(hipMemcpyAsync(hb.data(), b->dBail.p, ((size_t) n + 2) * 4, hipMemcpyDeviceToHost, b->stream));
@@ -1471,9 +1516,9 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 		const bool nanOnDevice = nNan > 16;       /* a database with partial sequences: nearly every read meets a node it shares no column with */
 		if(nanOnDevice) {
 			if((rc = b->dNanCnt.ensure((size_t) n)) != HU_OK || (rc = b->dNanId.ensure((size_t) n * HU_MAX_SEEDS)) != HU_OK || (rc = b->dNanDN.ensure((size_t) n * HU_MAX_SEEDS)) != HU_OK) return rc;
-			if(b->pair16) k_seed_topk<uint16_t><<<n, 256, 0, b->stream>>>(d, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
-			else k_seed_topk<uint32_t><<<n, 256, 0, b->stream>>>(d, b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
-			k_take_nan_rows<<<hb[0], 64, 0, b->stream>>>(d, b->dBail.p, b->dPairs.p, b->pair16 ? 1 : 0, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p);
+			if(b->pair16) k_seed_topk<uint16_t><<<n, 256, 0, b->stream>>>(d0, (const uint16_t*) b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
+			else k_seed_topk<uint32_t><<<n, 256, 0, b->stream>>>(d0, b->dPairs.p, o->max_height, o->max_nseed, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->knob.topk_fast_min);
+			k_take_nan_rows<<<hb[0], 64, 0, b->stream>>>(d0, b->dBail.p, b->dPairs.p, b->pair16 ? 1 : 0, b->dNanCnt.p, b->dNanId.p, b->dNanDN.p, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p);
 			HIPCHK(hipGetLastError());
 			if(b->knob.trace) fprintf(stderr, "[hu] reference seed order: %d reads with a NaN distance take the (dist, node id) selection on the device\n", nNan);
 		}

@@ -245,7 +245,7 @@ def test_engine_in_reference_seed_order_on_config_1():
 @pytest.mark.gpu
 def test_reference_seed_order_paths_agree_and_fall_back_where_the_reference_is_undefined(capfd):
     """The reference-order mode on a mid-size tree: (1) the device kernel and the host restatement (knob refsort_host) give the same seed lists,
-    equal to the oracle's literal std::sort; (2) with a height filter (-H) the pair rows are compacted on the host path — same rule; (3) a database
+    equal to the oracle's literal std::sort; (2) with a height filter (-H) the pair rows are compacted to the nodes that pass it (on the device: k_compact_rows, and on the host path) — same rule; (3) a database
     with partial sequences: reads meet nodes they share no column with (N = 0: dist = 0 / 0), std::sort is undefined on NaN, the oracle falls
     back to (dist, id) with NaN last and so must the engine — the device kernel hands such reads to the host path (trace line)."""
     import copy, re
@@ -284,7 +284,11 @@ def test_reference_seed_order_paths_agree_and_fall_back_where_the_reference_is_u
     # (2) height filter
     hmax = float(np.median(db.height))
     opts_h = E.default_opts(max_nseed=20, seed_order=1, max_height=hmax)
+    capfd.readouterr()
     cnt2, ids2, _, _, _ = engine_lists(db, opts_h)
+    assert re.search(r"k_seed_refsort: 24 reads.* 0 reads left to the host", capfd.readouterr().err)      # on the device too: the rows compacted to the nodes that pass
+    cnt2h, ids2h, _, _, _ = engine_lists(db, opts_h, ("refsort_host", 1))
+    assert (cnt2 == cnt2h).all() and (ids2 == ids2h).all()
     for i in range(len(rd)):
         oid, _, _, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_height=hmax, tie=1, max_n=20)
         assert cnt2[i] == len(oid) and (ids2[i, :cnt2[i]] == oid).all(), i
@@ -317,7 +321,7 @@ def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
     """A tree of ~24,000 nodes: the device sort runs its streaming levels on the pair row (count pass, right stoppers by rank, fused counts of the
     next level), moves into LDS below ~14 K places, finishes sequentially and traces the survivors back through every level to their nodes —
     the root being node 0, so every aligned vector of the row is one element off.  Against the host restatement on the same pair rows
-    (knob refsort_host), all reads, 16-bit and 32-bit pairs."""
+    (knob refsort_host), all reads, 16-bit and 32-bit pairs, and under a height filter (the rows compacted to the nodes that pass)."""
     import re
     from conftest import get_db, sim_reads
     from hmmufotu_amd import engine as E
@@ -327,12 +331,13 @@ def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
     reads, vps = sim_reads(db, 96, 100)
     rd = [r.seq for r in reads]
     D = E.Database.from_synth(db)
-    for wide in (0, 1):
+    hmax = float(np.quantile(db.height, 0.9))          # ~21,600 nodes pass: the compacted rows still start with a streaming level
+    for wide, maxh in ((0, None), (1, None), (0, hmax)):
         lists = []
         for host in (0, 1):
             B = E.Batch(D, len(rd))
             B.set_knob("pairs32", wide); B.set_knob("refsort_host", host); B.set_knob("trace", 1)
-            opts = E.default_opts(seed_order=1)
+            opts = E.default_opts(seed_order=1) if maxh is None else E.default_opts(seed_order=1, max_height=maxh)
             capfd.readouterr()
             B.set_reads(rd, vps); B.align(opts); B.get_seed(opts)
             err = capfd.readouterr().err
@@ -346,4 +351,6 @@ def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
         (c0, i0, d0, n0), (c1, i1, d1, n1) = lists
         assert (c0 == c1).all() and (c0 == 50).all()
         assert (i0 == i1).all() and (d0 == d1).all() and (n0 == n1).all()
+        if maxh is not None:
+            assert (db.height[i0] <= maxh).all()
     D.close()
