@@ -52,9 +52,11 @@ def parse_args(argv=None):
     ap.add_argument("--uniform-starts", action="store_true", help="read starts uniform over the resident window (SURVEY §8d second run)")
     ap.add_argument("--partial-frac", type=float, default=0.0, help="fraction of the leaves that lose a prefix or suffix (partial reference sequences)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (0 = skip, -1 = about 30 s worth on the CPUs the process may use)")
-    ap.add_argument("--seed-order", choices=["stable", "reference"], default="stable",
-                    help="hu_opts.seed_order: 'stable' = (dist, node id), selected on the device [default]; 'reference' = the first max_nseed of libstdc++'s "
-                         "std::sort on dist alone (HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, reproduced on the device by k_seed_refsort)")
+    ap.add_argument("--seed-order", choices=["stable", "reference"], default="reference",
+                    help="hu_opts.seed_order of the timed region: 'reference' [default] = the first max_nseed of libstdc++'s std::sort on dist alone "
+                         "(HU_SEED_ORDER_LIBSTDCXX: the reference binary's own tie permutation, src/HmmUFOtu_main.cpp:139 + src/hmmufotu.cpp:646-647, reproduced on the "
+                         "device by the pair scan + k_seed_refsort); 'stable' = (dist, node id) (distance-only scan + top-k).  The other order is measured after the "
+                         "timed region and reported as a side block (seed_order_stable / seed_order_reference)")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("HU_BENCH_E2E_READS", 1 << 20)),
                     help="distinct reads of the end-to-end block (host seed lookup + upload + engine + TSV formatting, measured after the timed region; 0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
@@ -124,10 +126,30 @@ def launch_ranks(args):
     sys.exit(0)
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """ONE JSON line on stdout is the contract; libraries this process loads write there too (RCCL prints its version banner to stdout when a process
+    group is created).  File descriptor 1 is pointed at stderr for the whole run and the line goes to a duplicate of the original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _REAL_STDOUT
+
+
+def emit(line):
+    out = claim_stdout()
+    out.write(line + "\n"); out.flush()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print("[bench] WORLD_SIZE=%d but --gpus %d: refusing to measure a different rank count than asked for" % (world, args.gpus),
@@ -152,6 +174,18 @@ def main():
             rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(backend)
+    rccl_error = None
+    if world == 1 and not args.rehearse and backend == "nccl" and not os.environ.get("HU_BENCH_NO_RCCL"):
+        # one rank is a process group too: RCCL is initialised on this GPU and the final gather of the result records runs through it exactly as at N > 1
+        # (an all_gather over one rank), so that the collective path has run on the hardware the line is measured on.  A failure here must not sink the line.
+        try:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+            rccl_ranks = dist.get_world_size()
+        except Exception as ex:
+            rccl_error = repr(ex); dist = None
+            log("RCCL at world size 1 failed to initialise: %s" % rccl_error)
     cdev = dev if backend == "nccl" else "cpu"              # where collective payloads live
 
     from hmmufotu_amd.shard import gather_records
@@ -184,12 +218,12 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t1)
         ok = len(gathered) == world * args.batch and (np.sort(gathered["c_node"]) == np.arange(world * args.batch)).all()
         if rank == 0:
-            print(json.dumps(dict(metric=metric, value=None, unit="reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            emit(json.dumps(dict(metric=metric, value=None, unit="reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                                   ms_per_step=dt / max(1, args.steps) * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                                   dtype="f64", data="control-flow rehearsal: no engine, no GPU, nothing measured",
                                   config=dict(workload="rehearsal", parallelism="read-sharded x%d" % world), backend=backend,
                                   rccl_ranks=rccl_ranks, gathered_records=int(len(gathered)), gather_ok=bool(ok),
-                                  self_launched=bool(os.environ.get("HU_BENCH_SELF_LAUNCHED")))), flush=True)
+                                  self_launched=bool(os.environ.get("HU_BENCH_SELF_LAUNCHED")))))
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -244,8 +278,9 @@ def main():
             mv_c = all_mvps[0] if args.paired else None
 
             def phase_a(n, lib):
+                # seed_ids: the (dist, node id) list; lib_ids (want_lib): the literal std::sort's, from the same scan
                 return O.pipeline_batch(H_o, T_a, reads_c[:n], all_vps[0][:n], mates=mates_c[:n] if mates_c else None, mvpaths=mv_c[:n] if mates_c else None,
-                                        threads=cores, mode=1, want_lib=lib)
+                                        opts=O.default_opts(tieMode=0), threads=cores, mode=1, want_lib=lib)
             n0 = min(len(reads_c), max(cores, 16))
             tc = time.perf_counter(); phase_a(n0, False); d0 = time.perf_counter() - tc
             ns = args.cpu_sample if args.cpu_sample > 0 else int(min(len(reads_c), max(n0, 24.0 / max(d0 / n0, 1e-6))))
@@ -276,14 +311,25 @@ def main():
     log("database resident: %.1f GB in HBM, K=%d, nodes=%d, build %.0fs" % (D.hbm_bytes / 1e9, D.K, D.n_nodes, time.time() - t0))
     batches = []
     opts = E.default_opts(seed_order=1 if args.seed_order == "reference" else 0)
+    # as many batches in flight as fit beside the database: the first one runs once (its device buffers exist then — in the reference's seed order a
+    # (d, N) pair row per read + the sort's scratch, 13 + 5 GB per 8,192 pairs at config 5) and what it took is asked of the others
+    per_batch = None
     for i in range(nb):
+        free_now, _ = torch.cuda.mem_get_info(local)
+        if per_batch is not None and free_now < 1.1 * per_batch + (2 << 30):
+            log("%d batches in flight instead of %d: %.1f GB free, %.1f GB per batch" % (i, nb, free_now / 1e9, per_batch / 1e9))
+            break
         B = E.Batch(D, args.batch)
         if args.paired:
             B.set_reads([r.seq for r in all_reads[i]], all_vps[i], [r.seq for r in all_mates[i]], all_mvps[i])
         else:
             B.set_reads([r.seq for r in all_reads[i]], all_vps[i])     # inputs resident in HBM before the timed region
         B.sync()
+        if i == 0:
+            B.assign(opts); B.sync()
+            per_batch = free_now - torch.cuda.mem_get_info(local)[0]
         batches.append(B)
+    nb = len(batches)
     log("reads simulated and uploaded: %d batches of %d (%.0fs)" % (nb, args.batch, time.time() - t0))
 
     # nb batches in flight, each driven by its own host thread on its own HIP stream (the C ABI's
@@ -321,7 +367,8 @@ def main():
     cpu0 = os.times()
     t1 = time.perf_counter()
     recs = run(args.steps)[-1]
-    if world > 1:                                           # the one collective: final result gather over RCCL
+    gathered = None
+    if world > 1 or rccl_ranks:                             # the one collective: final result gather over RCCL
         gathered = gather_records(recs, cdev)
     barrier()
     dt_local = time.perf_counter() - t1
@@ -365,15 +412,22 @@ def main():
     Rsum = float((en[ok] - st[ok] + 1).sum())
     Wp = args.read_len + 60
     # algorithmic bytes per launch (SURVEY.md §8d per-unit figures x units of one launch)
-    alg = dict(viterbi=nseq * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum, seed_topk=4.0 * D.n_nodes * nread,
+    ref_order = args.seed_order == "reference"
+    pair_bytes = 4 if (args.paired or args.read_len > 255) else 2       # the (d, N) pair row of the reference-order mode: 16-bit pairs while no read has more than 255 bases
+    alg = dict(viterbi=nseq * (args.read_len + 136.0 * Wp), seed_pdist=(D.n_nodes - 1) * Rsum,
+               seed_topk=(float(pair_bytes) * (D.n_nodes - 1) * nread if ref_order else 4.0 * D.n_nodes * nread),      # k_seed_refsort: the pair row once
                estimate=S * 65.0 * Rsum, place=C * 64.0 * Rsum)
     # measured HBM traffic + VALU issue per kernel: from the newest committed PMC summary that was taken on THIS workload
     # (rocprofv3 --pmc passes of this same command, profiles/make_pmc_summary.py); tagged with its source, null otherwise
     stages = ("viterbi", "seed_pdist", "seed_topk", "estimate", "place")
-    pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"), seed_pdist=("k_seed_dscan4", "k_seed_dscan", "k_seed_pdist2", "k_seed_pdist"),
-                      seed_topk=("k_seed_topk_straight", "k_seed_topk_d", "k_seed_topk"), estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
+    pmc_prefix = dict(viterbi=("k_viterbi_wave", "k_viterbi_dec2", "k_viterbi_dec", "k_viterbi_lds", "k_viterbi"),
+                      seed_pdist=("k_seed_pdist2", "k_seed_pdist") if ref_order else ("k_seed_dscan4", "k_seed_dscan", "k_seed_pdist2", "k_seed_pdist"),
+                      seed_topk=("k_seed_refsort",) if ref_order else ("k_seed_topk_straight", "k_seed_topk_d", "k_seed_topk"),
+                      estimate=("k_estimate_prod", "k_estimate_blk", "k_estimate"), place=("k_place_blk", "k_place_pair", "k_place"))
     workload_key = dict(leaves=args.leaves, cs_len=args.cs_len, read_len=args.read_len, batch=args.batch, dg_k=args.dg_k, paired=bool(args.paired),
                         uniform_starts=bool(args.uniform_starts), win=args.win)
+    if not ref_order:
+        workload_key["seed_order"] = "stable"
     if args.partial_frac:
         workload_key["partial_frac"] = args.partial_frac
     pmc, pmc_src, pmc_hash = {}, None, None
@@ -401,8 +455,10 @@ def main():
     for k in stages:
         name, ent = pmc_entry(k)
         tr = ent.get("hbm_bytes_per_launch")
+        # algorithmic_over_hbm_peak: the contract's figure (SURVEY.md section 8d bytes / isolated time / 8 TB/s).  Above 1 it is NOT a bandwidth anybody measured: the kernel does the
+        # reference's work on fewer bytes (bit-planes, sixteen reads per node tile, L2 sharing); what the chip really moved and issued are the two fields after it
         e = dict(stage=k, kernel=name, ms_isolated=round(iso[k], 3), ms_in_timed_region=round(acc[k], 3), algorithmic_bytes=alg[k],
-                 achieved=alg[k] / (iso[k] * 1e-3) / 1e9, unit="GB/s", frac=alg[k] / (iso[k] * 1e-3) / 1e9 / peak,
+                 algorithmic_GBps=alg[k] / (iso[k] * 1e-3) / 1e9, algorithmic_over_hbm_peak=alg[k] / (iso[k] * 1e-3) / 1e9 / peak,
                  traffic=tr, hbm_measured_frac=(tr / (iso[k] * 1e-3) / 1e9 / peak if tr else None))
         if ent.get("valu_issue_cycles_per_launch"):       # typed instruction counts x measured issue cycles (profiles/isa_cost.py), over 1,024 SIMDs
             e["valu_issue_frac"] = ent["valu_issue_cycles_per_launch"] / 1024.0 / (iso[k] * 1e-3 * ent.get("clock_hz", 2.37e9))   # 2.37 GHz: measured, profiles/r02d_clocks.json
@@ -410,24 +466,34 @@ def main():
     dom = max(kern, key=lambda x: x["ms_isolated"])
     # What binds the dominant kernel is FP64 VALU issue at the occupancy its per-site state allows, not HBM: `bound` says so.
     # `frac` stays the contract's number (algorithmic bytes / isolated time / HBM peak); the two measured roofs sit beside it.
-    roof = dict(bound="valu_fp64_issue", kernel=dom["kernel"], achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], traffic=dom["traffic"],
+    dfrac = dom["algorithmic_over_hbm_peak"]
+    roof = dict(bound="valu_fp64_issue", kernel=dom["kernel"], achieved=dom["algorithmic_GBps"], peak=peak, unit="GB/s", frac=dfrac, traffic=dom["traffic"],
                 ms=dom["ms_isolated"], timing="HIP events on the batch's stream, one batch in flight (the kernel's own cost)",
                 ms_in_timed_region=dom["ms_in_timed_region"], frac_in_timed_region=dom["algorithmic_bytes"] / (dom["ms_in_timed_region"] * 1e-3) / 1e9 / peak,
                 hbm_measured_frac=dom["hbm_measured_frac"], valu_issue_frac=dom.get("valu_issue_frac"), traffic_source=pmc_src,
                 pmc_kernel_source_hash=pmc_hash, kernel_source_hash=src_hash, pmc_stale=pmc_stale,
-                hbm_roof=dict(achieved=dom["achieved"], peak=peak, unit="GB/s", frac=dom["frac"], measured_frac=dom["hbm_measured_frac"]),
+                hbm_roof=dict(achieved=dom["algorithmic_GBps"], peak=peak, unit="GB/s", frac=dfrac, measured_frac=dom["hbm_measured_frac"]),
                 valu_roof=dict(frac=dom.get("valu_issue_frac"), unit="issue cycles of the kernel's vector instructions / (1,024 SIMDs x clock x isolated time)"),
-                note="frac = ALGORITHMIC bytes (SURVEY.md section 8d per-unit figures x the launch's units: int8 node sites, FP64 messages, no reuse credited) / isolated time / "
-                     "8 TB/s.  Kernels whose frac exceeds 1 (roofline_kernels: seed scan, top-k, estimate) do the reference's work on fewer bytes — three bit-planes instead "
-                     "of int8 sites, sixteen reads per node tile, only the 128-column quads that hold read bases, no pair row for the top-k, reads sharing a seed node meeting "
-                     "in one XCD's L2 — checked bit for bit against the reference's own pDist / the oracle; hbm_measured_frac (PMC bytes) and valu_issue_frac are the roofs "
-                     "that say how busy the chip is.  pmc_stale = the PMC summary was taken on other kernel sources than are running now.")
+                note="frac = ALGORITHMIC bytes of the dominant kernel (SURVEY.md section 8d per-unit figure x the launch's units: FP64 messages once per candidate) / its isolated "
+                     "time / 8 TB/s; traffic = PMC bytes of the same launch.  The kernel is bound by FP64 vector issue at the occupancy its per-site state allows (valu_roof), not "
+                     "by HBM.  BASELINE.json's '>= 50 % HBM-bandwidth utilisation' is NOT met at configs 2-4 and cannot be by this formulation: after the bit-plane / tiling / "
+                     "eigenbasis reformulations every kernel of the path is VALU-issue-bound (roofline_path.path_valu_issue_frac), and the path moves ~a fifth of the HBM peak "
+                     "(roofline_path.hbm_measured_frac).  pmc_stale = the PMC summary was taken on other kernel sources than are running now.")
     bytes_per_read = (D.n_nodes - 1) * R + S * 65 * R + C * 64 * R + (2 if args.paired else 1) * (args.read_len + 136 * Wp) + args.cs_len + 128
     step_traffic = sum(k["traffic"] for k in kern) if all(k["traffic"] for k in kern) else None
-    path = dict(bytes_per_read=bytes_per_read, achieved=bytes_per_read * value / world / 1e9, unit="GB/s per GPU",
-                frac=bytes_per_read * value / world / 1e9 / peak, mean_R=R, mean_candidates=C,
+    # every vector instruction of a step, priced at its measured issue cost, over what 1,024 SIMDs could issue in the step's time: how busy the chip's VALUs are, the roof
+    # that binds the path.  The per-step kernels of this seed order from the PMC summary (one-time kernels and the other order's seed kernels left out)
+    one_time = ("k_alleq_init", "k_node_cover", "k_pack_msgs", "k_col_planes", "k_tree_", "k_pairs_of_read", "k_sort_desc_test")
+    other_seed = ("k_seed_dscan", "k_seed_topk_straight", "k_seed_topk_d") if ref_order else ("k_seed_pdist2", "k_seed_refsort", "k_ref_pivots", "k_take_nan_rows")
+    issue_cycles = sum(v.get("valu_issue_cycles_per_launch", 0.0) for name_, v in pmc.items() if not name_.startswith(one_time) and not name_.startswith(other_seed))
+    clock_hz = next((v.get("clock_hz") for v in pmc.values() if v.get("clock_hz")), 2.37e9)
+    path = dict(algorithmic_bytes_per_read=bytes_per_read, algorithmic_GBps_equivalent=bytes_per_read * value / world / 1e9, mean_R=R, mean_candidates=C,
+                what="algorithmic bytes (SURVEY.md section 8d: int8 node sites streamed once per read, FP64 messages, no reuse credited) x reads/s.  An EQUIVALENT rate — "
+                     "%.0f x the HBM peak — not a bandwidth: the scan works on 3 bit-planes x 16 reads per node tile.  The measured roofs follow" % (bytes_per_read * value / world / 1e9 / peak),
                 hbm_measured_bytes_per_step=step_traffic,
-                hbm_measured_frac=(step_traffic / (dt / args.steps) / 1e9 / peak if step_traffic else None), traffic_source=pmc_src, pmc_stale=pmc_stale)
+                hbm_measured_frac=(step_traffic / (dt / args.steps) / 1e9 / peak if step_traffic else None),
+                path_valu_issue_frac=(issue_cycles / 1024.0 / ((dt / args.steps) * clock_hz) if issue_cycles else None),
+                traffic_source=pmc_src, pmc_stale=pmc_stale)
 
     shape = "%s %d bp" % ("PE 2 x" if args.paired else "SE", args.read_len)
     free_b, total_b = torch.cuda.mem_get_info(local)
@@ -444,44 +510,50 @@ def main():
                timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
                             "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: `end_to_end` below measures them in this same process",
                host_cores_busy_per_rank=round(host_cores_busy, 1), host_cpus=os.cpu_count(), host_cpu_quota=cpu_quota(),
-               rccl_ranks=rccl_ranks, backend=backend if world > 1 else None, gathered_records=(int(len(gathered)) if world > 1 else None),
+               rccl_ranks=rccl_ranks, rccl_error=rccl_error, backend=backend if (world > 1 or rccl_ranks) else None, gathered_records=(int(len(gathered)) if gathered is not None else None),
                roofline=roof, roofline_kernels=kern, roofline_path=path,
                kernel_ms={k: round(v, 3) for k, v in acc.items()}, kernel_ms_one_batch_in_flight={k: round(v, 3) for k, v in iso.items()},
                host_wall_ms={k: round(float(v), 2) for k, v in wall.items()}, place_iterations=place_iters)
 
-    # ---- the same task with the seeds in the REFERENCE's own order (hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX: the first max_nseed of libstdc++'s
-    # std::sort on dist alone, reproduced on the device by k_seed_refsort) — measured here, after the timed region, on the same resident batches, because
-    # that order is what the reference binary's output follows wherever nodes tie at the cut-off distance (cpu_baseline.tie_mode counts how often)
-    best_ref = None
-    if rank == 0 and world == 1 and args.seed_order == "stable":
+    # ---- the same task in the OTHER seed order, after the timed region, on the same resident batches.  The timed region runs the reference's own order
+    # (HU_SEED_ORDER_LIBSTDCXX: what a g++-built reference binary outputs wherever nodes tie at the cut-off distance; cpu_baseline.tie_mode counts how often
+    # that matters); (dist, node id) — HU_SEED_ORDER_STABLE, the distance-only scan + top-k — is the faster, library-independent mode and is reported beside it
+    other = "stable" if ref_order else "reference"
+    other_key = "seed_order_" + other
+    best_oth = cand_oth = None
+    if rank == 0 and world == 1:
         try:
-            opts_ref = E.default_opts(seed_order=1)
-            # per batch in this mode: the (d, N) pair matrix (batch x nodes x <= 4 bytes) + the sort's scratch (keys + level tables of 768 workgroups, <= 5 GB): as many in flight as fit beside the database
-            free_ref, _ = torch.cuda.mem_get_info(local)
-            need_ref = args.batch * int(D.n_nodes) * 4 + (5 << 30)
-            nbr = max(1, min(nb, int(free_ref * 0.9) // need_ref)); steps_ref = 4 * nbr
+            opts_oth = E.default_opts(seed_order=0 if ref_order else 1)
+            nbr = nb
+            if not ref_order:     # the reference-order mode asks for more memory per batch (pair rows + sort scratch): as many in flight as fit
+                free_ref, _ = torch.cuda.mem_get_info(local)
+                need_ref = args.batch * int(D.n_nodes) * 4 + (5 << 30)
+                nbr = max(1, min(nb, int(free_ref * 0.9) // need_ref))
+            steps_oth = 4 * nbr
             for i in range(nbr):
-                batches[i].assign(opts_ref)                     # setup: the mode's buffers (pair matrix, sort scratch) exist before the clock starts
-            def ref_steps(i):
-                for _ in range(steps_ref // nbr):
-                    batches[i].assign(opts_ref)
+                batches[i].assign(opts_oth)                     # setup: the mode's buffers exist before the clock starts
+            def oth_steps(i):
+                for _ in range(steps_oth // nbr):
+                    batches[i].assign(opts_oth)
                     batches[i].placements()
             torch.cuda.synchronize()
             tr0 = time.perf_counter()
-            list(pool.map(ref_steps, range(nbr)))
+            list(pool.map(oth_steps, range(nbr)))
             torch.cuda.synchronize()
             dtr = time.perf_counter() - tr0
-            best_ref = batches[0].placements().copy(); cand_ref = batches[0].candidates()
+            best_oth = batches[0].placements().copy(); cand_oth = batches[0].candidates()
             tms = batches[0].timings()
-            out["seed_order_reference"] = dict(value=args.batch * steps_ref / dtr, unit=out["unit"], ms_per_step=dtr / steps_ref * 1e3, steps=steps_ref, batches_in_flight=nbr,
-                                               seed_stage_ms=round(tms["seed_pdist"] + tms["seed_topk"], 2),
-                                               what="hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX: full (d, N) pair scan + k_seed_refsort (libstdc++'s introsort restricted to the first "
-                                                    "max_nseed places, as data-parallel Hoare partitions) instead of the distance-only scan + top-k; everything else as in the timed region")
-            log("reference seed order: %.0f %s (%.1f ms/step, %d batches in flight)" % (args.batch * steps_ref / dtr, out["unit"], dtr / steps_ref * 1e3, nbr))
+            out[other_key] = dict(value=args.batch * steps_oth / dtr, unit=out["unit"], ms_per_step=dtr / steps_oth * 1e3, steps=steps_oth, batches_in_flight=nbr,
+                                  seed_stage_ms=round(tms["seed_pdist"] + tms["seed_topk"], 2),
+                                  what=("hu_opts.seed_order = HU_SEED_ORDER_STABLE: ascending (dist, node id) by the distance-only scan + top-k instead of the full (d, N) pair scan + "
+                                        "k_seed_refsort; everything else as in the timed region.  NOT the reference binary's tie permutation (cpu_baseline.tie_mode)" if ref_order else
+                                        "hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX: full (d, N) pair scan + k_seed_refsort (libstdc++'s introsort restricted to the first "
+                                        "max_nseed places, as data-parallel Hoare partitions) instead of the distance-only scan + top-k; everything else as in the timed region"))
+            log("seed order '%s': %.0f %s (%.1f ms/step, %d batches in flight)" % (other, args.batch * steps_oth / dtr, out["unit"], dtr / steps_oth * 1e3, nbr))
         except Exception as ex:
             import traceback
             traceback.print_exc()
-            out["seed_order_reference"] = dict(value=None, failed=repr(ex))
+            out[other_key] = dict(value=None, failed=repr(ex))
 
     # ---- end to end in this process: host seed lookup (hu_seed_index_lookup over the leaf rows' own index) -> read upload -> engine -> TSV lines,
     # over the pool of distinct reads drawn before the database was packed; one worker thread per batch object, chunks dealt in order of completion
@@ -632,26 +704,28 @@ def main():
                                                     note="relative to max(|oracle|, 1e-3), every candidate of every sampled read matched by branch; est_loglik = estimateSeq's, "
                                                          "ratio / wnr / height = placeSeq's; iterations = outer loops of the joint optimisation and passes of the 2-node EM"),
                                        tie_mode=tsum)
-            if best_ref is not None:    # the engine in the reference's seed order against the oracle under the literal std::sort, read by read
-                want_c = np.where(tper["order_differs"][:ns], tper["picks"][:ns, 1, 0], r1["best_nodes"][:ns, 0])
-                row_of = {int(i): k for k, i in enumerate(tper["lib_idx"])}; rl = tper["lib_run"]
+            if best_oth is not None:    # the engine in the other seed order against the oracle in that order (tie_report ran both lists wherever they differ), read by read
+                col = 0 if ref_order else 1                 # tie_report's picks[:, 0] = under (dist, node id), [:, 1] = under the literal std::sort
+                want_c = np.where(tper["order_differs"][:ns], tper["picks"][:ns, col, 0], r1["best_nodes"][:ns, 0])
+                row_of = {int(i): k for k, i in enumerate(tper["lib_idx"])}; ro = tper["stable_run"] if ref_order else tper["lib_run"]
                 perr = []
-                for i in range(ns):                           # the same classification as for the default order, against the oracle's std::sort run
-                    src_, k_ = (rl, row_of[i]) if i in row_of else (r1, i)
-                    kc = int(src_["n_cand"][k_]); a, b = int(cand_ref["offs"][i]), int(cand_ref["offs"][i + 1])
+                for i in range(ns):                           # the same classification as for the timed region's order
+                    src_, k_ = (ro, row_of[i]) if i in row_of else (r1, i)
+                    kc = int(src_["n_cand"][k_]); a, b = int(cand_oth["offs"][i]), int(cand_oth["offs"][i + 1])
                     perr.append(parity.classify_read(src_["cand_node"][k_, :kc], src_["cand_est"][k_, :kc], src_["cand_ratio0"][k_, :kc],
-                                                     cand_ref["c_node"][a:b], db.parent, pos=int(src_["best_pos"][k_]) if kc else None))
+                                                     cand_oth["c_node"][a:b], db.parent, pos=int(src_["best_pos"][k_]) if kc else None))
                 totr = parity.summarize(perr)
-                out["seed_order_reference"].update(reads_compared=int(ns), final_branch_differs_from_oracle_std_sort=int((best_ref["c_node"][:ns] != want_c).sum()),
-                                                   best_branch_diffs_explained_near_tie=totr["best_differs"] - totr["best_unexplained"], unexplained_best_branch_diffs=totr["best_unexplained"],
-                                                   candidate_set_differs=totr["set_differs"], swaps_unexplained=totr["swaps_unexplained"])
+                out[other_key].update(reads_compared=int(ns), oracle_seed_order="TIE_STABLE (dist, node id)" if ref_order else "TIE_LIBSTDCXX (literal std::sort)",
+                                      final_branch_differs_from_oracle=int((best_oth["c_node"][:ns] != want_c).sum()),
+                                      best_branch_diffs_explained_near_tie=totr["best_differs"] - totr["best_unexplained"], unexplained_best_branch_diffs=totr["best_unexplained"],
+                                      candidate_set_differs=totr["set_differs"], swaps_unexplained=totr["swaps_unexplained"])
         except Exception as ex:                             # the baseline must never sink the measurement
             import traceback
             traceback.print_exc()
             out["cpu_baseline"] = dict(value=None, unit="reads/s", cores=0, kind="port", sample="failed: %r" % (ex,))
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(json.dumps(out))
+    if world > 1 or rccl_ranks:
         dist.destroy_process_group()
 
 

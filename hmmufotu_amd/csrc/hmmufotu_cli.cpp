@@ -49,8 +49,9 @@ static void usage(const char* p) {
 		"            --chimera-out FILE  --chimera-info  -a FILE  --align-only\n"
 		"            --batch INT [8192]  --gpu INT [0] first device  --gpus INT [1] devices, one database replica each\n"
 		"            --inflight INT [3] batches in flight per device  -v  --version  -h|--help\n"
-		"            --seed-order stable|reference  which of the nodes tying at the cut-off distance become seeds: (dist, node id) [stable, default],\n"
-		"                             or the reference binary's own choice — the first -N of libstdc++'s std::sort on dist alone (slower: sorted on the host)\n"
+		"            --seed-order reference|stable  which of the nodes tying at the cut-off distance become seeds: the reference binary's own choice\n"
+		"                             [reference, default] — the first -N of libstdc++'s std::sort on dist alone, reproduced on the device — or\n"
+		"                             (dist, node id) [stable]: independent of the sort's tie permutation and ~25 % faster\n"
 		"            -S|--seed INT    a seed hit drawn from all its occurrences (CSFMIndex::locateOne) with this seed; without it the first occurrence\n"
 		"                             (locateFirst).  A run repeats at any thread count.  -p|--process INT is accepted and has no effect\n";
 }
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
 	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0;
 	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false, noCsfm = false, randomHits = false;
-	uint64_t hitSeed = 0; std::string seedOrder = "stable";
+	uint64_t hitSeed = 0; std::string seedOrder = "reference";
 	std::string alnFn;
 	int numSeg = 2; double chimeraErr = NAN, chimeraLod = 0; std::string chiOutFn;
 	hu_opts o; hu_default_opts(&o);

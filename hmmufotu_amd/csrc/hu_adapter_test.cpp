@@ -82,6 +82,13 @@ int main(int argc, char** argv) {
 			if(aln.isValid()) {
 				DigitalSeq seq(aln.align);                                                                        /* :641 */
 				std::vector<PTLoc> seeds = getSeed(ptu, seq, aln.csStart - 1, aln.csEnd - 1, o.max_diff, o.max_height);   /* :645 */
+				if(r < 3) { /* the reference's WHOLE vector on request: every eligible node, sorted by the caller's own std::sort — its head is the device's list */
+					const std::vector<PTLoc> whole = getSeed(ptu, seq, aln.csStart - 1, aln.csEnd - 1, o.max_diff, o.max_height, true);
+					bool head = whole.size() >= seeds.size(), sorted = true;
+					for(size_t i = 0; head && i < seeds.size(); ++i) head = whole[i].id == seeds[i].id && whole[i].dist == seeds[i].dist;
+					for(size_t i = 1; i < whole.size(); ++i) sorted = sorted && !(whole[i].dist < whole[i - 1].dist);
+					printf("WHOLE %d %zu %d %d\n", r, whole.size(), (int) head, (int) sorted);
+				}
 				if(seeds.size() > maxNSeed) seeds.erase(seeds.end() - (seeds.size() - maxNSeed), seeds.end());      /* :646-647 */
 				printf("SEED %d %zu", r, seeds.size());
 				for(const PTLoc& l : seeds) printf(" %ld:%.17g", l.id, l.dist);

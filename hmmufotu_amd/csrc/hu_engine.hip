@@ -212,6 +212,29 @@ static int8_t host_sym(char c) {
 	}
 }
 
+/* How a host thread waits for its stream.  hipStreamSynchronize under HIP's default scheduling (hipDeviceScheduleAuto) SPINS: with six batches in flight
+ * per GPU that is six host cores at 100 % doing nothing (BENCH_r03: host_cores_busy_per_rank 5.8 of a 16-core quota — eight ranks would ask for ~46).
+ * hipDeviceScheduleBlockingSync is not an option for a library: set after the runtime has created its queues (PyTorch initialises the device first) it
+ * leaves this ROCm build with completion signals it cannot attach its interrupt handler to ("hsa_amd_signal_async_handler() failed to set the handler",
+ * the next hipHostFree never returns: gpurun_out/cli_probe/trace.err, round 4).  So the engine waits by itself: it polls hipStreamQuery — a read of the
+ * stream's completion signal, no system call — for the first ~30 us (a short kernel ends inside them), then sleeps between polls, 20 us growing to 100:
+ * a thread waiting out a 3 ms kernel makes ~35 polls and uses ~2 % of a core; a synchronisation returns at most one sleep (<= 100 us + the wake-up) after
+ * the stream has drained, which the other batches in flight hide.  HU_SYNC=spin keeps the runtime's wait. */
+static hipError_t hu_wait(hipStream_t st) {
+	static const bool spin = [] { const char* e = getenv("HU_SYNC"); return e && !strcmp(e, "spin"); }();
+	if(spin) return hipStreamSynchronize(st);
+	const auto t0 = std::chrono::steady_clock::now();
+	long ns = 20000;
+	for(;;) {
+		const hipError_t e = hipStreamQuery(st);
+		if(e != hipErrorNotReady) return e;
+		if(std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) continue;
+		timespec ts{0, ns};
+		nanosleep(&ts, nullptr);
+		if(ns < 100000) ns += 20000;
+	}
+}
+
 /* ------------------------------------------------------------------------------ database */
 extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu_model_desc* model,
 		int device, hu_db** out) try {
@@ -378,8 +401,14 @@ extern "C" int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tre
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_db_create"); }
 
-extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) try {
+extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out) { return hu_db_load_window(hmm_path, ptu_path, device, 0, 0, out); }
+
+/* the same for a COLUMN WINDOW of the messages (win_len > 0): the device keeps the 4 x win_len doubles of every directed edge that lie in
+ * [win_start, win_start + win_len) — the unit of column-window sharding (hu_windows_plan): a database beyond one GPU's HBM is held as several
+ * such windows, one per device.  Profile, node sequences and tree are whole in every window. */
+extern "C" int hu_db_load_window(const char* hmm_path, const char* ptu_path, int device, int64_t win_start, int64_t win_len, hu_db** out) try {
 	if(!hmm_path || !ptu_path || !out) { hu_set_error("hu_db_load: null argument"); return HU_ERR_ARG; }
+	if(win_len < 0 || win_start < 0) { hu_set_error("hu_db_load_window: negative window"); return HU_ERR_ARG; }
 	*out = nullptr;
 	if(hu_device_count() <= 0) { hu_set_error("no gfx950 device visible: the engine has no CPU path"); return HU_ERR_DEVICE; }
 	HuProfileHost prof; std::vector<double> EM, EI, T; std::vector<int32_t> p2cs; int K, L;
@@ -402,7 +431,8 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	size_t row = 0; int turn = 0; hipError_t herr = hipSuccess;
 	const std::function<int(bool, int64_t, const double*)> sink = [&](bool isDown, int64_t node, const double* data) -> int {
 		if(!dUp) { /* first message: n and csLen are known */
-			row = (size_t) t.csLen * 4;
+			if(win_len > 0 && win_start + win_len > t.csLen) { hu_set_error("hu_db_load_window: columns %lld .. %lld of a database of %d", (long long) win_start, (long long)(win_start + win_len - 1), t.csLen); return HU_ERR_ARG; }
+			row = (size_t)(win_len > 0 ? win_len : t.csLen) * 4;
 			const size_t bytes = (size_t) t.n * row * sizeof(double);
 			if((herr = hipMalloc((void**) &dUp, bytes)) != hipSuccess || (herr = hipMalloc((void**) &dDown, bytes)) != hipSuccess ||
 					(herr = hipMemset(dDown, 0, bytes)) != hipSuccess || (herr = hipStreamCreate(&st)) != hipSuccess) return HU_ERR_NOMEM;
@@ -410,7 +440,7 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 					(herr = hipEventCreate(&ev[i])) != hipSuccess) return HU_ERR_NOMEM;
 		}
 		if((herr = hipEventSynchronize(ev[turn])) != hipSuccess) return HU_ERR_DEVICE;     /* the copy that last used this staging row */
-		memcpy(stage[turn], data, row * sizeof(double));
+		memcpy(stage[turn], data + (win_len > 0 ? (size_t) win_start * 4 : 0), row * sizeof(double));
 		if((herr = hipMemcpyAsync((isDown ? dDown : dUp) + (size_t) node * row, stage[turn], row * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess ||
 				(herr = hipEventRecord(ev[turn], st)) != hipSuccess) return HU_ERR_DEVICE;
 		turn ^= 1;
@@ -428,12 +458,13 @@ extern "C" int hu_db_load(const char* hmm_path, const char* ptu_path, int device
 	memset(&td, 0, sizeof(td));
 	td.n_nodes = t.n; td.cs_len = t.csLen; td.parent = t.parent.data(); td.blen = t.blen.data(); td.seq = t.seq.data();
 	td.up = dUp; td.down = dDown; td.msgs_on_device = 1;
+	if(win_len > 0) { td.win_start = win_start; td.win_len = win_len; }
 	td.height = t.height.data(); td.anno_id = t.annoId.data(); td.anno_dist = t.annoDist.data();
 	rc = hu_db_create(&pd, &td, &t.model, device, out);
 	keepMsgs = rc == HU_OK;
 	if(rc == HU_OK) { (*out)->annos = t.annos; (*out)->names = t.names; (*out)->allocs.push_back(dUp); (*out)->allocs.push_back(dDown); }   /* the database owns them */
 	return rc;
-} catch(...) { return hu_catch_all("hu_db_load"); }
+} catch(...) { return hu_catch_all("hu_db_load_window"); }
 
 /* PTUnrooted::save (src/PhyloTreeUnrooted.cpp:537-567 and :116-129, :595-603, :632-670, :672-697; src/DigitalSeq.cpp:96-104;
  * src/util/ProgEnv.cpp:24-28): the database file hmmufotu / hu_db_load read.  The messages may live on the device (98 GB at
@@ -751,6 +782,7 @@ struct HuKnobs {
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 	int width_split = 1;         /* 0: one launch of the estimate / placement kernels for the whole batch, shaped by its widest region (rounds 1-2) */
 	int sort_seq = 0;            /* filterPlacements / the final sort by the restated std::sort for every read (else only where keys tie) */
+	int ref_nofuse = 0;          /* HU_SEED_ORDER_LIBSTDCXX: k_seed_refsort counts its level 0 itself (pass A over the pair row) instead of starting from the stopper masks the scan leaves */
 	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
 	                              * host pool, 2 = std::length_error on the calling thread of the finish stage, 3 = std::runtime_error in a pool worker
@@ -763,7 +795,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit}, {"width_split", &HuKnobs::width_split},
-	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host}, {"sort_seq", &HuKnobs::sort_seq},
+	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host}, {"ref_nofuse", &HuKnobs::ref_nofuse}, {"sort_seq", &HuKnobs::sort_seq},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -814,6 +846,8 @@ struct hu_batch {
 	DBuf<int32_t> dHv, dZeroPar; DBuf<unsigned long long> dPairsC; int refHvCount = 0; double refHvHeight = NAN;      /* the reference-order mode under a height filter: the nodes that pass, the compacted pair rows */
 	DBuf<int32_t> dBail, dNanCnt, dNanId; DBuf<uint32_t> dNanDN;      /* dNan*: the (dist, node id) selection of a batch whose reads met NaN distances in the reference-order mode */
 	int nRefBail = 0;                            /* reads of the last seed stage that the device sort left to the host */
+	DBuf<uint32_t> dRefPiv; DBuf<unsigned long long> dRefL0; bool refFused = false;      /* level 0 of the device sort prepared by the scan: pivots [n][4], stopper masks [n][nNodesPad / 64][2] */
+	int refHostAll = 0;                          /* the last seed stage in the reference's order ran entirely on the host path (tree beyond the device sort) */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
 	DBuf<uint32_t> dSortK, dSortV;
 	DBuf<uint8_t> dSortTmp;
@@ -840,7 +874,7 @@ struct hu_batch {
 	int rMain = 0;              /* width split of the batch (plan_width_split): regions of at most rMain columns take the main launch; 0 = one launch for all */
 	std::vector<int32_t> wideReads;     /* the reads beyond it */
 	std::vector<uint32_t> hWideOrd, hWideCand; DBuf<uint32_t> dWideOrd, dWideCand;      /* their (read, seed) slots and their candidates: the lists of the second launches */
-	std::vector<int32_t> hCandOffAll;   /* candidate offsets on the host when there are wide reads (scan_cands) */
+	PinnedVec<int32_t> hCandOffAll;   /* candidate offsets on the host when there are wide reads (scan_cands) */
 	int nFullRedo = 0;          /* sequences of the last align call whose banded DP found no path: full DP, one launch */
 	DBuf<double> dRedoScr; DBuf<HuReadDesc> dRedoDesc; DBuf<HuVitOut> dRedoVit;    /* the redo launches' own scratch: kept (an allocation or a release stalls every stream of the device) */
 	PinnedVec<HuAlnDev> hAlns;
@@ -852,7 +886,8 @@ struct hu_batch {
 	std::vector<int64_t> candOffs;
 	std::vector<HostPlace> places;    /* candidates in filterPlacements order, all reads */
 	std::vector<HostPlace> tmpPlaces;
-	std::vector<hu_place_rec> best;
+	PinnedVec<hu_place_rec> best;      /* page-locked: a device-to-host copy into pageable memory makes the runtime wait (spinning) for the stream inside the call */
+	PinnedVec<int32_t> hMeta, hBail;   /* the same for the few words the host reads between stages */
 	PinnedVec<char> hRows;            /* alignment rows of the last format call */
 	std::vector<char> tsvBuf; std::vector<size_t> tsvOff, tsvLen; size_t tsvSize = 0;
 	int maxRegion = 0;
@@ -893,16 +928,16 @@ extern "C" int hu_batch_set_knob(hu_batch* b, const char* name, int value) try {
 extern "C" void hu_batch_destroy(hu_batch* b) try {
 	if(!b) return;
 	(void) hipSetDevice(b->db->device);
-	(void) hipStreamSynchronize(b->stream);
+	(void) hu_wait(b->stream);
 	for(int i = 0; i < 2 * HU_T_COUNT; ++i) (void) hipEventDestroy(b->ev[i]);
 	(void) hipStreamDestroy(b->stream);
 	delete b;      /* the DBuf members free their device memory */
 } catch(...) { (void) hu_catch_all("hu_batch_destroy"); }
-extern "C" int hu_batch_sync(hu_batch* b) try { if(!b) return HU_ERR_ARG; HIPCHK(hipStreamSynchronize(b->stream)); return HU_OK; } catch(...) { return hu_catch_all("hu_batch_sync"); }
+extern "C" int hu_batch_sync(hu_batch* b) try { if(!b) return HU_ERR_ARG; HIPCHK(hu_wait(b->stream)); return HU_OK; } catch(...) { return hu_catch_all("hu_batch_sync"); }
 extern "C" int hu_batch_profile(hu_batch* b, int enable) try { if(!b) return HU_ERR_ARG; b->profile = enable != 0; return HU_OK; } catch(...) { return hu_catch_all("hu_batch_profile"); }
 extern "C" int hu_batch_timings(hu_batch* b, float* ms) try {
 	if(!b || !ms) return HU_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(b->stream));
+	HIPCHK(hu_wait(b->stream));
 	for(int i = 0; i < HU_T_COUNT; ++i) {
 		float t = 0;
 		if(b->profile && b->evSet[i] && hipEventElapsedTime(&t, b->ev[2 * i], b->ev[2 * i + 1]) == hipSuccess) b->ms[i] = t;
@@ -1189,7 +1224,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 		}
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 		if(usedDec) { /* sequences whose traceback cannot trust the fill-time decisions: redo with every value filed */
 			int nRedo = 0;
 			for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_VALUES) nRedo++;
@@ -1218,12 +1253,12 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 					k_viterbi_trace<<<((unsigned) rdv.size() + 63) / 64, 64, 0, b->stream>>>(d, dd.p, scr.p, b->dTraces.p, tNN, tNB, vo.p, (int) rdv.size());
 					HIPCHK(hipGetLastError());
 					HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
-					HIPCHK(hipStreamSynchronize(b->stream));
+					HIPCHK(hu_wait(b->stream));
 					for(size_t k = 0; k < rdv.size(); ++k) {
 						b->hVit[rs[at + k]] = hv[k];               /* the trace is written at the sequence's own traceOff */
 						HIPCHK(hipMemcpyAsync(b->dVit.p + rs[at + k], &b->hVit[rs[at + k]], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
 					}
-					HIPCHK(hipStreamSynchronize(b->stream));
+					HIPCHK(hu_wait(b->stream));
 					at = e;
 				}
 			}
@@ -1233,7 +1268,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 				k_viterbi_trace<<<(b->nSeq + 63) / 64, 64, 0, b->stream>>>(d, b->dDescs.p, b->dScratch.p, b->dTraces.p, tNN, tNB, b->dVit.p, b->nSeq);
 				HIPCHK(hipGetLastError());
 				HIPCHK(hipMemcpyAsync(b->hVit.data(), b->dVit.p, (size_t) b->nSeq * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
-				HIPCHK(hipStreamSynchronize(b->stream));
+				HIPCHK(hu_wait(b->stream));
 			}
 		}
 		/* banded version failed -> regular HMM (src/HmmUFOtu_main.cpp:89-93): all such sequences in ONE launch, each with a
@@ -1268,7 +1303,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 			else k_viterbi<<<(unsigned) rdv.size(), 64, 0, b->stream>>>(d, dd.p, b->dBases.p, scr.p, b->dTraces.p, tNN, tNB, tEC, tCC, vo.p);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipMemcpyAsync(hv.data(), vo.p, hv.size() * sizeof(HuVitOut), hipMemcpyDeviceToHost, b->stream));
-			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hu_wait(b->stream));
 			for(size_t k = 0; k < rdv.size(); ++k) {
 				const int s = redo[at + k];
 				b->hVit[s] = hv[k];                     /* the trace is already written at the sequence's traceOff */
@@ -1276,7 +1311,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 				HIPCHK(hipMemcpyAsync(b->dVit.p + s, &b->hVit[s], sizeof(HuVitOut), hipMemcpyHostToDevice, b->stream));
 				b->hDescs[s].nRegions = -1; /* mark: full DP was used */
 			}
-			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hu_wait(b->stream));
 			at = e;
 		}
 		for(int s = 0; s < b->nSeq; ++s) if(b->hVit[s].status == HU_READ_NEEDS_FULL) {
@@ -1299,7 +1334,7 @@ extern "C" int hu_align_batch(hu_batch* b, const hu_opts* o) try {
 		HIPCHK(hipMemcpyAsync(b->hAlns.data(), b->dAlns.p, (size_t) b->nSeq * sizeof(HuAlnDev), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(b->hStart.data(), b->dStart.p, (size_t) b->n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(b->hEnd.data(), b->dEnd.p, (size_t) b->n * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 		for(int s = 0; s < b->nSeq; ++s) b->hAlns[s].usedFull |= (b->hDescs[s].nRegions == -1 || (b->hDescs[s].nRegions == 1 && !b->hDescs[s].reg[0].band)) ? 1 : 0;
 		/* reads whose region leaves the resident message window carry HU_READ_OUT_OF_WINDOW and an empty region (k_encode_rows) */
 	}
@@ -1349,6 +1384,8 @@ extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int r
 	if(hu_refsort_lds(d.nNodes) > 150 * 1024) { hu_set_error("hu_sort_prefix_device: %lld elements are more than the kernel takes", (long long) n); return HU_ERR_ARG; }
 	for(size_t i = 0, e = (size_t) rows * (size_t) n; i < e; ++i) /* a p-distance: d differing sites of N compared ones (N = 0: NaN, left to the host path) */
 		if((pairs[i] >> 16) > (pairs[i] & 0xffffu) && (pairs[i] & 0xffffu)) { hu_set_error("hu_sort_prefix_device: pair %zu has d > N", i); return HU_ERR_ARG; }
+	if(pair16) for(size_t i = 0, e = (size_t) rows * (size_t) n; i < e; ++i)      /* the 16-bit form holds d and N in 8 bits each: a larger value would be cut, not sorted */
+		if((pairs[i] >> 16) > 255u || (pairs[i] & 0xffffu) > 255u) { hu_set_error("hu_sort_prefix_device: pair %zu (d = %u, N = %u) does not fit the 16-bit form (d, N <= 255)", i, pairs[i] >> 16, pairs[i] & 0xffffu); return HU_ERR_ARG; }
 	const size_t np = (size_t) d.nNodesPad;
 	DBuf<int32_t> dPar, dSt, dEn, dCnt, dId, dBail; DBuf<uint32_t> dDN, dPN, dP32; DBuf<uint16_t> dP16; DBuf<unsigned long long> scr;
 	int rc;
@@ -1430,10 +1467,12 @@ __global__ __launch_bounds__(64) void k_take_nan_rows(HuDbDev db, const int32_t*
 /* the reference-order mode under a height filter (-H): std::sort runs over the nodes that pass it, in node order — the pair rows compacted to
  * those nodes (k_compact_rows), sorted as the rows of a tree whose root stands behind the last of them, the places mapped back (k_map_seeds) */
 template<class PT>
-__global__ __launch_bounds__(256) void k_compact_rows(const PT* __restrict__ pairs, size_t np, const int32_t* __restrict__ hv, int m, PT* __restrict__ out, size_t npC) {
+__global__ __launch_bounds__(256) void k_compact_rows(const PT* __restrict__ pairs, size_t np, const int32_t* __restrict__ hv, int m, PT* __restrict__ out, size_t npC, int nRows) {
 	const int p = blockIdx.x * 256 + threadIdx.x;
 	if(p >= (int) npC) return;
-	out[(size_t) blockIdx.y * npC + p] = p < m ? pairs[(size_t) blockIdx.y * np + hv[p]] : HuPair<PT>::pack(1u);
+	const int src = p < m ? hv[p] : 0;
+	for(int row = blockIdx.y; row < nRows; row += gridDim.y)       /* gridDim.y ends at 65,535: a larger batch walks its rows */
+		out[(size_t) row * npC + p] = p < m ? pairs[(size_t) row * np + src] : HuPair<PT>::pack(1u);
 }
 __global__ __launch_bounds__(64) void k_map_seeds(HuDbDev db, const int32_t* __restrict__ hv, const void* __restrict__ pairs, int p16,
 		const int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN) {
@@ -1446,6 +1485,16 @@ __global__ __launch_bounds__(64) void k_map_seeds(HuDbDev db, const int32_t* __r
 }
 
 static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector<int32_t>* only = nullptr);
+
+/* does the scan of this batch prepare level 0 of the device sort (k_ref_pivots + the masks of k_seed_pdist2<PT, true>)?  Whenever k_seed_refsort will run on the
+ * pair rows as they are (no height filter: its rows are compacted first) and the row is a streaming level (more places than the kernel holds in LDS) */
+static bool ref_fused_l0(const hu_batch* b, const hu_opts* o, bool pair16) {
+	const HuDbDev& d = b->db->dev;
+	if(b->knob.refsort_host || b->knob.ref_nofuse || d.nNodes < 3 || o->max_height != INFINITY) return false;
+	const size_t m0 = (size_t) d.nNodes - 1;
+	if(hu_refsort_lds(d.nNodes) > 150 * 1024 || m0 >= ((size_t) 1 << 24)) return false;
+	return (int) m0 > (pair16 ? hu_refsort_lcap<uint16_t>(m0) : hu_refsort_lcap<uint32_t>(m0));
+}
 
 /* the same on the device (k_seed_refsort: data-parallel Hoare partitions, hu_kern_refsort.h); the reads it lists — a NaN distance, the
  * heap-sort branch of introsort — are finished by the host function */
@@ -1464,7 +1513,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 			for(int i = 0; i < d0.nNodes; ++i) if(i != d0.root && b->db->height[i] <= o->max_height) hv.push_back(i);
 			if((rc = b->dHv.ensure(std::max<size_t>(hv.size(), 1))) != HU_OK) return rc;
 			if(!hv.empty()) HIPCHK(hipMemcpyAsync(b->dHv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, b->stream));
-			HIPCHK(hipStreamSynchronize(b->stream));      /* hv is a local */
+			HIPCHK(hu_wait(b->stream));      /* hv is a local */
 			b->refHvCount = (int) hv.size(); b->refHvHeight = o->max_height;
 		}
 		const int m = b->refHvCount;
@@ -1472,9 +1521,9 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 		const size_t npC = ((size_t) m + 1 + HU_NODE_PAD - 1) / HU_NODE_PAD * HU_NODE_PAD, pb = b->pair16 ? 2 : 4;
 		if((rc = b->dPairsC.ensure(((size_t) n * npC * pb + 7) / 8)) != HU_OK || (rc = b->dZeroPar.ensure(npC)) != HU_OK) return rc;
 		HIPCHK(hipMemsetAsync(b->dZeroPar.p, 0, npC * 4, b->stream));
-		const dim3 gc((unsigned)((npC + 255) / 256), (unsigned) n);
-		if(b->pair16) k_compact_rows<uint16_t><<<gc, 256, 0, b->stream>>>((const uint16_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint16_t*) b->dPairsC.p, npC);
-		else k_compact_rows<uint32_t><<<gc, 256, 0, b->stream>>>((const uint32_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint32_t*) b->dPairsC.p, npC);
+		const dim3 gc((unsigned)((npC + 255) / 256), (unsigned) std::min(n, 65535));
+		if(b->pair16) k_compact_rows<uint16_t><<<gc, 256, 0, b->stream>>>((const uint16_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint16_t*) b->dPairsC.p, npC, n);
+		else k_compact_rows<uint32_t><<<gc, 256, 0, b->stream>>>((const uint32_t*) b->dPairs.p, (size_t) d0.nNodesPad, b->dHv.p, m, (uint32_t*) b->dPairsC.p, npC, n);
 		HIPCHK(hipGetLastError());
 		d.nNodes = m + 1; d.nNodesPad = (int32_t) npC; d.root = m; d.parent = b->dZeroPar.p;      /* (the kernel's own parent pairs are overwritten by k_map_seeds) */
 		pairsIn = b->dPairsC.p;
@@ -1482,7 +1531,14 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	const size_t m0 = (size_t) d.nNodes - 1;
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
-	if(lds > 150 * 1024 || m0 >= ((size_t) 1 << 24)) return seed_order_libstdcxx(b, o);      /* a place must fit the 24 bits of the trace-back's tag */
+	if(lds > 150 * 1024 || m0 >= ((size_t) 1 << 24)) {      /* the level-0 tables do not fit the LDS (above ~600 k nodes), or a place does not fit the 24 bits of the trace-back's tag */
+		static std::atomic<bool> said{false};
+		if(!said.exchange(true)) fprintf(stderr, "[hu] reference seed order: a tree of %d nodes is beyond the device sort (k_seed_refsort: %zu KB of LDS tables, limit 150): every read takes the "
+				"host restatement of std::sort — tens of times slower (DESIGN.md section 4); --seed-order stable runs on the device at any size\n", d.nNodes, lds / 1024);
+		b->nRefBail = n; b->refHostAll = 1;
+		return seed_order_libstdcxx(b, o);
+	}
+	b->refHostAll = 0;
 	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
 	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
 	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
@@ -1491,24 +1547,34 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	HuScope evg([&] { if(e0) (void) hipEventDestroy(e0); if(e1) (void) hipEventDestroy(e1); });
 	if(b->knob.trace) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, b->stream)); }
+	const bool fused = b->refFused && !filtered;      /* the scan of this batch left the pivots and stopper masks of level 0 */
+	const uint32_t* l0piv = fused ? b->dRefPiv.p : nullptr; const unsigned long long* l0m = fused ? b->dRefL0.p : nullptr;
 	if(b->pair16) {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		k_seed_refsort<uint16_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint16_t*) pairsIn, n, b->dStart.p, b->dEnd.p, o->max_nseed,
-				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p, l0piv, l0m);
 	}
 	else {
 		if(lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*) k_seed_refsort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		k_seed_refsort<uint32_t><<<G, HU_RS_THREADS, lds, b->stream>>>(d, (const uint32_t*) pairsIn, n, b->dStart.p, b->dEnd.p, o->max_nseed,
-				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p);
+				b->dRefScratch.p, perWg, cap, (int) rsOff, (int) hu_refsort_tabcap(m0), b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p, b->dBail.p, l0piv, l0m);
 	}
 	HIPCHK(hipGetLastError());
 	if(filtered) { k_map_seeds<<<n, 64, 0, b->stream>>>(d0, b->dHv.p, b->dPairs.p, b->pair16 ? 1 : 0, b->dSeedCnt.p, b->dSeedId.p, b->dSeedDN.p, b->dParDN.p); HIPCHK(hipGetLastError()); }
 	if(e1) HIPCHK(hipEventRecord(e1, b->stream));
-	std::vector<int32_t> hb((size_t) n + 2);
+	b->hBail.resize((size_t) n + 2);
+	PinnedVec<int32_t>& hb = b->hBail;
 	HIPCHK(hipMemcpyAsync(hb.data(), b->dBail.p, ((size_t) n + 2) * 4, hipMemcpyDeviceToHost, b->stream));
-	HIPCHK(hipStreamSynchronize(b->stream));
+	HIPCHK(hu_wait(b->stream));
 	b->nRefBail = hb[0];
-	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", ms, hb[0]); }
+	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs%s: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", fused ? ", level 0 from the scan" : "", ms, hb[0]);
+#ifdef HU_RS_PROF
+		unsigned long long pr[16]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
+		static const char* nm[10] = {"idle", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher", "trace-back"};
+		for(int i = 0; i < 10; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
+		unsigned long long z[16] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
+#endif
+	}
 	if(hb[0] > 0) {
 		std::vector<int32_t> only;
 		int nNan = 0;
@@ -1540,7 +1606,7 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector
 		const bool p16 = b->pair16;
 		for(int32_t r : *only) {
 			HIPCHK(hipMemcpyAsync(rowBuf.data(), (const uint8_t*) b->dPairs.p + (size_t) r * rowB, rowB, hipMemcpyDeviceToHost, b->stream));
-			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hu_wait(b->stream));
 			const uint16_t* q16 = (const uint16_t*) rowBuf.data(); const uint32_t* q32 = (const uint32_t*) rowBuf.data();
 			auto pairOf = [&](int i) -> uint32_t { return p16 ? (((uint32_t)(q16[i] >> 8) << 16) | (q16[i] & 0xffu)) : q32[i]; };
 			a.clear();
@@ -1560,7 +1626,7 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector
 			HIPCHK(hipMemcpyAsync(b->dSeedId.p + (size_t) r * HU_MAX_SEEDS, ids, keep * 4, hipMemcpyHostToDevice, b->stream));
 			HIPCHK(hipMemcpyAsync(b->dSeedDN.p + (size_t) r * HU_MAX_SEEDS, dn, keep * 4, hipMemcpyHostToDevice, b->stream));
 			HIPCHK(hipMemcpyAsync(b->dParDN.p + (size_t) r * HU_MAX_SEEDS, pn, keep * 4, hipMemcpyHostToDevice, b->stream));
-			HIPCHK(hipStreamSynchronize(b->stream));      /* the staging arrays are locals */
+			HIPCHK(hu_wait(b->stream));      /* the staging arrays are locals */
 		}
 		return HU_OK;
 	}
@@ -1637,7 +1703,7 @@ static int seed_order_libstdcxx(hu_batch* b, const hu_opts* o, const std::vector
 		HIPCHK(hipMemcpyAsync(b->dSeedId.p, b->hSeedId.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
 		HIPCHK(hipMemcpyAsync(b->dSeedDN.p, b->hSeedDN.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
 		HIPCHK(hipMemcpyAsync(b->dParDN.p, hPar.data(), n * HU_MAX_SEEDS * 4, hipMemcpyHostToDevice, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));      /* hPar is a local */
+		HIPCHK(hu_wait(b->stream));      /* hPar is a local */
 	}
 	return HU_OK;
 }
@@ -1675,6 +1741,12 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 		if((rc = b->dRetry.ensure(n + 1)) != HU_OK) return rc;
 		bmin = b->dBmin.p;
 	}
+	b->refFused = refOrder && n > 0 && ref_fused_l0(b, o, b->pair16);
+	if(b->refFused) { /* level 0 of the device sort rides on the scan: the pivots first (four pairs per read straight from the planes) */
+		if((rc = b->dRefPiv.ensure(n * 4)) != HU_OK || (rc = b->dRefL0.ensure(n * (size_t)(d.nNodesPad / 64) * 2)) != HU_OK) return rc;
+		k_ref_pivots<<<(unsigned)((n + 63) / 64), 64, 0, b->stream>>>(d, read_planes(b), b->n, b->dRefPiv.p);
+		HIPCHK(hipGetLastError());
+	}
 	uint32_t* stat = bmin && b->knob.trace ? bmin + n * nBlk : nullptr;      /* block path: reads served, blocks read, candidates, reads passed on */
 	if(stat) HIPCHK(hipMemsetAsync(stat, 0, 64, b->stream));
 	(void) hipGetLastError();
@@ -1686,6 +1758,8 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 			const dim3 grid4(tiles, (d.nNodesPad + 1023) / 1024);
 			if(dOnly && narrow) k_seed_dscan4<uint8_t><<<grid4, 256, (size_t)(b->knob.scan_lds_pad > 0 && b->knob.scan_lds_pad <= 44 ? b->knob.scan_lds_pad : 0) * 1024, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint8_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
 			else if(dOnly) k_seed_dscan4<uint16_t><<<grid4, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, bmin, (const uint2*) b->dTileSpan.p);
+			else if(b->refFused && b->pair16) k_seed_pdist2<uint16_t, true><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p, b->dRefPiv.p, b->dRefL0.p);
+			else if(b->refFused) k_seed_pdist2<uint32_t, true><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p, b->dRefPiv.p, b->dRefL0.p);
 			else if(b->pair16) k_seed_pdist2<uint16_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, (uint16_t*) b->dPairs.p, b->dSlotRead.p);
 			else k_seed_pdist2<uint32_t><<<grid, 256, 0, b->stream>>>(d, b->dRp.p, b->dTileQ.p, b->dTileIns.p, b->dPairs.p, b->dSlotRead.p);
 		}
@@ -1710,7 +1784,7 @@ extern "C" int hu_seed_batch(hu_batch* b, const hu_opts* o) try {
 		HIPCHK(hipGetLastError());
 		if(stat) {
 			uint32_t h[16];
-			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hipMemcpyAsync(h, stat, 64, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hu_wait(b->stream));
 			fprintf(stderr, "[hu] top-k after the distance-only scan: %u of %zu reads on the block path (%.1f blocks, %.1f candidates per read), %u by the exact recomputation; "
 				"%u of them through the general launch\n",
 				h[0] + h[8], n, h[0] + h[8] ? (double) h[1] / (h[0] + h[8]) : 0.0, h[0] + h[8] ? (double) h[2] / (h[0] + h[8]) : 0.0, h[3], h[8]);
@@ -1781,7 +1855,7 @@ extern "C" int hu_seed_batch_given(hu_batch* b, const int32_t* n_seeds, const in
 			k_seed_drop_empty<<<(b->n + 255) / 256, 256, 0, b->stream>>>(b->n, b->dStart.p, b->dEnd.p, b->dSeedCnt.p);
 		}
 		HIPCHK(hipGetLastError());
-		HIPCHK(hipStreamSynchronize(b->stream)); /* pk is a local */
+		HIPCHK(hu_wait(b->stream)); /* pk is a local */
 	}
 	b->seedCap = 1;
 	for(size_t r = 0; r < n; ++r) b->seedCap = std::max(b->seedCap, (int) n_seeds[r]);
@@ -1912,7 +1986,7 @@ static int sync_host_cands(hu_batch* b) {
 	HIPCHK(hipSetDevice(b->db->device));
 	if(n) HIPCHK(hipMemcpyAsync(off.data(), b->dCandOff.p, (n + 1) * 4, hipMemcpyDeviceToHost, b->stream));
 	if(b->nc) HIPCHK(hipMemcpyAsync(b->places.data(), b->dPlaces.p, b->nc * sizeof(HuPlaceRec), hipMemcpyDeviceToHost, b->stream));
-	HIPCHK(hipStreamSynchronize(b->stream));
+	HIPCHK(hu_wait(b->stream));
 	b->candOffs.assign(off.begin(), off.end());      /* [n + 1], all zero for an empty batch */
 	b->hostCands = true;
 	return HU_OK;
@@ -1923,10 +1997,11 @@ static int scan_cands(hu_batch* b, bool withPerm) {
 	if((rc = b->dCandOff.ensure((size_t) b->n + 1)) != HU_OK || (rc = b->dMeta.ensure(4)) != HU_OK) return rc;
 	k_cand_scan<<<1, 1024, 0, b->stream>>>(b->n, b->dCandCnt.p, b->dCandOff.p, withPerm ? b->dPermCnt.p : nullptr, b->dStart.p, b->dEnd.p, b->dMeta.p, b->rMain);
 	HIPCHK(hipGetLastError());
-	int32_t meta[4] = {0, 0, 0, 0};
+	b->hMeta.assign(4, 0);
+	int32_t* meta = b->hMeta.data();
 	HIPCHK(hipMemcpyAsync(meta, b->dMeta.p, 12, hipMemcpyDeviceToHost, b->stream));
 	if(b->rMain) { b->hCandOffAll.resize((size_t) b->n + 1); HIPCHK(hipMemcpyAsync(b->hCandOffAll.data(), b->dCandOff.p, ((size_t) b->n + 1) * 4, hipMemcpyDeviceToHost, b->stream)); }   /* the wide reads' candidates: the placement stage lists them */
-	HIPCHK(hipStreamSynchronize(b->stream));
+	HIPCHK(hu_wait(b->stream));
 	b->nc = (size_t) meta[0]; b->maxGapSites = meta[1]; b->maxBaseSites = meta[2];
 	return HU_OK;
 }
@@ -2086,7 +2161,7 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 					else k_place_blk<12, 2, 3, 0, 2, true, 1><<<grid, 128, 0, b->stream>>>(PL_ARGS, dd);
 					std::vector<long long> hd(nc * 12);
 					HIPCHK(hipMemcpyAsync(hd.data(), dd, nc * 12 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
-					HIPCHK(hipStreamSynchronize(b->stream));
+					HIPCHK(hu_wait(b->stream));
 					double acc[8] = {0}, ae[4] = {0};
 					for(size_t c = 0; c < nc; ++c) { for(int i = 0; i < 8; ++i) acc[i] += (double) hd[c * 8 + i]; for(int i = 0; i < 4; ++i) ae[i] += (double) hd[nc * 8 + c * 4 + i]; }
 					fprintf(stderr, "[place dbg] per candidate (s_memtime ticks): load %.0f tables %.0f sweeps %.0f em %.0f total %.0f | outer %.2f em steps %.2f\n",
@@ -2182,7 +2257,7 @@ extern "C" int hu_finish_batch(hu_batch* b, const hu_opts* o) try {
 				b->fixedRoot ? b->dRootLL.p : nullptr, db->dLlTab, db->dAnnoId, o->max_height, o->only_ml, o->prior, b->placesGiven ? 1 : 0, b->dBest.p, b->knob.sort_seq);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(b->best.data(), b->dBest.p, n * sizeof(hu_place_rec), hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 	}
 	b->hostCands = false;                /* the records changed on the device */
 	b->state = ST_FINISHED;
@@ -2248,7 +2323,7 @@ extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, cons
 		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(ids.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
 	}
-	HIPCHK(hipStreamSynchronize(b->stream)); /* the work batch reads b's codes on its own stream */
+	HIPCHK(hu_wait(b->stream)); /* the work batch reads b's codes on its own stream */
 	for(size_t r = 0; r < n; ++r) {
 		hu_chimera_rec& c = out[r];
 		memset(&c, 0, sizeof(c));
@@ -2309,9 +2384,72 @@ extern "C" int hu_chimera_batch(hu_batch* b, hu_batch* w, const hu_opts* o, cons
 	return HU_OK;
 } catch(...) { return hu_catch_all("hu_chimera_batch"); }
 /* host wall-clock of the last hu_assign_batch: align | seed+estimate+filter | place | finish (ms) */
+extern "C" int hu_batch_refsort_stats(hu_batch* b, int32_t* left_to_host, int32_t* whole_batch_on_host) try {
+	if(!b) return HU_ERR_ARG;
+	if(left_to_host) *left_to_host = b->nRefBail;
+	if(whole_batch_on_host) *whole_batch_on_host = b->refHostAll;
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_batch_refsort_stats"); }
 extern "C" int hu_batch_wall(hu_batch* b, double* ms4) try { if(!b || !ms4) return HU_ERR_ARG; for(int i = 0; i < 4; ++i) ms4[i] = b->wall[i]; return HU_OK; } catch(...) { return hu_catch_all("hu_batch_wall"); }
 
 /* ------------------------------------------------------------------------------ host helpers */
+/* ---- column-window sharding: plan and routing (host only) */
+extern "C" int hu_windows_plan(int64_t cs_len, int n_win, int64_t overlap, hu_window* out) try {
+	if(cs_len < 1 || n_win < 1 || overlap < 0 || !out) { hu_set_error("hu_windows_plan: bad argument"); return HU_ERR_ARG; }
+	/* n_win windows of width w at stride w - overlap cover cs_len: w = ceil((cs_len + (n_win - 1) overlap) / n_win) */
+	const int64_t w = std::min<int64_t>(cs_len, (cs_len + (int64_t)(n_win - 1) * overlap + n_win - 1) / n_win);
+	if(n_win > 1 && w <= overlap) { hu_set_error("hu_windows_plan: %d windows overlapping by %lld columns do not advance over %lld columns", n_win, (long long) overlap, (long long) cs_len); return HU_ERR_ARG; }
+	for(int i = 0; i < n_win; ++i) {
+		int64_t st = (int64_t) i * (w - overlap);
+		if(st + w > cs_len) st = cs_len - w;          /* the last window ends with the consensus */
+		out[i].win_start = st; out[i].win_len = w;
+	}
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_windows_plan"); }
+
+static int route_interval(int n_win, const hu_window* win, int64_t lo, int64_t hi /* 0-based inclusive columns */) {
+	int best = -1; int64_t bestMargin = -1, bestOv = -1; int bestOvW = 0;
+	for(int w = 0; w < n_win; ++w) {
+		const int64_t ws = win[w].win_start, we = ws + win[w].win_len - 1;
+		if(lo >= ws && hi <= we) { const int64_t m = std::min(lo - ws, we - hi); if(m > bestMargin) { bestMargin = m; best = w; } }
+		const int64_t ov = std::min(hi, we) - std::max(lo, ws) + 1;
+		if(ov > bestOv) { bestOv = ov; bestOvW = w; }
+	}
+	return best >= 0 ? best : -1 - bestOvW;         /* -1 - w: no window contains the interval, w overlaps it most */
+}
+extern "C" int hu_route_by_region(int n_win, const hu_window* win, int n, const int32_t* cs_start, const int32_t* cs_end, int32_t* out) try {
+	if(n_win < 1 || !win || n < 0 || (n > 0 && (!cs_start || !cs_end || !out))) { hu_set_error("hu_route_by_region: bad argument"); return HU_ERR_ARG; }
+	for(int r = 0; r < n; ++r) { const int w = route_interval(n_win, win, (int64_t) cs_start[r] - 1, (int64_t) cs_end[r] - 1); out[r] = w >= 0 ? w : -1; }
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_route_by_region"); }
+extern "C" int hu_route_by_seeds(const hu_db* db, int n_win, const hu_window* win, int n, const int32_t* lens, const int32_t* vpaths,
+		const int32_t* mate_lens, const int32_t* mate_vpaths, int32_t* out) try {
+	if(!db || n_win < 1 || !win || n < 0 || (n > 0 && (!lens || !vpaths || !out)) || ((mate_lens == nullptr) != (mate_vpaths == nullptr))) { hu_set_error("hu_route_by_seeds: bad argument"); return HU_ERR_ARG; }
+	const int K = db->dev.K;
+	const std::vector<int32_t>& p2cs = db->prof.p2cs;       /* [K + 1], 1-based CS column of a profile position */
+	auto span = [&](int len, const int32_t* vp, int64_t& lo, int64_t& hi) -> bool { /* profile positions of the read's first and last base, from its seed paths */
+		const bool s5 = vp[0] > 0, s3 = vp[6] > 0;
+		if(!s5 && !s3) return false;
+		const int slack = len / 8 + 4;                      /* indels between the seeds and the read's ends */
+		int ps, pe;
+		if(s5) ps = vp[0] - (vp[2] - 1); else ps = vp[7] - (vp[9] - 1);          /* start - (from - 1) | end - (to - 1) of the 3' seed */
+		if(s3) pe = vp[7] + (len - vp[9]); else pe = vp[1] + (len - vp[3]);       /* end + (len - to) */
+		ps = std::max(1, std::min(K, ps - slack)); pe = std::max(1, std::min(K, pe + slack));
+		if(pe < ps) std::swap(ps, pe);
+		lo = (int64_t) p2cs[ps] - 1; hi = (int64_t) p2cs[pe] - 1;
+		return true;
+	};
+	for(int r = 0; r < n; ++r) {
+		int64_t lo = 0, hi = 0, l2, h2;
+		bool have = span(lens[r], vpaths + (size_t) r * 12, lo, hi);
+		if(mate_lens && span(mate_lens[r], mate_vpaths + (size_t) r * 12, l2, h2)) { if(have) { lo = std::min(lo, l2); hi = std::max(hi, h2); } else { lo = l2; hi = h2; have = true; } }
+		if(!have) { out[r] = 0; continue; }                 /* no seed: any window aligns it; its region decides afterwards */
+		const int w = route_interval(n_win, win, lo, hi);
+		out[r] = w >= 0 ? w : -1 - w;
+	}
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_route_by_seeds"); }
+
 extern "C" int hu_build_align_path(const hu_db* db, int cs_start, int cs_end, const char* cs, int cs_from, int cs_to, int32_t* out6) try {
 	if(!db || !cs || !out6) return HU_ERR_ARG;
 	(void) cs_end; (void) cs_to;
@@ -2350,7 +2488,7 @@ static int64_t format_tsv_impl(hu_batch* b, const char* const* ids, const char* 
 	b->hRows.resize((size_t) b->n * L);
 	if(b->n) {
 		if(hipSetDevice(b->db->device) != hipSuccess || hipMemcpyAsync(b->hRows.data(), b->dRows.p, b->hRows.size(), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
-				hipStreamSynchronize(b->stream) != hipSuccess) { hu_set_error("hu_batch_format_tsv: device copy failed"); return HU_ERR_DEVICE; }
+				hu_wait(b->stream) != hipSuccess) { hu_set_error("hu_batch_format_tsv: device copy failed"); return HU_ERR_DEVICE; }
 	}
 	/* lines are written per read into slices of one buffer, the reads spread over the host pool: pass 1 sizes, pass 2 fills */
 	const size_t n = (size_t) b->n;
@@ -2458,11 +2596,11 @@ extern "C" int hu_batch_get_alignments(hu_batch* b, hu_align_rec* recs, char* al
 	}
 	if(align && !b->fromCodes && b->n) {
 		HIPCHK(hipMemcpyAsync(align, b->dRows.p, (size_t) b->n * d.csLen, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 	}
 	if(trace && !b->fromCodes && trace_stride > 0) {
 		std::vector<char> all(b->hDescs.empty() ? 0 : (size_t)(b->hDescs.back().traceOff + b->hDescs.back().len + d.K + 8));
-		if(!all.empty()) { HIPCHK(hipMemcpyAsync(all.data(), b->dTraces.p, all.size(), hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+		if(!all.empty()) { HIPCHK(hipMemcpyAsync(all.data(), b->dTraces.p, all.size(), hipMemcpyDeviceToHost, b->stream)); HIPCHK(hu_wait(b->stream)); }
 		for(int r = 0; r < b->n; ++r) {
 			const int len = std::min(b->hVit[r].traceLen, trace_stride - 1);
 			memcpy(trace + (size_t) r * trace_stride, all.data() + b->hDescs[r].traceOff, len > 0 ? len : 0);
@@ -2475,7 +2613,7 @@ extern "C" int hu_batch_get_codes(hu_batch* b, int8_t* codes, int32_t* start, in
 	if(!b) return HU_ERR_ARG;
 	if(b->state < ST_ALIGNED) { hu_set_error("no alignments yet"); return HU_ERR_STATE; }
 	HIPCHK(hipSetDevice(b->db->device));
-	if(codes && b->n) { HIPCHK(hipMemcpyAsync(codes, b->dCodes.p, (size_t) b->n * b->db->dev.csLen, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+	if(codes && b->n) { HIPCHK(hipMemcpyAsync(codes, b->dCodes.p, (size_t) b->n * b->db->dev.csLen, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hu_wait(b->stream)); }
 	if(start) memcpy(start, b->hStart.data(), (size_t) b->n * 4);
 	if(end) memcpy(end, b->hEnd.data(), (size_t) b->n * 4);
 	return HU_OK;
@@ -2495,13 +2633,13 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 		k_pairs_of_read<<<(nn + 255) / 256, 256, 0, b->stream>>>(b->db->dev, read_planes(b), read, tmp.p, b->scanWidth ? tmp.p + nn : nullptr);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(v.data(), tmp.p, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 		if(b->scanWidth) { /* the scan leaves the read's LISTED inserts out */
 			std::vector<uint8_t> row((size_t) nn * b->scanWidth);
 			std::vector<uint32_t> want(nn);
 			HIPCHK(hipMemcpyAsync(row.data(), (const uint8_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad * b->scanWidth, row.size(), hipMemcpyDeviceToHost, b->stream));
 			HIPCHK(hipMemcpyAsync(want.data(), tmp.p + nn, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
-			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hu_wait(b->stream));
 			const uint32_t sat = b->scanWidth == 1 ? 255u : 65535u;
 			for(int i = 0; i < nn; ++i) {
 				const uint32_t got = b->scanWidth == 1 ? row[i] : ((const uint16_t*) row.data())[i];
@@ -2512,12 +2650,12 @@ extern "C" int hu_batch_get_pdist(hu_batch* b, int read, int32_t* d, int32_t* N)
 	else if(b->pair16) {
 		std::vector<uint16_t> h(nn);
 		HIPCHK(hipMemcpyAsync(h.data(), (const uint16_t*) b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 2, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 		for(int i = 0; i < nn; ++i) v[i] = ((uint32_t)(h[i] >> 8) << 16) | (h[i] & 0xffu);
 	}
 	else {
 		HIPCHK(hipMemcpyAsync(v.data(), b->dPairs.p + (size_t) read * b->db->dev.nNodesPad, (size_t) nn * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 	}
 	for(int i = 0; i < nn; ++i) { if(d) d[i] = (int32_t)(v[i] >> 16); if(N) N[i] = (int32_t)(v[i] & 0xffffu); }
 	return HU_OK;
@@ -2538,7 +2676,7 @@ extern "C" int hu_batch_get_seeds_strided(hu_batch* b, int32_t* n_seeds, int32_t
 		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(id.data(), b->dSeedId.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(dn.data(), b->dSeedDN.p, n * HU_MAX_SEEDS * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 	}
 	for(size_t r = 0; r < n; ++r) {
 		if(n_seeds) n_seeds[r] = cnt[r];
@@ -2561,7 +2699,7 @@ extern "C" int hu_batch_get_estimates_strided(hu_batch* b, double* ratio, double
 	if(n) {
 		HIPCHK(hipMemcpyAsync(e.data(), b->dEst.p, e.size() * sizeof(HuEstOut), hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipMemcpyAsync(cnt.data(), b->dSeedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hu_wait(b->stream));
 	}
 	for(size_t r = 0; r < n; ++r) for(int s = 0; s < HU_MAX_SEEDS && s < stride; ++s) {
 		const size_t k = r * HU_MAX_SEEDS + s, w = r * (size_t) stride + s; const bool ok = s < cnt[r];

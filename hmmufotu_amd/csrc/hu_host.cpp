@@ -50,7 +50,9 @@ static int cpu_budget_compute() {
 	return (int) best;
 }
 int hu_cpu_budget() { static const int b = cpu_budget_compute(); return b; }
-static std::atomic<int>& helper_tokens() { static std::atomic<int> t{hu_cpu_budget()}; return t; }
+/* helpers of ALL pools together: the budget less one, because every caller of a pool works itself (the other callers — one thread per batch in
+ * flight — sleep on their stream while a batch's host stage runs: hipDeviceScheduleBlockingSync, hu_engine.hip) */
+static std::atomic<int>& helper_tokens() { static std::atomic<int> t{std::max(0, hu_cpu_budget() - 1)}; return t; }
 int hu_helpers_acquire(int want) {
 	if(want <= 0) return 0;
 	std::atomic<int>& t = helper_tokens();
@@ -163,7 +165,7 @@ extern "C" void hu_default_opts(hu_opts* o) {
 	o->only_ml = 0;
 	o->prior = HU_PRIOR_UNIFORM;
 	o->fix_root_loglik = 0;
-	o->seed_order = HU_SEED_ORDER_STABLE;
+	o->seed_order = HU_SEED_ORDER_LIBSTDCXX;      /* the reference's own std::sort order (src/HmmUFOtu_main.cpp:139) */
 	o->ignore_orient = 0;
 }
 

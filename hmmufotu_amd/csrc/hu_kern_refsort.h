@@ -88,6 +88,11 @@ static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * 
 #define HU_RS_LTAB 260                 /* subtiles of a range held in LDS, + 1 */
 #define HU_RS_LHEAD (HU_RS_LTAB * (4 + 4 + 8 + 8 + 2) + 24)     /* = 6784: scanned counts, masks, counts of such a range; the keys follow */
 __host__ __device__ static inline size_t hu_refsort_big(size_t m0) { const size_t NT = (m0 + 63) / 64 + 1, b = (10 * (NT + 2) + 15) & ~(size_t) 15; return b > 36864 ? b : 36864; }
+/* places a range may hold to live in LDS (the kernel's LCAP); a tree with more places than this starts with a streaming level on the pair row */
+template<class PT> __host__ __device__ static inline int hu_refsort_lcap(size_t m0) {
+	const int c = ((((int) hu_refsort_big(m0) - HU_RS_LHEAD) / (int) sizeof(PT)) - 128) & ~63;
+	return c < 16384 - 192 ? c : 16384 - 192;
+}
 static inline size_t hu_refsort_lds(int nNodes) {
 	const size_t m0 = (size_t) nNodes - 1;
 	return HU_RS_FIN * 8 + 64 * 4 + 2 * (hu_refsort_tabcap(m0) / 64) * 4 + hu_refsort_big(m0);
@@ -201,12 +206,30 @@ __device__ inline void rs_emit(uint32_t mLb, uint32_t mRb, int g, bool store, in
 	if(store && (lane & (LPS - 1)) == 0) cnt16[g / LPS] = (uint16_t)((c & 0xffu) | ((c >> 16) << 8));
 }
 
+/* Level 0 of a read whose pair row is a streaming level, prepared BEFORE the scan: the pivot of introsort's first partition is the median of the
+ * elements at places 1, mid and last - 1 (__move_median_to_first), swapped with the element at place 0 — four FIXED nodes, whatever the read.  Their
+ * pairs straight from the bit-planes (pair_exact: what the scan will write for them), one thread per read:
+ *     piv[read * 4] = {pivot pair, the pair that stood at place 0, the place the pivot came from, flags (bit 0: a compared-site count of zero, set by the scan)}
+ * With these the scan classifies every pair it writes (k_seed_pdist2<PT, true>) and k_seed_refsort starts from the masks. */
+__global__ __launch_bounds__(64) void k_ref_pivots(HuDbDev db, HuReadPlanes R, int n, uint32_t* __restrict__ piv) {
+	const int r = blockIdx.x * 64 + threadIdx.x;
+	if(r >= n) return;
+	const int m0 = db.nNodes - 1, lo = 0, hi = m0, mid = lo + (hi - lo) / 2;
+	auto nodeOf = [&](int p) { return p < db.root ? p : p + 1; };
+	const uint32_t ea = pair_exact(db, R, r, nodeOf(lo + 1)), eb = pair_exact(db, R, r, nodeOf(mid)), ec = pair_exact(db, R, r, nodeOf(hi - 1)), ef = pair_exact(db, R, r, nodeOf(lo));
+	const int c = rs_median3(ea, eb, ec);
+	piv[(size_t) r * 4 + 0] = c == 0 ? ea : (c == 1 ? eb : ec);
+	piv[(size_t) r * 4 + 1] = ef;
+	piv[(size_t) r * 4 + 2] = (uint32_t)(c == 0 ? lo + 1 : (c == 1 ? mid : hi - 1));
+	piv[(size_t) r * 4 + 3] = ((ea & 0xffffu) == 0 || (eb & 0xffffu) == 0 || (ec & 0xffffu) == 0 || (ef & 0xffffu) == 0) ? 1u : 0u;
+}
+
 template<class PT>
 __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refsort(HuDbDev db, const PT* __restrict__ pairs, int nReads,
 		const int32_t* __restrict__ rstart, const int32_t* __restrict__ rend, int K,
 		unsigned long long* __restrict__ scratch, size_t wgWords, size_t cap, int rsOff, int tabCap,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
-		int32_t* __restrict__ bail) {
+		int32_t* __restrict__ bail, const uint32_t* __restrict__ l0piv = nullptr, const unsigned long long* __restrict__ l0m = nullptr) {
 	constexpr int EPL = HuRsGeom<PT>::EPL, LPS = HuRsGeom<PT>::LPS, VU = HU_RS_VU;
 	extern __shared__ unsigned char rs_smem[];
 	const int m0 = db.nNodes - 1;
@@ -226,7 +249,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	unsigned long long* const mLs = reinterpret_cast<unsigned long long*>(sufRs + HU_RS_LTAB); unsigned long long* const mRs = mLs + HU_RS_LTAB;
 	uint16_t* const cnt16s = reinterpret_cast<uint16_t*>(mRs + HU_RS_LTAB);
 	PT* const lk = reinterpret_cast<PT*>(big + HU_RS_LHEAD);               /* place p at lk[p - lbase + 64] */
-	const int LCAP = min(16384 - 192, ((((int) hu_refsort_big((size_t) m0) - HU_RS_LHEAD) / (int) sizeof(PT)) - 128) & ~63);
+	const int LCAP = hu_refsort_lcap<PT>((size_t) m0);
 	__shared__ unsigned long long wtot[HU_RS_THREADS / 64];
 	__shared__ uint32_t shP[4];              /* pivot pair, the pair it displaced, next pivot pair */
 	__shared__ int shI[12];                  /* broadcast slots */
@@ -296,50 +319,84 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				off = tabNext;
 				if(off + R > tabCap) { failed = true; why = 2; break; }
 				tabNext = off + R;
-				/* ---- pivot: median of lo + 1, mid, hi - 1 swapped into lo */
-				if(tid == 0) {
-					const int mid = lo + (hi - lo) / 2;
-					const uint32_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
-					const int c = rs_median3(ea, eb, ec);
-					const int w = c == 0 ? lo + 1 : (c == 1 ? mid : hi - 1);
-					const uint32_t ew = c == 0 ? ea : (c == 1 ? eb : ec);
-					shP[0] = ew; shP[1] = ef; shI[0] = w;
-					if(inLds) { lk[lo - lbase + 64] = HuPair<PT>::pack(ew); lk[w - lbase + 64] = HuPair<PT>::pack(ef); }
-					else if(!level0) { PT* s = const_cast<PT*>(src); s[lo] = HuPair<PT>::pack(ew); s[w] = HuPair<PT>::pack(ef); }
+				const bool fusedL0 = l0m != nullptr && level0 && level == 0 && !inLds;
+				if(fusedL0) {
+					/* ---- level 0 from the scan: pivot, swap and both stopper masks are there (k_ref_pivots, k_seed_pdist2<PT, true>).  The masks are in NODE order:
+					 * place p is node p before the root and node p + 1 from it on, so from the root's subtile on a word of the place order is a funnel shift of
+					 * two words of the node order.  Place lo holds the pivot (not part of the partition), place w the element that stood at lo. */
+					pivP = l0piv[(size_t) read * 4]; const uint32_t ef = l0piv[(size_t) read * 4 + 1];
+					wAbs = (int) l0piv[(size_t) read * 4 + 2]; nan |= (l0piv[(size_t) read * 4 + 3] & 1u) != 0;
+					pA = lo; vA = pivP; pB = wAbs; vB = ef;
+					RS_T(1);
+					const int npw = db.nNodesPad >> 6, tr = db.root >> 6;
+					const unsigned long long* nm = l0m + (size_t) read * npw * 2;
+					const unsigned long long below = rs_lane_lt(db.root & 63);
+					const bool efL = !rs_ltp(ef, pivP), efR = !rs_ltp(pivP, ef);
+					for(int t = tid; t < NTl; t += HU_RS_THREADS) {
+						const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t) t);
+						unsigned long long mL = a.x, mR = a.y;
+						if(t >= tr) {
+							ulonglong2 c = make_ulonglong2(0ull, 0ull);
+							if(t + 1 < npw) c = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t)(t + 1));
+							const unsigned long long sL = (a.x >> 1) | (c.x << 63), sR = (a.y >> 1) | (c.y << 63);
+							mL = t > tr ? sL : ((a.x & below) | (sL & ~below));
+							mR = t > tr ? sR : ((a.y & below) | (sR & ~below));
+						}
+						/* valid places of this subtile: o0 <= 64 t + i < qEnd */
+						const int v0 = max(o0 - 64 * t, 0), v1 = min(qEnd - 64 * t, 64);
+						const unsigned long long vm = (v1 >= 64 ? ~0ull : rs_lane_lt(max(v1, 0))) & ~rs_lane_lt(min(v0, 63)) & (v0 >= 64 ? 0ull : ~0ull);
+						mL &= vm; mR &= vm;
+						if((wAbs >> 6) == t && wAbs > lo) { const unsigned long long bit = 1ull << (wAbs & 63); mL = efL ? (mL | bit) : (mL & ~bit); mR = efR ? (mR | bit) : (mR & ~bit); }
+						gML[off + t] = mL; gMR[off + t] = mR;
+						cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
+					}
 				}
-				__threadfence_block();
-				__syncthreads();
-				RS_T(1);
-				pivP = shP[0]; wAbs = shI[0];
-				if(level0) { pA = lo; vA = pivP; pB = wAbs; vB = shP[1]; }
-				/* ---- pass A: stopper masks and counts per subtile */
-				auto passA = [&](auto l0) {
-					constexpr bool L0 = decltype(l0)::value;
-					unsigned char* bL = reinterpret_cast<unsigned char*>(gML + off); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + off);
-					for(int gb = 0; gb < gEnd; gb += HU_RS_THREADS * VU) {
-						uint32_t k[VU][EPL];
+				else {
+				/* ---- pivot: median of lo + 1, mid, hi - 1 swapped into lo */
+					if(tid == 0) {
+						const int mid = lo + (hi - lo) / 2;
+						const uint32_t ea = E(lo + 1), eb = E(mid), ec = E(hi - 1), ef = E(lo);
+						const int c = rs_median3(ea, eb, ec);
+						const int w = c == 0 ? lo + 1 : (c == 1 ? mid : hi - 1);
+						const uint32_t ew = c == 0 ? ea : (c == 1 ? eb : ec);
+						shP[0] = ew; shP[1] = ef; shI[0] = w;
+						if(inLds) { lk[lo - lbase + 64] = HuPair<PT>::pack(ew); lk[w - lbase + 64] = HuPair<PT>::pack(ef); }
+						else if(!level0) { PT* s = const_cast<PT*>(src); s[lo] = HuPair<PT>::pack(ew); s[w] = HuPair<PT>::pack(ef); }
+					}
+					__threadfence_block();
+					__syncthreads();
+					RS_T(1);
+					pivP = shP[0]; wAbs = shI[0];
+					if(level0) { pA = lo; vA = pivP; pB = wAbs; vB = shP[1]; }
+					/* ---- pass A: stopper masks and counts per subtile */
+					auto passA = [&](auto l0) {
+						constexpr bool L0 = decltype(l0)::value;
+						unsigned char* bL = reinterpret_cast<unsigned char*>(gML + off); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + off);
+						for(int gb = 0; gb < gEnd; gb += HU_RS_THREADS * VU) {
+							uint32_t k[VU][EPL];
 #pragma unroll
-						for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd - 1) * EPL, k[u]);
+							for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd - 1) * EPL, k[u]);
 #pragma unroll
-						for(int u = 0; u < VU; ++u) {
-							const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
-							const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
-							if(L0) rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, vb, nan);
-							uint32_t mLb, mRb;
-							rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
-							rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
+							for(int u = 0; u < VU; ++u) {
+								const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
+								const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
+								if(L0) rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, vb, nan);
+								uint32_t mLb, mRb;
+								rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+								rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
+							}
+						}
+					};
+					if(inLds) {
+						for(int qb = wave * 64; qb < NTl * 64; qb += HU_RS_THREADS) {
+							const int q = qb + lane, t = qb >> 6; const bool valid = q >= o0 && q < qEnd;
+							const uint32_t e = valid ? HuPair<PT>::canon(lk[qBase + q - lbase + 64]) : 0u;
+							const unsigned long long mL = __ballot(valid && !rs_ltp(e, pivP)), mR = __ballot(valid && !rs_ltp(pivP, e));
+							if(lane == 0) { cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8)); mLs[t] = mL; mRs[t] = mR; gML[off + t] = mL; gMR[off + t] = mR; }
 						}
 					}
-				};
-				if(inLds) {
-					for(int qb = wave * 64; qb < NTl * 64; qb += HU_RS_THREADS) {
-						const int q = qb + lane, t = qb >> 6; const bool valid = q >= o0 && q < qEnd;
-						const uint32_t e = valid ? HuPair<PT>::canon(lk[qBase + q - lbase + 64]) : 0u;
-						const unsigned long long mL = __ballot(valid && !rs_ltp(e, pivP)), mR = __ballot(valid && !rs_ltp(pivP, e));
-						if(lane == 0) { cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8)); mLs[t] = mL; mRs[t] = mR; gML[off + t] = mL; gMR[off + t] = mR; }
-					}
+					else if(level0) passA(std::true_type{}); else passA(std::false_type{});
 				}
-				else if(level0) passA(std::true_type{}); else passA(std::false_type{});
 				if(__syncthreads_or(nan ? 1 : 0)) { failed = true; why = 3; break; }
 				RS_T(2);
 			}

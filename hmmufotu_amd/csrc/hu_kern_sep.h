@@ -103,9 +103,16 @@ __device__ inline uint32_t dpp_min_full(uint32_t v) {
 	const uint32_t o = (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xf, 0xf, true);
 	return o < v ? o : v;
 }
-template<class PT>
+/* L0 (the reference's seed order on a tree whose pair row is a streaming level of k_seed_refsort): the scan also CLASSIFIES every pair it writes
+ * against the pivot of introsort's first partition of that read — the median of the elements at places 1, mid and last - 1 of the row, three
+ * FIXED nodes whose pairs k_ref_pivots computes before the scan (hu_kern_refsort.h) — and leaves the two stopper masks of level 0 in node order,
+ * one bit per node: bit (node & 63) of l0m[(read * np / 64 + node / 64) * 2 + {0: !(e < pivot), 1: !(pivot < e)}].  The sort kernel then starts
+ * from 16 bytes per 64 nodes instead of a counting pass over the 128 (256) bytes of their pairs: that pass was a quarter of its time.
+ * A compared-site count of zero (dist = 0 / 0, std::sort undefined) is flagged in piv[read * 4 + 3]. */
+template<class PT, bool L0 = false>
 __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t* __restrict__ rp,
-		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead) {
+		const int32_t* __restrict__ tileQ, const int32_t* __restrict__ tileIns, PT* __restrict__ pairs, const int32_t* __restrict__ slotRead,
+		uint32_t* __restrict__ piv = nullptr, unsigned long long* __restrict__ l0m = nullptr) {
 	constexpr int T = HU_READ_TILE;
 	__shared__ uint32_t acc[T][256];
 	const int tile = blockIdx.x, tid = threadIdx.x;
@@ -148,10 +155,24 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 			atomicAdd(&acc[t][tid], add);     /* own slot: no contention, a plain ds_add_u32 */
 		}
 	}
+	const bool counts = L0 && node < db.nNodes && node != db.root;      /* a place of the sort: every node but the root */
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
-		if(read >= 0) pairs[(size_t) read * np + node] = HuPair<PT>::pack(((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u));
+		if(read >= 0) {
+			const uint32_t v = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
+			pairs[(size_t) read * np + node] = HuPair<PT>::pack(v);
+			if(L0) { /* the pivot is wave-uniform (scalar); dist(e) < dist(pivot) <=> d_e N_p < d_p N_e, exact in 32 bits */
+				const uint32_t pp = piv[(size_t) read * 4];
+				const uint32_t a = (v >> 16) * (pp & 0xffffu), bb = (pp >> 16) * (v & 0xffffu);
+				const unsigned long long mL = __ballot(counts && a >= bb), mR = __ballot(counts && bb >= a), mZ = __ballot(counts && (v & 0xffffu) == 0u);
+				if((tid & 63) == 0) {
+					unsigned long long* o = l0m + ((size_t) read * (np / 64) + (size_t)(node >> 6)) * 2;
+					*reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(mL, mR);
+					if(mZ) atomicOr(&piv[(size_t) read * 4 + 3], 1u);
+				}
+			}
+		}
 	}
 }
 

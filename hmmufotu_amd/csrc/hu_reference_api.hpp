@@ -124,6 +124,33 @@ public:
 		for(int i = 0; i < n; ++i) locs.push_back(PTLoc{start, end, ids[i], (double) d[i] / N[i]});
 		return locs;
 	}
+	/* getSeed's WHOLE vector (src/HmmUFOtu_main.cpp:127-152): a PTLoc for every node but the root under maxHeight, from the device's (d, N) of every node
+	 * (hu_batch_get_pdist), ordered by LITERALLY the reference's call — std::sort on dist alone, in the caller's own libstdc++ — and cut by maxDiff as
+	 * there (a branch that only runs when no seed exceeds the bound).  ~n_nodes PTLocs per read: for callers that walk the list beyond
+	 * HU_MAX_SEEDS or apply -d themselves; the fast path keeps the first max_nseed places on the device (seedMany).  A read that shares no column with
+	 * some node (dist = 0 / 0) takes (dist, node id) with NaN last: std::sort is undefined there and the reference asserts nothing. */
+	std::vector<PTLoc> seedAll(const DigitalSeq& seq, int start, int end, double maxDiff, double maxHeight) {
+		load(seq, start, end);
+		hu_opts o = opts_; o.max_height = maxHeight; o.max_nseed = 1;
+		check(hu_seed_batch(b_, &o));
+		const int n = nNodes();
+		std::vector<int32_t> d(n), N(n), par(n); std::vector<double> bl(n), h(n);
+		check(hu_batch_get_pdist(b_, 0, d.data(), N.data()));
+		check(hu_db_get_tree(db_, par.data(), bl.data(), nullptr, h.data()));
+		std::vector<PTLoc> locs;
+		bool nan = false;
+		for(int i = 0; i < n; ++i) if(par[i] >= 0 && h[i] <= maxHeight) { locs.push_back(PTLoc{start, end, i, (double) d[i] / N[i]}); nan |= N[i] == 0; }
+		if(locs.empty()) return locs;
+		if(!nan) std::sort(locs.begin(), locs.end());
+		else std::sort(locs.begin(), locs.end(), [](const PTLoc& a, const PTLoc& b) { const bool na = std::isnan(a.dist), nb = std::isnan(b.dist); return na != nb ? nb : (!na && a.dist != b.dist ? a.dist < b.dist : a.id < b.id); });
+		const double bestDist = locs[0].dist, worstDist = locs[locs.size() - 1].dist;
+		if(worstDist < bestDist + maxDiff) {
+			std::vector<PTLoc>::iterator goodSeed;
+			for(goodSeed = locs.begin(); goodSeed != locs.end(); ++goodSeed) if(goodSeed->dist - bestDist > maxDiff) break;
+			locs.erase(goodSeed, locs.end());
+		}
+		return locs;
+	}
 	std::vector<PTPlacement> estimateMany(const DigitalSeq& seq, const std::vector<PTLoc>& locs, const std::string& method) {
 		if(method != "unweighted" && method != "weighted") throw std::invalid_argument("Unknown branch length estimating method '" + method + "'");   /* src/PhyloTreeUnrooted.cpp:1010-1016 */
 		std::vector<PTPlacement> places;
@@ -217,9 +244,10 @@ private:
 typedef Engine PerRead;   /* the name of rounds 1-2 */
 
 /* ---- the free functions of src/HmmUFOtu_main.h, `Engine&` standing for `const PTUnrooted&` ---- */
-/* :86 — every seed the engine holds for the read (<= HU_MAX_SEEDS, ascending by (dist, node id)); the caller truncates to maxNSeed */
-inline std::vector<PTLoc> getSeed(Engine& ptu, const DigitalSeq& seq, int start, int end, double maxDiff, double maxHeight) {
-	return ptu.seedMany(seq, start, end, maxDiff, maxHeight);
+/* :86 — the first HU_MAX_SEEDS places of the reference's sorted vector (std::sort on dist alone, reproduced on the device); the caller truncates to
+ * maxNSeed (src/hmmufotu.cpp:646-647).  whole = true: the reference's WHOLE vector, every eligible node (Engine::seedAll; host-side sort of ~n_nodes PTLocs) */
+inline std::vector<PTLoc> getSeed(Engine& ptu, const DigitalSeq& seq, int start, int end, double maxDiff, double maxHeight, bool whole = false) {
+	return whole ? ptu.seedAll(seq, start, end, maxDiff, maxHeight) : ptu.seedMany(seq, start, end, maxDiff, maxHeight);
 }
 /* :91 */
 inline std::vector<PTPlacement> estimateSeq(Engine& ptu, const DigitalSeq& seq, const std::vector<PTLoc>& locs, const std::string& method) {

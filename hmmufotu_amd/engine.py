@@ -61,6 +61,7 @@ class PlaceRec(C.Structure):
                 ("root_loglik", C.c_double)]
 
 
+READ_OK, READ_INVALID, READ_CHIMERA, READ_OUT_OF_WINDOW = 1, 0, 2, 16     # hu_align_rec.status (HU_READ_*)
 ALIGN_DTYPE = np.dtype([("seq_start", "i4"), ("seq_end", "i4"), ("hmm_start", "i4"), ("hmm_end", "i4"), ("cs_start", "i4"),
                         ("cs_end", "i4"), ("status", "i4"), ("used_full", "i4"), ("cost", "f8")])
 PLACE_DTYPE = np.dtype([("c_node", "i4"), ("p_node", "i4"), ("a_node", "i4"), ("n_cand", "i4"), ("wuv", "f8"), ("ratio", "f8"),
@@ -326,9 +327,10 @@ class Database:
         return cls.from_arrays(db.hmm, db.parent, db.blen, db.seq, db.up, db.down, db.height, md, db.anno_id, db.anno_dist, device=device)
 
     @classmethod
-    def load(cls, hmm_path: str, ptu_path: str, device=0):
+    def load(cls, hmm_path: str, ptu_path: str, device=0, win_start=0, win_len=0):
+        """hu_db_load / hu_db_load_window (win_len > 0: only the messages of the CS columns [win_start, win_start + win_len) stay on the device)"""
         h = C.c_void_p()
-        _chk(load_library().hu_db_load(hmm_path.encode(), ptu_path.encode(), C.c_int(device), C.byref(h)))
+        _chk(load_library().hu_db_load_window(hmm_path.encode(), ptu_path.encode(), C.c_int(device), C.c_int64(win_start), C.c_int64(win_len), C.byref(h)))
         return cls(h)
 
     def model_pr(self, t):
@@ -361,6 +363,106 @@ class Database:
             self.close()
         except Exception:
             pass
+
+
+class Window(C.Structure):
+    _fields_ = [("win_start", C.c_int64), ("win_len", C.c_int64)]
+
+
+def windows_plan(cs_len: int, n_win: int, overlap: int):
+    """hu_windows_plan: n_win column windows [(start, len)] covering [0, cs_len), neighbours overlapping by `overlap` columns"""
+    w = (Window * n_win)()
+    _chk(load_library().hu_windows_plan(C.c_int64(cs_len), C.c_int(n_win), C.c_int64(overlap), w))
+    return [(int(x.win_start), int(x.win_len)) for x in w]
+
+
+class WindowedDatabase:
+    """Column-window sharding (last row; include/hmmufotu_amd.h): one database held as W column windows — one hu_db per window,
+    usually one per device — for message sets beyond one GPU's HBM.  PTUnrooted::load keeps every column of every edge (src/PhyloTreeUnrooted.cpp:496-535);
+    here a read is routed to the window that holds the columns its seeds point at, and re-routed ONCE by its exact region when it comes back
+    HU_READ_OUT_OF_WINDOW.  The windows never exchange anything."""
+
+    def __init__(self, dbs, windows):
+        assert len(dbs) == len(windows) >= 1
+        self.dbs = list(dbs); self.windows = [(int(a), int(b)) for a, b in windows]
+        self._w = (Window * len(windows))(*[Window(a, b) for a, b in self.windows])
+        self.last = {}
+
+    @classmethod
+    def from_synth(cls, db, n_win, overlap, devices=None):
+        md = model_desc(db.model.type_id, db.model.pi, db.model.par, db.dg_r if db.dg_k > 0 else None)
+        wins = windows_plan(db.cs_len, n_win, overlap)
+        dbs = [Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, db.up[:, a:a + l], db.down[:, a:a + l], db.height, md, db.anno_id, db.anno_dist,
+                                    win_start=a, win_len=l, device=(devices[i] if devices else 0)) for i, (a, l) in enumerate(wins)]
+        return cls(dbs, wins)
+
+    @classmethod
+    def load(cls, hmm_path, ptu_path, cs_len, n_win, overlap, devices=None):
+        wins = windows_plan(cs_len, n_win, overlap)
+        return cls([Database.load(hmm_path, ptu_path, devices[i] if devices else 0, a, l) for i, (a, l) in enumerate(wins)], wins)
+
+    def route_by_seeds(self, lens, vpaths, mate_lens=None, mvpaths=None):
+        n = len(lens)
+        lens = np.ascontiguousarray(lens, np.int32); vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 12)
+        ml = np.ascontiguousarray(mate_lens, np.int32) if mate_lens is not None else None
+        mv = np.ascontiguousarray(mvpaths, np.int32).reshape(n, 12) if mvpaths is not None else None
+        out = np.zeros(n, np.int32)
+        _chk(load_library().hu_route_by_seeds(self.dbs[0].h, C.c_int(len(self.windows)), self._w, C.c_int(n), _p(lens, C.c_int32), _p(vp, C.c_int32),
+                                              _p(ml, C.c_int32) if ml is not None else None, _p(mv, C.c_int32) if mv is not None else None, _p(out, C.c_int32)))
+        return out
+
+    def route_by_region(self, cs_start, cs_end):
+        s_ = np.ascontiguousarray(cs_start, np.int32); e_ = np.ascontiguousarray(cs_end, np.int32)
+        out = np.zeros(len(s_), np.int32)
+        _chk(load_library().hu_route_by_region(C.c_int(len(self.windows)), self._w, C.c_int(len(s_)), _p(s_, C.c_int32), _p(e_, C.c_int32), _p(out, C.c_int32)))
+        return out
+
+    def assign(self, reads, vpaths, opts, mates=None, mvpaths=None, first_window=None, ids=None, annos=None):
+        """The whole per-read task over the windows: route by seeds, one batch per window, re-route the reads that came back out of their window by
+        their region, merge in read order.  Returns (placements [n], alignment records [n]); self.last holds the routing (window per read, reads
+        re-routed, reads no window holds) and, with ids, the TSV lines per read.  first_window: a routing to use instead of the seeds' (tests)."""
+        n = len(reads)
+        vp = np.ascontiguousarray(vpaths, np.int32).reshape(n, 2, 6)
+        mvp = np.ascontiguousarray(mvpaths, np.int32).reshape(n, 2, 6) if mvpaths is not None else None
+        win = np.asarray(first_window, np.int32) if first_window is not None else \
+            self.route_by_seeds([len(r) for r in reads], vp, [len(r) for r in mates] if mates is not None else None, mvp)
+        best = np.zeros(n, PLACE_DTYPE); recs = np.zeros(n, ALIGN_DTYPE); lines = [None] * n
+        final = win.copy(); rerouted = np.zeros(n, bool)
+
+        def run(w, idx):
+            B = Batch(self.dbs[w], len(idx))
+            B.set_reads([reads[i] for i in idx], vp[idx], [mates[i] for i in idx] if mates is not None else None, mvp[idx] if mvp is not None else None)
+            B.assign(opts)
+            b_, r_ = B.placements().copy(), B.alignments(want_align=False)["recs"].copy()
+            t_ = None
+            if ids is not None:     # a read that is not placed has no line: keyed by the read id at the head of each line
+                txt = B.format_tsv([ids[i] for i in idx], None, annos).strip("\n")
+                t_ = {l.split("\t", 1)[0]: l for l in txt.split("\n")} if txt else {}
+            B.close()
+            return b_, r_, t_
+
+        def take(idx, b_, r_, t_):
+            best[idx] = b_; recs[idx] = r_
+            if t_ is not None:
+                for i in idx:
+                    lines[i] = t_.get(ids[i])
+        for w in range(len(self.dbs)):
+            idx = np.nonzero(win == w)[0]
+            if len(idx):
+                take(idx, *run(w, idx))
+        out = np.nonzero(recs["status"] == READ_OUT_OF_WINDOW)[0]
+        if len(out):
+            w2 = self.route_by_region(recs["cs_start"][out], recs["cs_end"][out])
+            for w in range(len(self.dbs)):
+                idx = out[(w2 == w) & (win[out] != w)]
+                if len(idx):
+                    take(idx, *run(w, idx)); final[idx] = w; rerouted[idx] = True
+        self.last = dict(first_window=win, window=final, rerouted=rerouted, unplaceable=(recs["status"] == READ_OUT_OF_WINDOW), lines=lines)
+        return best, recs
+
+    def close(self):
+        for d in self.dbs:
+            d.close()
 
 
 class Batch:
@@ -426,6 +528,12 @@ class Batch:
     def set_knob(self, name: str, value: int = 1):
         """hu_batch_set_knob: pick an alternative kernel / diagnostic for this batch (tests force every kernel path with it)."""
         _chk(load_library().hu_batch_set_knob(self.h, name.encode(), C.c_int(int(value))))
+
+    def refsort_stats(self):
+        """(reads of the last seed stage in the reference's order that the device sort left to the host, whole batch on the host path?)"""
+        a = C.c_int32(0); w = C.c_int32(0)
+        _chk(load_library().hu_batch_refsort_stats(self.h, C.byref(a), C.byref(w)))
+        return int(a.value), bool(w.value)
 
     def wall(self):
         ms = np.zeros(4)

@@ -117,11 +117,17 @@ typedef struct {
 	                           * ranked by it (q-values, --ML sort, chimera log-odds all become informative).  A documented
 	                           * deviation from the reference, off by default                                          */
 	int32_t seed_order;       /* which of the nodes that TIE at the cut-off distance getSeed keeps, and in which order the seeds reach estimateSeq:
-	                           * HU_SEED_ORDER_STABLE (0, default): ascending (dist, node id) — deterministic, selected on the device;
-	                           * HU_SEED_ORDER_LIBSTDCXX (1): the reference's own — the first max_nseed elements of std::sort(locs) on dist ALONE
-	                           * (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647), i.e. the tie permutation of libstdc++'s introsort over
-	                           * all ~n_nodes PTLocs in node order, reproduced on the host from the device's (d, N) of every node (a mode for
-	                           * exact agreement with the reference binary: several times slower than the default) */
+	                           * HU_SEED_ORDER_LIBSTDCXX (1, the default of hu_default_opts): the reference's own — the first max_nseed elements of
+	                           * std::sort(locs) on dist ALONE (src/HmmUFOtu_main.cpp:139, src/hmmufotu.cpp:646-647), i.e. the tie permutation of
+	                           * libstdc++'s introsort over all ~n_nodes PTLocs in node order.  Reproduced ON THE DEVICE (full (d, N) pair scan +
+	                           * k_seed_refsort: data-parallel Hoare partitions restricted to the ranges that reach the first max_nseed places).
+	                           * The host restatement (hu_sort_prefix_libstdcxx) finishes only the reads the kernel lists: a row that reaches
+	                           * introsort's heap-sort branch, level tables that overflow, and every read of a tree whose sort tables exceed
+	                           * 150 KB of LDS (above ~600 k nodes; reported once on stderr and in hu_batch_refsort_stats).  A read with a NaN
+	                           * distance (a node sharing no column with it: std::sort is undefined) takes (dist, node id) with NaN last.
+	                           * HU_SEED_ORDER_STABLE (0): ascending (dist, node id) — independent of any library's tie permutation, selected by
+	                           * the distance-only scan + top-k; ~25 % faster, differs from a g++-built reference wherever nodes tie at the
+	                           * cut-off distance.  NOTE: a zero-filled hu_opts selects STABLE; call hu_default_opts. */
 } hu_opts;
 enum { HU_SEED_ORDER_STABLE = 0, HU_SEED_ORDER_LIBSTDCXX = 1 };
 
@@ -154,6 +160,9 @@ int hu_db_create(const hu_profile_desc* prof, const hu_tree_desc* tree, const hu
 		int device, hu_db** out);
 /* same from the reference's on-disk formats (.hmm text, .ptu binary) */
 int hu_db_load(const char* hmm_path, const char* ptu_path, int device, hu_db** out);
+/* the same keeping only the messages of the CS columns [win_start, win_start + win_len) on the device (win_len 0: all) — one shard of a database
+ * held as column windows, see "column-window sharding" below */
+int hu_db_load_window(const char* hmm_path, const char* ptu_path, int device, int64_t win_start, int64_t win_len, hu_db** out);
 /* The reference's own TEXT forms, from memory — for a caller that holds loaded reference objects: BandedHMMP7 keeps its cost
  * matrices private and has no accessors for them (src/BandedHMMP7.h:497-548), but operator<<(ostream&, const BandedHMMP7&)
  * (src/BandedHMMP7.cpp:324-378) writes exactly what hu_profile_desc wants; likewise DNASubModel::write (src/GTR.cpp:83-104 and
@@ -392,6 +401,26 @@ const char* hu_tsv_header_chimera(void);
 /* the header line of the assignment file (src/hmmufotu.cpp:592-594) */
 const char* hu_tsv_header(void);
 
+/* ---- column-window sharding (last row) -------------------------------
+ * PTUnrooted::load keeps the messages of EVERY column of every directed edge in one address space (src/PhyloTreeUnrooted.cpp:496-535); a database whose
+ * messages exceed one GPU's HBM (72 bytes per node and column once packed: 28.8 MB per column at 399,999 nodes) is held as W column WINDOWS instead,
+ * one hu_db per window (hu_db_load_window, or hu_tree_desc.win_*), usually one per device.  A read's placement touches only the columns of its
+ * alignment region, so it runs unchanged on any window that holds the region; the seed scan runs on the node sequences, which every window holds whole.
+ * Reads are ROUTED by where their seeds say they lie, before the alignment; a read that comes back HU_READ_OUT_OF_WINDOW (aligned, region known
+ * exactly, not placed) is routed once more by its region.  No window exchanges anything with another: still no data-path collective.
+ *   hu_windows_plan      W windows of equal width that cover [0, cs_len) and overlap their neighbours by `overlap` columns (choose it >= the widest
+ *                        alignment region to be expected, so that every region lies inside at least one window)
+ *   hu_route_by_seeds    per read the window to try first: the CS interval the read is expected to cover — from the profile positions of its
+ *                        seed paths (vpaths [n][2][6] as for hu_batch_set_reads), extended by the bases left and right of the seeds; the window
+ *                        that contains it with the widest margin, else the one that overlaps it most.  A read without a seed goes to window 0.
+ *                        lens [n]: bases of each read (of the merged pair: pass the forward read's and the mate's through lens / mate_lens)
+ *   hu_route_by_region   the same from exact 1-based inclusive CS regions (hu_align_rec.cs_start / cs_end); -1 when no window contains the region */
+typedef struct { int64_t win_start, win_len; } hu_window;
+int hu_windows_plan(int64_t cs_len, int n_win, int64_t overlap, hu_window* out /* [n_win] */);
+int hu_route_by_seeds(const hu_db* db, int n_win, const hu_window* win, int n, const int32_t* lens, const int32_t* vpaths,
+		const int32_t* mate_lens, const int32_t* mate_vpaths, int32_t* window_of_read /* [n] */);
+int hu_route_by_region(int n_win, const hu_window* win, int n, const int32_t* cs_start, const int32_t* cs_end, int32_t* window_of_read /* [n] */);
+
 /* ---- measurement ------------------------------------------------------------------------
  * per-kernel device time of the LAST call of each stage, measured with HIP events on the
  * batch's stream: ms[HU_T_*]; and the algorithmic work it covered */
@@ -402,6 +431,10 @@ int hu_batch_timings(hu_batch* b, float* ms /* [HU_T_COUNT] */);
 int hu_batch_profile(hu_batch* b, int enable);
 /* host wall-clock (ms) of the last hu_assign_batch: align | seed+estimate+filter | place | finish */
 int hu_batch_wall(hu_batch* b, double* ms4);
+/* the last hu_seed_batch under HU_SEED_ORDER_LIBSTDCXX: reads the device sort (k_seed_refsort) handed to the host restatement (heap-sort branch, table
+ * overflow; the NaN-distance reads of a database with partial sequences are counted too), and whether the WHOLE batch took the host path (a tree beyond
+ * the kernel's LDS tables, ~600 k nodes: said once on stderr) — so that a rate quoted for the mode is never silently a host-path rate */
+int hu_batch_refsort_stats(hu_batch* b, int32_t* left_to_host, int32_t* whole_batch_on_host);
 
 #ifdef __cplusplus
 }

@@ -415,7 +415,7 @@ struct AssignOpts {
 	int weighted = 0;
 	int onlyML = 0;
 	int prior = 0;
-	int tieMode = TIE_STABLE;
+	int tieMode = TIE_LIBSTDCXX;       /* the reference's: literal std::sort on dist alone */
 	int fixRootLoglik = 0;
 	double tieTol = 0;     /* > 0: argmax4_tol in estimateSeq (test aid, see there); 0 = the reference's rule */
 };

@@ -42,7 +42,8 @@ class OrcOpts(C.Structure):
 
 
 def default_opts(**kw):
-    o = OrcOpts(float("inf"), float("inf"), 20.0, 50, 0, 0, 0, 0, 0, 0.0)
+    """the reference's defaults; tieMode = 1 (TIE_LIBSTDCXX: getSeed's literal std::sort on dist alone, src/HmmUFOtu_main.cpp:139)"""
+    o = OrcOpts(float("inf"), float("inf"), 20.0, 50, 0, 0, 0, 1, 0, 0.0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -142,7 +143,7 @@ class Tree:
         self.row_of = None if row_of is None else np.ascontiguousarray(row_of, np.int32)
         lib().orc_tree_set_rows(self.h, _p(self.row_of, C.c_int) if self.row_of is not None else None)
 
-    def get_seed(self, seq, start, end, max_diff=float("inf"), max_height=float("inf"), tie=0, max_n=50):
+    def get_seed(self, seq, start, end, max_diff=float("inf"), max_height=float("inf"), tie=1, max_n=50):
         seq = np.ascontiguousarray(seq, np.int8)
         ids = np.zeros(max(max_n, 1), np.int64); d = np.zeros_like(ids); N = np.zeros_like(ids); dist = np.zeros(len(ids))
         n = lib().orc_get_seed(self.h, _p(seq, C.c_int8), C.c_int(start), C.c_int(end), C.c_double(max_diff), C.c_double(max_height),
@@ -269,7 +270,7 @@ def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, op
     list (mode 2; reads with equal lists give estimateSeq the same inputs in the same order and cannot differ).
     phase1: a mode-1 result to reuse; tree2: the tree for the mode-2 runs (e.g. one holding only the seed nodes' message rows).
     Returns (per_read dict of arrays, summary dict)."""
-    opts = opts or default_opts()
+    opts = opts or default_opts(tieMode=0)       # phase 1's own list (seed_ids) is the (dist, node id) one; lib_ids is the literal std::sort's
     n = len(reads)
     p1 = phase1 if phase1 is not None else pipeline_batch(hmm, tree, reads, vpaths, mates, mvpaths, opts, threads, mode=1, want_lib=True)
     ok = p1["aln_ints"][:, 7] == 1
@@ -311,7 +312,7 @@ def tie_report(hmm: Hmm, tree: Tree, reads, vpaths, mates=None, mvpaths=None, op
                 final_a_node_differs=int(((pick_mask & 4) != 0).sum()), final_pick_differs=int(pick.sum()),
                 final_pick_diffs_traced_to_a_cutoff_tie=int(via_tie[pick].sum()))
     return dict(order_differs=order_diff, seeds_only_in_libstdcxx=only_lib, filtered_set_differs=filt_diff, pick_mask=pick_mask,
-                picks=picks, via_cutoff_seed=via_tie, phase1=p1, lib_idx=idx, lib_run=rl), summ
+                picks=picks, via_cutoff_seed=via_tie, phase1=p1, lib_idx=idx, lib_run=rl, stable_run=rs if len(idx) else None), summ
 
 
 def std_sort_prefix(dist, k):

@@ -84,7 +84,7 @@ if os.path.exists(p1):
 for x in ("fetch", "write", "sq", "valu"):
     shutil.copy(os.path.join(d, x + "_engine.csv"), "profiles/%s_pmc_%s.csv" % (tag, x))
 onetime = lambda nm: nm.startswith(('k_pack', 'k_tree', 'k_model', 'k_col'))
-stage_prefix = [("k_viterbi", "viterbi"), ("k_seed_dscan", "seed_pdist"), ("k_seed_pdist", "seed_pdist"), ("k_seed_topk", "seed_topk"), ("k_estimate", "estimate"), ("k_place", "place")]
+stage_prefix = [("k_viterbi", "viterbi"), ("k_seed_dscan", "seed_pdist"), ("k_seed_pdist", "seed_pdist"), ("k_seed_topk", "seed_topk"), ("k_seed_refsort", "seed_topk"), ("k_estimate", "estimate"), ("k_place", "place")]
 by_stage = {k["stage"]: k for k in bench.get("roofline_kernels", [])}
 def stage_entry(nm):
     for pre, st in stage_prefix:

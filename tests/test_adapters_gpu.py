@@ -24,7 +24,7 @@ def _run(tmp_path, db, reads, vps, how):
             f.write(r + " " + " ".join(str(int(x)) for x in np.asarray(vp).ravel()) + "\n")
     p = subprocess.run([EXE, pre + ".hmm", pre + ".ptu", rf, how], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
-    recs = {"ALN": {}, "SEED": {}, "PLACE": {}, "EST": {}, "MEMBER": {}, "FILT": {}, "PLACED": {}, "Q": {}, "QDROP": {}}
+    recs = {"ALN": {}, "SEED": {}, "PLACE": {}, "EST": {}, "MEMBER": {}, "FILT": {}, "PLACED": {}, "Q": {}, "QDROP": {}, "WHOLE": {}}
     for line in p.stdout.splitlines():
         f = line.split()
         recs[f[0]][int(f[1])] = f[2:]
@@ -55,6 +55,8 @@ def test_per_read_adapters_against_oracle(tmp_path, how, model, dg_k):
         assert float(g[7]) == a["cost"] and g[8] == a["align"]         # bit-exact cost (printed with 17 digits), same string
         cd = O.digitize(a["align"])
         res = T.assign(cd, a["csStart"] - 1, a["csEnd"] - 1, O.default_opts())
+        if i < 3:      # getSeed(..., whole = true): the reference's whole sorted vector (every node but the root), its head the device's list
+            assert [int(x) for x in recs["WHOLE"][i]] == [db.n_nodes - 1, 1, 1], recs["WHOLE"][i]
         s = recs["SEED"][i]
         ids = [int(x.split(":")[0]) for x in s[1:]]
         assert int(s[0]) == len(res["seed_ids"]) and ids == [int(x) for x in res["seed_ids"]]

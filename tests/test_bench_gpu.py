@@ -47,8 +47,31 @@ def test_single_rank_line_has_the_contract_fields_and_zero_unexplained_differenc
     t = c["tie_mode"]
     assert t["reads"] == 96 and t["seed_set_diffs_all_exact_cutoff_ties"] and t["final_pick_differs"] == t["final_pick_diffs_traced_to_a_cutoff_tie"]
     assert r["bound"] == "valu_fp64_issue" and "hbm_roof" in r and "valu_roof" in r and len(r["kernel_source_hash"]) == 16
-    sr = j["seed_order_reference"]
+    # the timed region runs the reference's own seed order (libstdc++'s std::sort on dist alone) and is compared with the oracle's literal std::sort;
+    # (dist, node id) is the side block, compared with the oracle in that order
+    assert j["config"]["seed_order"] == "reference" and c["oracle_seed_order"].startswith("TIE_LIBSTDCXX") and "seed_order_reference" not in j
+    sr = j["seed_order_stable"]
     assert sr["value"] > 0 and sr["reads_compared"] == 96 and sr["unexplained_best_branch_diffs"] == 0 and sr["candidate_set_differs"] == 0 and sr["swaps_unexplained"] == 0, sr
+    assert sr["oracle_seed_order"].startswith("TIE_STABLE")
+    # RCCL has run on this GPU: a process group of one rank over the nccl backend, the final gather of the records through it (device tensors)
+    assert j["rccl_ranks"] == 1 and j["rccl_error"] is None and j["backend"] == "nccl" and j["gathered_records"] == 96, (j["rccl_ranks"], j["rccl_error"])
     e = j["end_to_end"]
     assert "failed" not in e, e
     assert e["reads"] == 500 and e["value"] > 0 and e["placed"] > 400 and e["tsv_mb"] > 0.5
+
+
+def test_paired_line_and_the_stable_order_as_the_timed_region():
+    """--paired (BASELINE configs 4 / 5: two mates per unit, merged regions, 32-bit pairs) on a small database, and --seed-order stable as the timed
+    region with the reference's order as the side block: both against the oracle in the same order, zero unexplained differences"""
+    j = _run(["--paired", "--read-len", "250", "--cpu-sample", "48", "--e2e-reads", "0", "--leaves", "600", "--cs-len", "2800", "--batch", "48", "--inflight", "2",
+              "--steps", "2", "--warmup", "1"])
+    assert j["unit"] == "pairs/s" and j["value"] > 0 and j["config"]["seed_order"] == "reference"
+    c = j["cpu_baseline"]
+    assert c["value"] is not None and c["unexplained_best_branch_diffs"] == 0 and c["candidate_order"]["swaps_unexplained"] == 0 and c["candidate_order"]["candidate_set_differs"] == 0, c
+    assert c["max_rel"]["outer_iteration_mismatches"] == 0 and c["max_rel"]["est_loglik"]["max_rel"] <= 1e-6
+    sr = j["seed_order_stable"]
+    assert sr["reads_compared"] == 48 and sr["unexplained_best_branch_diffs"] == 0 and sr["candidate_set_differs"] == 0, sr
+    j2 = _run(["--seed-order", "stable", "--cpu-sample", "96", "--e2e-reads", "0"] + SMALL)
+    assert j2["config"]["seed_order"] == "stable" and j2["cpu_baseline"]["oracle_seed_order"].startswith("TIE_STABLE") and j2["cpu_baseline"]["unexplained_best_branch_diffs"] == 0
+    sr2 = j2["seed_order_reference"]
+    assert sr2["reads_compared"] == 96 and sr2["unexplained_best_branch_diffs"] == 0 and sr2["candidate_set_differs"] == 0 and sr2["oracle_seed_order"].startswith("TIE_LIBSTDCXX"), sr2

@@ -67,6 +67,11 @@ def test_oracle_pipeline_against_golden():
     assert (res["aln_ints"] == g["aln_ints"]).all() and np.array_equal(res["cost"], g["cost"])
     assert (res["n_cand"] == g["n_cand"]).all() and (res["cand_node"] == g["cand_node"]).all() and (res["best_nodes"] == g["best_nodes"]).all()
     assert np.allclose(res["best_vals"], g["best_vals"], rtol=1e-12, atol=0, equal_nan=True)
+    # the same under (dist, node id) — the arrays the file held alone until round 4, unchanged
+    stab, _, _ = G.run_oracle(db, reads, vps, threads=4, tie=0)
+    assert (stab["n_cand"] == g["stable_n_cand"]).all() and (stab["cand_node"] == g["stable_cand_node"]).all() and (stab["best_nodes"] == g["stable_best_nodes"]).all()
+    assert np.allclose(stab["best_vals"], g["stable_best_vals"], rtol=1e-12, atol=0, equal_nan=True)
+    assert int((stab["best_nodes"][:, 0] != res["best_nodes"][:, 0]).sum()) == 19
     # plumbing sanity: every read is aligned and placed, and mostly next to where it was drawn from
     assert (res["aln_ints"][:, 7] == 1).all() and (res["n_cand"] > 0).all()
     near = 0
@@ -145,8 +150,9 @@ def test_tie_mode_report_on_config_1():
     H = O.Hmm(db.hmm.K, db.hmm.L, db.hmm.EM, db.hmm.EI, db.hmm.T, db.hmm.p2cs, 0)
     T = O.Tree(db.parent, db.blen, db.seq, db.up, db.down, db.height, m, None, db.anno_id)
     rd = [r.seq for r in reads]
-    whole = O.pipeline_batch(H, T, rd, vps, threads=4, want_cands=True)
-    p1 = O.pipeline_batch(H, T, rd, vps, threads=4, mode=1, want_lib=True)
+    stable = O.default_opts(tieMode=0)
+    whole = O.pipeline_batch(H, T, rd, vps, opts=stable, threads=4, want_cands=True)
+    p1 = O.pipeline_batch(H, T, rd, vps, opts=stable, threads=4, mode=1, want_lib=True)
     # phase 2 on compact rows: only the nodes some list names
     nodes = np.unique(np.concatenate([p1["seed_ids"].ravel(), p1["lib_ids"].ravel()])); nodes = nodes[nodes >= 0]
     row_of = np.full(db.n_nodes, -1, np.int32); row_of[nodes] = np.arange(len(nodes))

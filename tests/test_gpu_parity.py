@@ -314,19 +314,27 @@ def test_pe_merge_parity():
                                  dict(model="F81", dg_k=0, n_leaves=100, cs_len=700, read_len=150, db_kw=dict(pi=(0.2, 0.3, 0.2, 0.3))),
                                  dict(model="TN93", dg_k=3, n_leaves=100, cs_len=700, read_len=100, db_kw=dict(pi=(0.35, 0.15, 0.35, 0.15))),
                                  # 5,199 nodes = 21 blocks of 256 >= 2 x max_nseed: the distance-only scan and its top-k (the gg_97-scale path)
+                                 dict(model="GTR", dg_k=4, n_leaves=2600, cs_len=300, read_len=100, max_nseed=10, n_reads=24, db_kw=dict(n_match=200), seed_order=0),
+                                 dict(model="HKY85", dg_k=0, n_leaves=2600, cs_len=700, read_len=300, max_nseed=8, n_reads=12, db_kw=dict(n_match=450), seed_order=0),
+                                 # the same two trees in the reference's own seed order (the default): pair scan + k_seed_refsort, 16- and 32-bit pairs
                                  dict(model="GTR", dg_k=4, n_leaves=2600, cs_len=300, read_len=100, max_nseed=10, n_reads=24, db_kw=dict(n_match=200)),
                                  dict(model="HKY85", dg_k=0, n_leaves=2600, cs_len=700, read_len=300, max_nseed=8, n_reads=12, db_kw=dict(n_match=450)),
+                                 # (dist, node id) on the small-tree kernels (pair matrix + k_seed_topk)
+                                 dict(model="GTR", dg_k=4, n_leaves=300, cs_len=1400, read_len=250, seed_order=0),
+                                 dict(model="JC69", dg_k=0, n_leaves=100, cs_len=700, read_len=150, seed_order=0),
                                  # full-length reads: > 256 base sites and > 1,536 region columns per read (the kernels without split slots)
                                  dict(model="GTR", dg_k=4, read_len=600, n_reads=12, **LONG_DB),
                                  dict(model="GTR", dg_k=4, read_len=1300, n_reads=8, **LONG_DB)])
 def test_sep_parity(cfg):
-    """seed scan, top-k, estimate, filter, place, q-values vs the oracle, stage by stage."""
+    """seed scan, top-k, estimate, filter, place, q-values vs the oracle, stage by stage.  seed_order: 1 (default) = the reference's own
+    (literal std::sort on dist alone: oracle TIE_LIBSTDCXX, engine HU_SEED_ORDER_LIBSTDCXX), 0 = (dist, node id) on both sides."""
     E = _engine()
     from oracle import oracle_py as O
     db = get_db(cfg["n_leaves"], cfg["cs_len"], cfg["model"], dg_k=cfg["dg_k"], **cfg.get("db_kw", {}))
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, cfg.get("n_reads", 40), cfg["read_len"])
-    opts = E.default_opts(max_nseed=cfg.get("max_nseed", 50))
+    order = cfg.get("seed_order", 1)
+    opts = E.default_opts(max_nseed=cfg.get("max_nseed", 50), seed_order=order)
     D, B = _run_stages(E, db, reads, vps, opts)
     B.get_seed(opts); B.estimate_seq(opts); B.filter_placements(opts); B.place_seq(opts); B.calc_q_values(opts)
     cd, st, en = B.codes()
@@ -335,8 +343,8 @@ def test_sep_parity(cfg):
     cand = B.candidates()
     best = B.placements()
     coffs, cpl = B.candidate_places()
-    oo = O.default_opts(maxNSeed=cfg.get("max_nseed", 50))
-    oo_tie = O.default_opts(maxNSeed=cfg.get("max_nseed", 50), tieTol=1e-9)
+    oo = O.default_opts(maxNSeed=cfg.get("max_nseed", 50), tieMode=order)
+    oo_tie = O.default_opts(maxNSeed=cfg.get("max_nseed", 50), tieTol=1e-9, tieMode=order)
     exact_ties = "pi" in cfg.get("db_kw", {})                 # equal base frequencies outside K80 / JC69
     worst = dict(est=0.0, ratio=0.0, wnr=0.0)
     stats = dict(reads=0, near_tie_swaps=0, best_differs_by_tie=0, reads_decided_by_exact_ties=0)
@@ -717,11 +725,15 @@ def test_cli_end_to_end(tmp_path):
     ls = [[l for l in o_.stdout.split("\n") if l and not l.startswith("#")][1:] for o_ in outs]
     B.set_reads(reads, ix.lookup_random(reads, 7, 0, 50, 0)); B.assign(E.default_opts())
     assert ls[0] == ls[1] == B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
-    # --seed-order reference: the seeds under libstdc++'s std::sort on dist alone (hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX)
+    # --seed-order: `reference` (the default: libstdc++'s std::sort on dist alone, hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX) spelled out gives the
+    # lines of the plain run; `stable` = (dist, node id) gives the ABI's lines under HU_SEED_ORDER_STABLE
     outr = subprocess.run([cli, pre, fa, "-s", "1", "--seed-order", "reference"], capture_output=True, text=True, timeout=300)
     assert outr.returncode == 0, outr.stderr
-    B.set_reads(reads, ix.lookup(reads, 50, 0)); B.assign(E.default_opts(seed_order=1))
-    assert [l for l in outr.stdout.split("\n") if l and not l.startswith("#")][1:] == \
+    assert [l for l in outr.stdout.split("\n") if l and not l.startswith("#")][1:] == want
+    outst = subprocess.run([cli, pre, fa, "-s", "1", "--seed-order", "stable"], capture_output=True, text=True, timeout=300)
+    assert outst.returncode == 0, outst.stderr
+    B.set_reads(reads, ix.lookup(reads, 50, 0)); B.assign(E.default_opts(seed_order=0))
+    assert [l for l in outst.stdout.split("\n") if l and not l.startswith("#")][1:] == \
         B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
     assert subprocess.run([cli, pre, fa, "--seed-order", "x"], capture_output=True).returncode != 0
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
@@ -918,9 +930,9 @@ def test_topk_sampled_threshold_path(monkeypatch):
     default size limit: seed ids, order and (d, N) stay bit-exact, whether the estimate suffices or the exact
     two-pass path has to take over"""
     monkeypatch.setenv("HU_TOPK_FAST_MIN", "1")
-    test_sep_parity(dict(model="GTR", dg_k=4, n_leaves=1500, cs_len=700, read_len=150))
-    test_sep_parity(dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100))
-    test_topk_degenerate_tie_mass()
+    test_sep_parity(dict(model="GTR", dg_k=4, n_leaves=1500, cs_len=700, read_len=150, seed_order=0))
+    test_sep_parity(dict(model="K80", dg_k=2, n_leaves=80, cs_len=500, read_len=100, seed_order=0))
+    test_topk_degenerate_tie_mass(0)
 
 
 @pytest.mark.parametrize("mean_blen,max_nseed,read_len,wide", [(0.05, 10, 60, 0), (0.05, 3, 60, 1), (1e-9, 10, 60, 0), (0.002, 8, 60, 0), (0.05, 10, 300, 0), (0.0005, 10, 120, 0)])
@@ -934,14 +946,14 @@ def test_distance_only_scan_and_its_topk(mean_blen, max_nseed, read_len, wide):
     db = get_db(2600, 700 if long_ else 200, "JC69", dg_k=0, seed=11, mean_blen=mean_blen, n_match=450 if long_ else 120)      # 5,199 nodes = 21 blocks of 256
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, 12 if long_ else 24, read_len, amplicon=True, cols=650 if long_ else 140)
-    opts = E.default_opts(max_nseed=max_nseed)
+    opts = E.default_opts(max_nseed=max_nseed, seed_order=0)           # (dist, node id): the order of the distance-only path
     D, B = _run_stages(E, db, reads, vps, opts)
     assert D.n_nodes // 256 >= 2 * max_nseed
     B.set_knob("pairs32", wide)
     B.get_seed(opts)
     cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
     for i in range(len(reads)):
-        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=max_nseed)
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), tie=0, max_n=max_nseed)
         assert cnt[i] == len(oid) == max_nseed and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
     for i in (0, len(reads) - 1):
         d, N = B.pdist(i)                      # from the planes, and the scan's row checked against them inside
@@ -984,7 +996,7 @@ def test_seed_stage_with_partial_sequences(kind, capfd):
     db.seq = seq
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db0, 24, 100)
-    opts = E.default_opts(max_nseed=10)
+    opts = E.default_opts(max_nseed=10, seed_order=0)
     D, B = _run_stages(E, db, reads, vps, opts)
     B.set_knob("trace", 1)
     B.set_knob("scan_pairs", -1)        # with so many partial sequences the engine would choose the pair matrix by itself: force the distance-only path
@@ -997,7 +1009,7 @@ def test_seed_stage_with_partial_sequences(kind, capfd):
         assert int(m.group(3)) == 0, err
     cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
     for i in range(len(reads)):
-        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), max_n=10)
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), tie=0, max_n=10)
         assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all() and (sN[i, :cnt[i]] == oN).all(), i
     B.estimate_seq(opts); e1 = B.estimates()
     B.set_knob("scan_pairs", 0)                                   # the engine's own choice: the pair matrix when many sequences lack an end
@@ -1028,7 +1040,7 @@ def test_seed_paths_agree_on_a_large_tree():
     D = E.Database.from_arrays(db.hmm, db.parent, db.blen, db.seq, up.data_ptr(), down.data_ptr(), db.height, md, db.anno_id, msgs_on_device=True)
     assert D.n_nodes // 256 >= 100
     B = E.Batch(D, len(reads))
-    opts = E.default_opts()
+    opts = E.default_opts(seed_order=0)
     B.set_reads([r.seq for r in reads], vps); B.align(opts)
     B.set_knob("trace", 1)
     B.get_seed(opts); a = B.seeds(); B.estimate_seq(opts); ea = B.estimates()
@@ -1062,20 +1074,22 @@ def test_streaming_sep_kernels(monkeypatch):
     test_sep_parity(dict(model="HKY85", dg_k=4, n_leaves=100, cs_len=700, read_len=100))
 
 
-def test_topk_degenerate_tie_mass():
+@pytest.mark.parametrize("order", [0, 1])
+def test_topk_degenerate_tie_mass(order):
     """thousands of nodes at exactly the same distance: the bounded slow path of k_seed_topk must still
-    return the (dist, id) order"""
+    return the (dist, id) order (order 0); in the reference's order (1) every element of the row is a stopper of every partition and
+    the first 50 places are purely libstdc++'s tie permutation — k_seed_refsort against the oracle's literal std::sort"""
     E = _engine()
     from oracle import oracle_py as O
     db = get_db(2600, 200, "JC69", dg_k=0, seed=5, mean_blen=1e-9, n_match=120)   # all sequences identical up to gaps
     _, H, T = oracle_objects(db)
     reads, vps = sim_reads(db, 4, 60, amplicon=True, cols=140)
-    opts = E.default_opts()
+    opts = E.default_opts(seed_order=order)
     D, B = _run_stages(E, db, reads, vps, opts)
     B.get_seed(opts)
     cd, st, en = B.codes(); cnt, ids, sd, sN = B.seeds()
     for i in range(len(reads)):
-        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]))
+        oid, od, oN, _ = T.get_seed(cd[i], int(st[i]), int(en[i]), tie=order)
         assert cnt[i] == len(oid) and (ids[i, :cnt[i]] == oid).all() and (sd[i, :cnt[i]] == od).all()
     B.close(); D.close()
 

@@ -199,7 +199,7 @@ def test_device_sort_prefix_against_the_host_restatement():
 def test_engine_in_reference_seed_order_on_config_1():
     """all 1,000 reads of config 1 (the reference's 70_otus fixture) with hu_opts.seed_order = HU_SEED_ORDER_LIBSTDCXX against the oracle's
     task under TIE_LIBSTDCXX (literal std::sort): the seed lists are identical id by id, in order; candidates and final branches identical
-    or a documented near-tie; and the default order differs from it on this fixture (19 final branches), so the mode does something"""
+    or a documented near-tie; and the (dist, node id) order differs from it on this fixture (19 final branches), so the mode does something"""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_cfg1_golden as G
@@ -212,7 +212,7 @@ def test_engine_in_reference_seed_order_on_config_1():
     B = E.Batch(D, len(reads))
     rd = [r.seq for r in reads]
     B.set_reads(rd, vps)
-    B.assign(E.default_opts())
+    B.assign(E.default_opts(seed_order=0))
     stable = B.placements().copy()
     opts = E.default_opts(seed_order=1)
     B.assign(opts)
@@ -334,23 +334,27 @@ def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
     hmax = float(np.quantile(db.height, 0.9))          # ~21,600 nodes pass: the compacted rows still start with a streaming level
     for wide, maxh in ((0, None), (1, None), (0, hmax)):
         lists = []
-        for host in (0, 1):
+        for host in (0, 1, 2):                         # 0: the device sort, level 0 from the scan's stopper masks; 1: the host restatement; 2: the device sort counting level 0 itself
             B = E.Batch(D, len(rd))
-            B.set_knob("pairs32", wide); B.set_knob("refsort_host", host); B.set_knob("trace", 1)
+            B.set_knob("pairs32", wide); B.set_knob("refsort_host", int(host == 1)); B.set_knob("ref_nofuse", int(host == 2)); B.set_knob("trace", 1)
             opts = E.default_opts(seed_order=1) if maxh is None else E.default_opts(seed_order=1, max_height=maxh)
             capfd.readouterr()
             B.set_reads(rd, vps); B.align(opts); B.get_seed(opts)
             err = capfd.readouterr().err
-            if not host:
+            if host != 1:
                 assert re.search(r"k_seed_refsort: 96 reads.* %s pairs.* 0 reads left to the host" % ("32-bit" if wide else "16-bit"), err), err
+                # the scan prepares level 0 whenever the sort runs on the pair rows as they are (a height filter compacts them first)
+                assert ("level 0 from the scan" in err) == (host == 0 and maxh is None), err
+                assert B.refsort_stats() == (0, False)
             else:
                 assert "k_seed_refsort" not in err
             cnt, ids, sd, sN = B.seeds()
             lists.append((cnt.copy(), ids.copy(), sd.copy(), sN.copy()))
             B.close()
-        (c0, i0, d0, n0), (c1, i1, d1, n1) = lists
-        assert (c0 == c1).all() and (c0 == 50).all()
+        (c0, i0, d0, n0), (c1, i1, d1, n1), (c2, i2, d2, n2) = lists
+        assert (c0 == c1).all() and (c0 == 50).all() and (c2 == c0).all()
         assert (i0 == i1).all() and (d0 == d1).all() and (n0 == n1).all()
+        assert (i0 == i2).all() and (d0 == d2).all() and (n0 == n2).all()
         if maxh is not None:
             assert (db.height[i0] <= maxh).all()
     D.close()
