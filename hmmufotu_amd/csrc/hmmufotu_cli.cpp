@@ -52,6 +52,10 @@ static void usage(const char* p) {
 		"            --seed-order reference|stable  which of the nodes tying at the cut-off distance become seeds: the reference binary's own choice\n"
 		"                             [reference, default] — the first -N of libstdc++'s std::sort on dist alone, reproduced on the device — or\n"
 		"                             (dist, node id) [stable]: independent of the sort's tie permutation and ~25 % faster\n"
+		"            --col-windows INT [1]  hold the database as INT column windows (messages of a window's CS columns only; window i on device\n"
+		"                             --gpu + i mod --gpus) instead of whole replicas: for databases beyond one GPU's memory.  Reads are routed\n"
+		"                             by their seeds and re-routed once by their alignment region.  --win-overlap INT [3200] columns shared by\n"
+		"                             neighbouring windows: at least the widest alignment region to be expected\n"
 		"            -S|--seed INT    a seed hit drawn from all its occurrences (CSFMIndex::locateOne) with this seed; without it the first occurrence\n"
 		"                             (locateFirst).  A run repeats at any thread count.  -p|--process INT is accepted and has no effect\n";
 }
@@ -74,7 +78,7 @@ static int seed_lookup(const hu_seed_index* ix, Packed& p, int seedRegion, int m
 
 int main(int argc, char** argv) {
 	std::vector<std::string> pos; std::string outFn, fmt, method = "unweighted", prior = "uniform";
-	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0;
+	int seedLen = 20, seedRegion = 50, strand = 0, nTest = 100, batch = 8192, gpu = 0, nGpus = 1, inflight = 3, verbose = 0, colWindows = 1; long winOverlap = 3200;
 	bool single = false, checkChimera = false, chimeraInfo = false, alignOnly = false, noCsfm = false, randomHits = false;
 	uint64_t hitSeed = 0; std::string seedOrder = "reference";
 	std::string alnFn;
@@ -116,6 +120,8 @@ int main(int argc, char** argv) {
 		else if(a == "--gpu") gpu = atoi(val());
 		else if(a == "--gpus") nGpus = atoi(val());
 		else if(a == "--inflight") inflight = atoi(val());
+		else if(a == "--col-windows") colWindows = atoi(val());
+		else if(a == "--win-overlap") winOverlap = atol(val());
 		else if(a == "-v") verbose++;
 		else if(a == "-S" || a == "--seed") { hitSeed = (uint64_t) strtoull(val(), nullptr, 10); randomHits = true; }   /* src/hmmufotu.cpp:262-266 */
 		else if(a == "--seed-order") seedOrder = val();
@@ -137,6 +143,7 @@ int main(int argc, char** argv) {
 	/* the chimera options only count with -C (src/hmmufotu.cpp:248-260); checks of :325-340 */
 	if(!checkChimera) { chimeraInfo = false; chiOutFn.clear(); numSeg = 2; chimeraErr = NAN; chimeraLod = 0; }
 	if(nGpus < 1 || nGpus > 64 || inflight < 1 || inflight > 16 || batch < 1) { std::cerr << "--gpus must be in [1, 64], --inflight in [1, 16], --batch positive" << std::endl; return EXIT_FAILURE; }
+	if(colWindows < 1 || colWindows > 64 || winOverlap < 0) { std::cerr << "--col-windows must be in [1, 64], --win-overlap non-negative" << std::endl; return EXIT_FAILURE; }
 	if(numSeg < 2 || numSeg > 6) { std::cerr << "--num-segment must be in [2, 6]" << std::endl; return EXIT_FAILURE; }
 	if(numSeg % 2) { std::cerr << "--num-segment must be an even number" << std::endl; return EXIT_FAILURE; }
 	if(std::isnan(chimeraErr)) chimeraErr = o.max_error / numSeg;
@@ -154,19 +161,32 @@ int main(int argc, char** argv) {
 	};
 
 	if(hu_device_count() < (getenv("HU_CLI_SHARE_GPU") ? 1 : nGpus) + gpu) { std::cerr << "Error: " << nGpus << " device(s) from index " << gpu << " asked for, " << hu_device_count() << " gfx950 device(s) visible" << std::endl; return EXIT_FAILURE; }
-	/* one database replica per device (src/hmmufotu.cpp:457-494 loads the one shared copy); loaded side by side */
-	std::vector<hu_db*> dbs(nGpus, nullptr);
+	/* one database replica per device (src/hmmufotu.cpp:457-494 loads the one shared copy), loaded side by side — or, with --col-windows W, W column
+	 * windows of ONE database spread over the devices (hu_db_load_window): dbs[k] then holds window k */
+	const int nDb = colWindows > 1 ? colWindows : nGpus;
+	std::vector<hu_db*> dbs(nDb, nullptr);
+	std::vector<hu_window> wins((size_t) colWindows);
+	if(colWindows > 1) {
+		int32_t K0 = 0, L0 = 0, n0 = 0, r0 = 0;
+		CHK(hu_files_parse((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), &K0, &L0, &n0, &r0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0));
+		CHK(hu_windows_plan(L0, colWindows, std::min<long>(winOverlap, L0 - 1), wins.data()));
+	}
 	{
-		std::vector<std::thread> lt; std::vector<int> lrc(nGpus, HU_OK); std::vector<std::string> lmsg(nGpus);
+		std::vector<std::thread> lt; std::vector<int> lrc(nDb, HU_OK); std::vector<std::string> lmsg(nDb);
 		const bool share = getenv("HU_CLI_SHARE_GPU") != nullptr;    /* rehearsal of --gpus N on a box with one device: every replica on --gpu */
-		for(int g = 0; g < nGpus; ++g) lt.emplace_back([&, g] { lrc[g] = hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), share ? gpu : gpu + g, &dbs[g]); if(lrc[g] != HU_OK) lmsg[g] = hu_last_error(); });
+		for(int g = 0; g < nDb; ++g) lt.emplace_back([&, g] {
+			const int dev = share ? gpu : gpu + g % nGpus;
+			lrc[g] = colWindows > 1 ? hu_db_load_window((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), dev, wins[g].win_start, wins[g].win_len, &dbs[g])
+			                        : hu_db_load((pos[0] + ".hmm").c_str(), (pos[0] + ".ptu").c_str(), dev, &dbs[g]);
+			if(lrc[g] != HU_OK) lmsg[g] = hu_last_error(); });
 		for(auto& t : lt) t.join();
-		for(int g = 0; g < nGpus; ++g) if(lrc[g] != HU_OK) { std::cerr << "Error: " << lmsg[g] << std::endl; return EXIT_FAILURE; }
+		for(int g = 0; g < nDb; ++g) if(lrc[g] != HU_OK) { std::cerr << "Error: " << lmsg[g] << std::endl; return EXIT_FAILURE; }
 	}
 	hu_db* db = dbs[0];
 	int32_t K, L, nNodes, root; int64_t hbm;
 	CHK(hu_db_info(db, &K, &L, &nNodes, &root, &hbm));
 	if(verbose) std::cerr << "database loaded on " << nGpus << " device(s): K=" << K << " csLen=" << L << " nodes=" << nNodes << " HBM=" << hbm / 1e9 << " GB each" << std::endl;
+	if(verbose && colWindows > 1) { std::cerr << colWindows << " column windows:"; for(const hu_window& w : wins) std::cerr << " [" << w.win_start << ", " << w.win_start + w.win_len << ")"; std::cerr << std::endl; }
 	std::vector<int32_t> parent(nNodes), p2cs(K + 1); std::vector<int8_t> seq((size_t) nNodes * L);
 	CHK(hu_db_get_tree(db, parent.data(), nullptr, seq.data(), nullptr));
 	CHK(hu_db_get_profile(db, nullptr, nullptr, nullptr, p2cs.data(), nullptr, nullptr));
@@ -248,13 +268,20 @@ int main(int argc, char** argv) {
 	/* busy seconds per stage (reported with -v): which stage bounds the pipeline */
 	std::atomic<long long> usParse{0}, usSeed{0}, usEngine{0}, usFormat{0}, usWrite{0};
 	auto usSince = [](std::chrono::steady_clock::time_point t) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
-	const int nWorkers = nGpus * inflight;
+	/* ordinary mode: worker w drives one batch object on replica w % nGpus.  Column-window mode: worker w is a LANE with one batch object per window
+	 * (batch object w * colWindows + k on window k): it splits a batch of reads by window, runs the parts, re-routes, and puts the lines back in read order */
+	const int nWorkers = (colWindows > 1 ? 1 : nGpus) * inflight;
 	const size_t depth = (size_t) nWorkers + 2;
 	P.workersLeft = nWorkers;
-	std::vector<hu_batch*> wgb(nWorkers, nullptr), wwb(nWorkers, nullptr);
-	for(int w = 0; w < nWorkers; ++w) { CHK(hu_batch_create(dbs[w % nGpus], batch, &wgb[w])); if(checkChimera) CHK(hu_batch_create(dbs[w % nGpus], batch, &wwb[w])); }
+	const int perWorker = colWindows > 1 ? colWindows : 1;
+	std::vector<hu_batch*> wgb((size_t) nWorkers * perWorker, nullptr), wwb((size_t) nWorkers * perWorker, nullptr);
+	for(int w = 0; w < nWorkers * perWorker; ++w) {
+		hu_db* d = colWindows > 1 ? dbs[w % colWindows] : dbs[w % nGpus];
+		CHK(hu_batch_create(d, batch, &wgb[w])); if(checkChimera) CHK(hu_batch_create(d, batch, &wwb[w]));
+	}
 
-	auto process = [&](int w, Slot& sl, Done& dn) -> int { /* engine worker: one batch through the engine, then its text */
+	struct PerRead { std::vector<int64_t> mainLen, chiLen, alnLen; std::vector<hu_align_rec> recs; };      /* column-window mode: where each read's lines are in the part's text */
+	auto process = [&](int w, Slot& sl, Done& dn, PerRead* pr = nullptr) -> int { /* engine worker: one batch through the engine, then its text */
 		hu_batch* gb = wgb[w]; hu_batch* wb = wwb[w];
 		Packed& f = sl.f; Packed& r = sl.r; std::vector<std::string>& ids = sl.ids; std::vector<std::string>& descs = sl.descs;
 		const int n = f.n();
@@ -282,13 +309,20 @@ int main(int argc, char** argv) {
 		const int64_t need = hu_batch_format_tsv_ptr(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, mainKind, &txt);
 		if(need < 0) return (int) need;
 		dn.mainTxt.assign(txt, (size_t) need);
+		if(pr) {
+			pr->mainLen.assign((size_t) n, 0); pr->recs.resize((size_t) n);
+			if((rc = hu_batch_tsv_line_lengths(gb, pr->mainLen.data())) != HU_OK || (rc = hu_batch_get_alignments(gb, pr->recs.data(), nullptr, nullptr, 0)) != HU_OK) return rc;
+			pr->alnLen.assign((size_t) n, 0); pr->chiLen.assign((size_t) n, 0);
+		}
 		if(alnOut.on) { /* aligned reads that are not chimeras (src/hmmufotu.cpp:709-715; SeqIO::writeFastaSeq, 60 columns) */
 			std::vector<hu_align_rec> alnRecs((size_t) n); std::vector<char> alnRows((size_t) n * L);
 			if((rc = hu_batch_get_alignments(gb, alnRecs.data(), alnRows.data(), nullptr, 0)) != HU_OK) return rc;
 			for(int i = 0; i < n; ++i) {
 				if(alnRecs[i].status != HU_READ_OK || (cp && cp[i].is_chimera)) continue;
+				const size_t at0 = dn.alnTxt.size();
 				dn.alnTxt += ">" + ids[i] + " " + descs[i] + ";csStart=" + std::to_string(alnRecs[i].cs_start) + ";csEnd=" + std::to_string(alnRecs[i].cs_end) + ";\n";
 				for(int c = 0; c < L; c += 60) { dn.alnTxt.append(&alnRows[(size_t) i * L + c], (size_t) std::min(60, L - c)); dn.alnTxt += '\n'; }
+				if(pr) pr->alnLen[(size_t) i] = (int64_t)(dn.alnTxt.size() - at0);
 			}
 		}
 		if(chiOut.on) {
@@ -296,10 +330,68 @@ int main(int argc, char** argv) {
 			const int64_t cneed = hu_batch_format_tsv_ptr(gb, pid.data(), pdesc.data(), annos.data(), cp, chimeraInfo, 1, &ctxt);
 			if(cneed < 0) return (int) cneed;
 			dn.chiTxt.assign(ctxt, (size_t) cneed);
+			if(pr && (rc = hu_batch_tsv_line_lengths(gb, pr->chiLen.data())) != HU_OK) return rc;
 		}
 		for(char c : dn.mainTxt) if(c == '\n') dn.placed++;
 		dn.n = n;
 		usFormat += usSince(tF);
+		return HU_OK;
+	};
+	/* column-window mode: one batch of reads over the windows.  Route by the seeds (hu_route_by_seeds), one part per window through `process`, the reads
+	 * that come back HU_READ_OUT_OF_WINDOW routed once more by their region (hu_route_by_region), every read's lines put back in read order */
+	std::atomic<long> nRerouted{0}, nUnplaceable{0};
+	auto process_windows = [&](int lane, Slot& sl, Done& dn) -> int {
+		const int n = sl.f.n();
+		std::vector<int32_t> lens((size_t) n), mlens((size_t) n), first((size_t) n);
+		for(int i = 0; i < n; ++i) { lens[i] = (int32_t)(sl.f.offs[i + 1] - sl.f.offs[i]); if(paired) mlens[i] = (int32_t)(sl.r.offs[i + 1] - sl.r.offs[i]); }
+		int rc = hu_route_by_seeds(db, colWindows, wins.data(), n, lens.data(), sl.f.vp.data(), paired ? mlens.data() : nullptr, paired ? sl.r.vp.data() : nullptr, first.data());
+		if(rc != HU_OK) return rc;
+		std::vector<std::string> mainL((size_t) n), chiL((size_t) n), alnL((size_t) n);
+		std::vector<hu_align_rec> recs((size_t) n);
+		std::vector<int32_t> win(first);
+		auto run_part = [&](int k, const std::vector<int>& idx) -> int {
+			Slot part; Done pd; PerRead pr;
+			for(int i : idx) {
+				part.f.add(sl.f.bases.substr((size_t) sl.f.offs[i], (size_t)(sl.f.offs[i + 1] - sl.f.offs[i]))); part.f.vp.insert(part.f.vp.end(), sl.f.vp.begin() + (size_t) i * 12, sl.f.vp.begin() + (size_t) i * 12 + 12);
+				if(paired) { part.r.add(sl.r.bases.substr((size_t) sl.r.offs[i], (size_t)(sl.r.offs[i + 1] - sl.r.offs[i]))); part.r.vp.insert(part.r.vp.end(), sl.r.vp.begin() + (size_t) i * 12, sl.r.vp.begin() + (size_t) i * 12 + 12); }
+				part.ids.push_back(sl.ids[i]); part.descs.push_back(sl.descs[i]);
+			}
+			const int prc = process(lane * colWindows + k, part, pd, &pr);
+			if(prc != HU_OK) return prc;
+			size_t am = 0, ac = 0, aa = 0;
+			for(size_t j = 0; j < idx.size(); ++j) {
+				const int i = idx[j];
+				mainL[i].assign(pd.mainTxt, am, (size_t) pr.mainLen[j]); am += (size_t) pr.mainLen[j];
+				chiL[i].assign(pd.chiTxt, ac, (size_t) pr.chiLen[j]); ac += (size_t) pr.chiLen[j];
+				alnL[i].assign(pd.alnTxt, aa, (size_t) pr.alnLen[j]); aa += (size_t) pr.alnLen[j];
+				recs[i] = pr.recs[j];
+			}
+			dn.flagged += pd.flagged;
+			return HU_OK;
+		};
+		for(int k = 0; k < colWindows; ++k) {
+			std::vector<int> idx;
+			for(int i = 0; i < n; ++i) if(win[i] == k) idx.push_back(i);
+			if(!idx.empty() && (rc = run_part(k, idx)) != HU_OK) return rc;
+		}
+		std::vector<int> out;
+		for(int i = 0; i < n; ++i) if(recs[i].status == HU_READ_OUT_OF_WINDOW) out.push_back(i);
+		if(!out.empty()) {
+			std::vector<int32_t> cs((size_t) out.size()), ce((size_t) out.size()), w2((size_t) out.size());
+			for(size_t j = 0; j < out.size(); ++j) { cs[j] = recs[out[j]].cs_start; ce[j] = recs[out[j]].cs_end; }
+			if((rc = hu_route_by_region(colWindows, wins.data(), (int) out.size(), cs.data(), ce.data(), w2.data())) != HU_OK) return rc;
+			for(int k = 0; k < colWindows; ++k) {
+				std::vector<int> idx;
+				for(size_t j = 0; j < out.size(); ++j) if(w2[j] == k && win[out[j]] != k) idx.push_back(out[j]);
+				if(idx.empty()) continue;
+				if((rc = run_part(k, idx)) != HU_OK) return rc;
+				nRerouted += (long) idx.size();
+			}
+			for(int i : out) if(recs[i].status == HU_READ_OUT_OF_WINDOW) ++nUnplaceable;
+		}
+		for(int i = 0; i < n; ++i) { dn.mainTxt += mainL[i]; dn.chiTxt += chiL[i]; dn.alnTxt += alnL[i]; }
+		for(char c : dn.mainTxt) if(c == '\n') dn.placed++;
+		dn.n = n;
 		return HU_OK;
 	};
 	std::thread seeder([&] {
@@ -329,7 +421,7 @@ int main(int argc, char** argv) {
 			  job = std::move(P.seeded.front()); P.seeded.pop_front(); }
 			P.cv.notify_all();
 			Done dn;
-			const int rc = process(w, *job.second, dn);
+			const int rc = colWindows > 1 ? process_windows(w, *job.second, dn) : process(w, *job.second, dn);
 			if(rc != HU_OK) { P.fail(rc, hu_last_error()); continue; }
 			{ std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.err != HU_OK || P.done.size() < depth + (size_t) nWorkers || P.done.empty() || job.first < P.done.begin()->first; });
 			  P.done.emplace(job.first, std::move(dn)); }
@@ -386,7 +478,7 @@ int main(int argc, char** argv) {
 	seeder.join();
 	for(auto& t : workers) t.join();
 	writer.join();
-	for(int w = 0; w < nWorkers; ++w) { if(wwb[w]) hu_batch_destroy(wwb[w]); hu_batch_destroy(wgb[w]); }
+	for(size_t w = 0; w < wgb.size(); ++w) { if(wwb[w]) hu_batch_destroy(wwb[w]); hu_batch_destroy(wgb[w]); }
 	if(P.err != HU_OK) { std::cerr << "Error: " << P.msg << std::endl; return EXIT_FAILURE; }
 	if(verbose) {
 		const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tLoop).count();
@@ -395,6 +487,7 @@ int main(int argc, char** argv) {
 		std::cerr << "stage busy seconds: parse " << usParse / 1e6 << " (1 thread), seed lookup " << usSeed / 1e6 << " (1 thread driving <= 16), engine " << usEngine / 1e6
 		          << " + format " << usFormat / 1e6 << " (summed over " << nWorkers << " workers), write " << usWrite / 1e6 << " (1 thread)" << std::endl;
 	}
+	if(verbose && colWindows > 1) std::cerr << "column windows: " << nRerouted << " reads re-routed by their region, " << nUnplaceable << " whose region no window holds (widen --win-overlap)" << std::endl;
 	if(verbose) std::cerr << total << " reads processed, " << placed << " assigned" << (checkChimera ? ", " + std::to_string(flagged) + " flagged as chimera" : std::string()) << std::endl;
 	hu_seed_index_destroy(ix);
 	for(hu_db* d : dbs) hu_db_destroy(d);

@@ -25,7 +25,6 @@
 #include "hu_kern_blk.h"
 #include "hu_kern_refsort.h"
 #include "hu_kern_rank.h"
-#include <hipcub/hipcub.hpp>
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
 	hu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return HU_ERR_DEVICE; } } while(0)
@@ -782,6 +781,7 @@ struct HuKnobs {
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 	int width_split = 1;         /* 0: one launch of the estimate / placement kernels for the whole batch, shaped by its widest region (rounds 1-2) */
 	int sort_seq = 0;            /* filterPlacements / the final sort by the restated std::sort for every read (else only where keys tie) */
+	int refsort_wgs = 768;       /* resident workgroups of k_seed_refsort (three per CU fill its LDS and wave slots; fewer leave room for the other batches' kernels beside it) */
 	int ref_nofuse = 0;          /* HU_SEED_ORDER_LIBSTDCXX: k_seed_refsort counts its level 0 itself (pass A over the pair row) instead of starting from the stopper masks the scan leaves */
 	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
@@ -795,7 +795,7 @@ static const HuKnobEntry kKnobs[] = {
 	{"pairs32", &HuKnobs::pairs32}, {"tile_unsorted", &HuKnobs::tile_unsorted}, {"topk_fast_min", &HuKnobs::topk_fast_min}, {"scan_pairs", &HuKnobs::scan_pairs}, {"topk_general", &HuKnobs::topk_general}, {"streaming_sep", &HuKnobs::streaming_sep},
 	{"est_unsorted", &HuKnobs::est_unsorted}, {"place_unsorted", &HuKnobs::place_unsorted}, {"xcd_map", &HuKnobs::xcd_map},
 	{"est_var", &HuKnobs::est_var}, {"place_var", &HuKnobs::place_var}, {"place_nosplit", &HuKnobs::place_nosplit}, {"width_split", &HuKnobs::width_split},
-	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host}, {"ref_nofuse", &HuKnobs::ref_nofuse}, {"sort_seq", &HuKnobs::sort_seq},
+	{"place_lds_pad", &HuKnobs::place_lds_pad}, {"est_lds_pad", &HuKnobs::est_lds_pad}, {"vit_lds_pad", &HuKnobs::vit_lds_pad}, {"scan_lds_pad", &HuKnobs::scan_lds_pad}, {"trace", &HuKnobs::trace}, {"inject_fault", &HuKnobs::inject_fault}, {"refsort_host", &HuKnobs::refsort_host}, {"ref_nofuse", &HuKnobs::ref_nofuse}, {"refsort_wgs", &HuKnobs::refsort_wgs}, {"sort_seq", &HuKnobs::sort_seq},
 };
 static void knobs_from_env(HuKnobs& k) {
 	for(const HuKnobEntry& e : kKnobs) {
@@ -850,7 +850,7 @@ struct hu_batch {
 	int refHostAll = 0;                          /* the last seed stage in the reference's order ran entirely on the host path (tree beyond the device sort) */
 	DBuf<int32_t> dIns, dTileIns, dRetry;     /* dRetry: [0] = count, then the reads the straight top-k launch left to the general one */
 	DBuf<uint32_t> dSortK, dSortV;
-	DBuf<uint8_t> dSortTmp;
+	DBuf<uint32_t> dCsCnt;      /* counting sort of the launch orders (hu_kern_rank.h): counters, run starts, cursors */
 	DBuf<HuEstOut> dEst;
 	DBuf<HuCand> dCands;
 	DBuf<HuPlaceOut> dPlaceOut;
@@ -1091,6 +1091,27 @@ static int ensure_read_buffers(hu_batch* b) {
 	return HU_OK;
 }
 
+/* out[0 .. n) = the values in the order of their keys; keys beyond `bound` count as bound.  runsInOrder: the values of one key in ascending order (the scan's tiling:
+ * the same tiles run after run); else in the order the scatter's atomics gave them (the launch orders: which workgroup of a node's run comes first changes nothing).
+ * A counting sort on the batch's stream */
+static int order_by_key(hu_batch* b, const uint32_t* key, const uint32_t* val, size_t n, uint32_t bound, uint32_t* out, bool runsInOrder) {
+	if(!n) return HU_OK;
+	const size_t m = (size_t) bound + 1;
+	int rc;
+	const size_t nTiles = (m + 1023) / 1024;
+	if((rc = b->dCsCnt.ensure(3 * m + nTiles + 8)) != HU_OK) return rc;
+	uint32_t* cnt = b->dCsCnt.p; uint32_t* start = cnt + m; uint32_t* cur = start + m + 1; uint32_t* tiles = cur + m;
+	HIPCHK(hipMemsetAsync(cnt, 0, m * 4, b->stream));
+	k_cs_hist<<<(unsigned)((n + 255) / 256), 256, 0, b->stream>>>((int) n, key, bound, cnt);
+	k_cs_tile_sums<<<(unsigned) nTiles, 1024, 0, b->stream>>>((int) m, cnt, tiles);
+	k_cs_scan_tiles<<<1, 1024, 0, b->stream>>>((int) nTiles, tiles);
+	k_cs_scan<<<(unsigned) nTiles, 1024, 0, b->stream>>>((int) m, cnt, tiles, start, cur);
+	k_cs_scatter<<<(unsigned)((n + 255) / 256), 256, 0, b->stream>>>((int) n, key, val, bound, cur, out);
+	if(runsInOrder) k_cs_runs<<<(unsigned)((m + 3) / 4), 256, 0, b->stream>>>((int) bound, start, out);      /* (the overflow bucket — invalid slots — is left as scattered) */
+	HIPCHK(hipGetLastError());
+	return HU_OK;
+}
+
 /* the scan's tiling: reads sorted by the first column of their region (from the alignments, or from dStart / dEnd when alns is NULL) */
 static int tile_reads(hu_batch* b, const HuAlnDev* alns) {
 	const int n = b->n;
@@ -1098,12 +1119,9 @@ static int tile_reads(hu_batch* b, const HuAlnDev* alns) {
 	const int tiles = (n + HU_READ_TILE - 1) / HU_READ_TILE;
 	int rc;
 	if((rc = b->dSortK.ensure((size_t) n * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) n * 2)) != HU_OK) return rc;
-	size_t tb = 0;
-	HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + n, b->dSortV.p, b->dSortV.p + n, n, 0, 32, b->stream));
-	if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
 	k_tile_keys<<<(n + 255) / 256, 256, 0, b->stream>>>(n, alns, b->dStart.p, b->dEnd.p, b->dSortK.p, b->dSortV.p);
 	if(b->knob.tile_unsorted) HIPCHK(hipMemcpyAsync(b->dSortV.p + n, b->dSortV.p, (size_t) n * 4, hipMemcpyDeviceToDevice, b->stream));   /* tiles in read order */
-	else HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + n, b->dSortV.p, b->dSortV.p + n, n, 0, 32, b->stream));
+	else if((rc = order_by_key(b, b->dSortK.p, b->dSortV.p, (size_t) n, (uint32_t) b->db->dev.csLen + 1u, b->dSortV.p + n, true)) != HU_OK) return rc;      /* keys: 1-based first column, unplaced reads last */
 	k_tile_slots<<<(tiles * HU_READ_TILE + 255) / 256, 256, 0, b->stream>>>(n, tiles * HU_READ_TILE, b->dSortV.p + n, b->dSlotRead.p, b->dReadSlot.p);
 	HIPCHK(hipGetLastError());
 	return HU_OK;
@@ -1539,7 +1557,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 		return seed_order_libstdcxx(b, o);
 	}
 	b->refHostAll = 0;
-	int G = std::min(n, 3 * 256);        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
+	int G = std::min(n, std::max(1, std::min(b->knob.refsort_wgs, 3 * 256)));        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
 	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
 	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
 	if((rc = b->dRefScratch.ensure((size_t) G * perWg)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;
@@ -1926,11 +1944,8 @@ extern "C" int hu_estimate_batch(hu_batch* b, const hu_opts* o) try {
 			if(pass) order = b->dWideOrd.p;
 			else if(!b->knob.est_unsorted) {
 				if((rc = b->dSortK.ensure((size_t) eg * 2)) != HU_OK || (rc = b->dSortV.ensure((size_t) eg * 2)) != HU_OK) return rc;
-				size_t tb = 0;
-				HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
-				if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
 				k_seed_sortkeys<<<(eg + 255) / 256, 256, 0, b->stream>>>(b->n, b->dSeedCnt.p, b->dSeedId.p, b->dSortK.p, b->dSortV.p);
-				HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + eg, b->dSortV.p, b->dSortV.p + eg, (int) eg, 0, 32, b->stream));
+				if((rc = order_by_key(b, b->dSortK.p, b->dSortV.p, (size_t) eg, (uint32_t) b->db->dev.nNodes, b->dSortV.p + eg, false)) != HU_OK) return rc;      /* empty slots (key 0xffffffff) last */
 				order = b->dSortV.p + eg;
 			}
 			/* register-resident variant (messages cross HBM once) while a read's region fits 256 x SPT sites, the
@@ -2144,11 +2159,8 @@ extern "C" int hu_place_batch(hu_batch* b, const hu_opts* o) try {
 				if(pass) order = b->dWideCand.p;
 				else if(!b->knob.place_unsorted) { /* launch order: by candidate node */
 					if((rc = b->dSortK.ensure(nc * 2)) != HU_OK || (rc = b->dSortV.ensure(nc * 2)) != HU_OK) return rc;
-					size_t tb = 0;
-					HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
-					if((rc = b->dSortTmp.ensure(tb + 16)) != HU_OK) return rc;
 					k_cand_sortkeys<<<(unsigned)((nc + 255) / 256), 256, 0, b->stream>>>((int) nc, b->dCands.p, b->dSortK.p, b->dSortV.p);
-					HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dSortTmp.p, tb, b->dSortK.p, b->dSortK.p + nc, b->dSortV.p, b->dSortV.p + nc, (int) nc, 0, 32, b->stream));
+					if((rc = order_by_key(b, b->dSortK.p, b->dSortV.p, nc, (uint32_t) b->db->dev.nNodes, b->dSortV.p + nc, false)) != HU_OK) return rc;
 					order = b->dSortV.p + nc;
 				}
 				#define PL_GO(S, NW, E, R, O) k_place_blk<S, NW, E, R, O><<<grid, 64 * NW, 0, b->stream>>>(PL_ARGS, nullptr, order, nullptr, nullptr, xm)
@@ -2577,6 +2589,12 @@ extern "C" int64_t hu_batch_format_tsv_ptr(hu_batch* b, const char* const* ids, 
 	*text = need >= 0 ? b->tsvBuf.data() : nullptr;
 	return need;
 } catch(...) { return hu_catch_all("hu_batch_format_tsv_ptr"); }
+extern "C" int hu_batch_tsv_line_lengths(hu_batch* b, int64_t* lens) try {
+	if(!b || (b->n > 0 && !lens)) { hu_set_error("hu_batch_tsv_line_lengths: bad argument"); return HU_ERR_ARG; }
+	if(b->tsvLen.size() != (size_t) b->n) { hu_set_error("hu_batch_tsv_line_lengths: no lines were formatted for this batch"); return HU_ERR_STATE; }
+	for(int r = 0; r < b->n; ++r) lens[r] = (int64_t) b->tsvLen[(size_t) r];
+	return HU_OK;
+} catch(...) { return hu_catch_all("hu_batch_tsv_line_lengths"); }
 extern "C" const char* hu_tsv_header_chimera(void) {
 	return "id\tdescription\tseq_start\tseq_end\thmm_start\thmm_end\tCS_start\tCS_end\tcost\talignment\t"
 	       "seg5_taxon_id\tseg3_taxon_id\tseg5_taxon_anno\tseg3_taxon_anno\tchimera_lod\t"

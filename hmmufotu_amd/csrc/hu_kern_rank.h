@@ -276,3 +276,96 @@ __global__ __launch_bounds__(64) void k_finish(HuDbDev db, int n, const int32_t*
 	br.q_place = p.qPlace; br.q_taxon = p.qTaxon; br.anno_dist = p.annoDist(); br.est_loglik = p.estLoglik; br.root_loglik = p.rootLoglik;
 	best[r] = br;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch orders (the scan's tiles by region start, the estimate workgroups by seed node, the placement workgroups by candidate node): the order of
+ * (key, value) pairs by key, ties by value, for keys in [0, bound] (a larger key counts as bound: invalid slots, last).  The keys are node ids or
+ * CS columns — a few hundred thousand distinct values at most — so this is a COUNTING sort on the key itself: one histogram, one scan of the
+ * counters, one scatter, and a pass that puts every key's short run of values in ascending order (which makes the order independent of the
+ * scatter's atomics).  Rounds 1-3 called hipcub::DeviceRadixSort here, four passes of a general 32-bit radix sort for a key space this small.
+ * Only speed depends on these orders (which workgroups share an L2), never a result. */
+/* (the overflow bucket — the empty (read, seed) slots, a fifth of all — is counted and filled once per WAVE: 10^5 atomics on one address serialise) */
+__global__ __launch_bounds__(256) void k_cs_hist(int n, const uint32_t* __restrict__ key, uint32_t bound, uint32_t* __restrict__ cnt) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t k = i < n ? key[i] : 0u;
+	const unsigned long long over = __ballot(i < n && k >= bound);
+	if(i < n && k < bound) atomicAdd(&cnt[k], 1u);
+	if(over && (threadIdx.x & 63) == 0) atomicAdd(&cnt[bound], (uint32_t) __popcll(over));
+}
+/* start[b] = elements with a key below b (b = 0 .. m), cursor = start: tiles of 1,024 counters — (1) the tiles' sums, (2) their scan by one workgroup,
+ * (3) every tile scanned behind its offset.  All loads coalesced; a one-workgroup scan of 2 x 10^5 counters walked them at one memory round trip per
+ * element and thread: 3 ms. */
+__device__ inline uint32_t cs_block_scan(uint32_t v, uint32_t* wsum /* LDS [16] */, uint32_t& total) { /* inclusive scan over 1,024 threads */
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for(int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if(lane >= o) v += t; }
+	if(lane == 63) wsum[wave] = v;
+	__syncthreads();
+	uint32_t before = 0, tot = 0;
+#pragma unroll
+	for(int w = 0; w < 16; ++w) { const uint32_t t = wsum[w]; if(w < wave) before += t; tot += t; }
+	total = tot;
+	__syncthreads();
+	return v + before;
+}
+__global__ __launch_bounds__(1024) void k_cs_tile_sums(int m, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ tileSum) {
+	__shared__ uint32_t wsum[16];
+	const int i = blockIdx.x * 1024 + threadIdx.x;
+	uint32_t tot;
+	(void) cs_block_scan(i < m ? cnt[i] : 0u, wsum, tot);
+	if(threadIdx.x == 0) tileSum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_cs_scan_tiles(int nTiles, uint32_t* __restrict__ tileSum) { /* exclusive, in place; nTiles <= 2^24 / 1024 */
+	__shared__ uint32_t wsum[16];
+	uint32_t carry = 0;
+	for(int base = 0; base < nTiles; base += 1024) {
+		const int i = base + threadIdx.x;
+		const uint32_t v = i < nTiles ? tileSum[i] : 0u;
+		uint32_t tot;
+		const uint32_t inc = cs_block_scan(v, wsum, tot);
+		if(i < nTiles) tileSum[i] = carry + inc - v;
+		carry += tot;
+	}
+}
+__global__ __launch_bounds__(1024) void k_cs_scan(int m, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tileOff, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor) {
+	__shared__ uint32_t wsum[16];
+	const int i = blockIdx.x * 1024 + threadIdx.x;
+	const uint32_t v = i < m ? cnt[i] : 0u;
+	uint32_t tot;
+	const uint32_t inc = cs_block_scan(v, wsum, tot);
+	const uint32_t ex = tileOff[blockIdx.x] + inc - v;
+	if(i < m) { start[i] = ex; cursor[i] = ex; }
+	if(i == m - 1) start[m] = ex + v;
+}
+__global__ __launch_bounds__(256) void k_cs_scatter(int n, const uint32_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t bound, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out) {
+	const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+	const uint32_t k = i < n ? key[i] : 0u;
+	const bool ov = i < n && k >= bound;
+	const unsigned long long over = __ballot(ov);
+	if(i < n && k < bound) out[atomicAdd(&cursor[k], 1u)] = val[i];
+	if(over) {
+		uint32_t base = 0;
+		if(lane == 0) base = atomicAdd(&cursor[bound], (uint32_t) __popcll(over));
+		base = __shfl(base, 0);
+		if(ov) out[base + (uint32_t) __popcll(over & ((1ull << lane) - 1ull))] = val[i];
+	}
+}
+/* the values of one key in ascending order: one wave per key, runs of up to 1,024 values staged in LDS and placed by rank (the values of a run are
+ * distinct: slot or read numbers).  A key shared by more values than that keeps the scatter's order — harmless, see above. */
+__global__ __launch_bounds__(256) void k_cs_runs(int m, const uint32_t* __restrict__ start, uint32_t* __restrict__ out) {
+	__shared__ uint32_t stage[4][1024];
+	const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if(b >= m) return;
+	const uint32_t s = start[b], len = start[b + 1] - s;
+	if(len < 2 || len > 1024) return;
+	uint32_t* st = stage[threadIdx.x >> 6];
+	for(uint32_t i = lane; i < len; i += 64) st[i] = out[s + i];
+	__builtin_amdgcn_wave_barrier();
+	__threadfence_block();
+	for(uint32_t i = lane; i < len; i += 64) {
+		const uint32_t v = st[i];
+		uint32_t r = 0;
+		for(uint32_t j = 0; j < len; ++j) r += st[j] < v;
+		out[s + r] = v;
+	}
+}

@@ -156,43 +156,73 @@ template<class PT> struct HuRsGeom { static constexpr int EPL = 16 / (int) sizeo
 struct __attribute__((packed, aligned(2))) HuRsU4h { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) HuRsU4w { uint32_t x, y, z, w; };
 
+/* The streaming passes work on the keys AS STORED ("raw": the 16-bit form d << 8 | N, or the 32-bit pair itself) — what a pass moves it moves unchanged, and a
+ * comparison takes d and N straight out of the stored form.  Round 3 widened every key to the canonical 32-bit pair on load and narrowed it again on store: 7 of
+ * the ~30 vector instructions a key cost per visit.  The whole path is bound by vector ISSUE (six batches in flight: this kernel's time hides behind the other
+ * batches' kernels, its instructions do not — resident workgroups 768 -> 256 double its time and leave the step rate where it was), so instructions are what counts. */
+template<class PT> struct HuRsRaw;
+template<> struct HuRsRaw<uint16_t> {
+	__device__ static inline uint32_t d(uint32_t x) { return x >> 8; }
+	__device__ static inline uint32_t N(uint32_t x) { return x & 0xffu; }
+	__device__ static inline void unpack(const uint4& v, uint32_t* o) {
+		o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16; o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
+	}
+};
+template<> struct HuRsRaw<uint32_t> {
+	__device__ static inline uint32_t d(uint32_t x) { return x >> 16; }
+	__device__ static inline uint32_t N(uint32_t x) { return x & 0xffffu; }
+	__device__ static inline void unpack(const uint4& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
 template<bool L0, class PT>
 __device__ inline void rs_load(const PT* __restrict__ src, const PT* __restrict__ row, int root, int rowLast, int p0, uint32_t (&k)[HuRsGeom<PT>::EPL]) {
 	constexpr int EPL = HuRsGeom<PT>::EPL;
-	if(!L0) { const uint4 v = *reinterpret_cast<const uint4*>(src + p0); HuPair<PT>::unpack(v, k); return; }
+	if(!L0) { const uint4 v = *reinterpret_cast<const uint4*>(src + p0); HuRsRaw<PT>::unpack(v, k); return; }
 	/* level 0: the row in node order without the root — from the root on, the element of place p is row[p + 1] */
 	uint32_t o[EPL + 1];
 	const uint4 v = *reinterpret_cast<const uint4*>(row + p0);
-	HuPair<PT>::unpack(v, o);
-	o[EPL] = HuPair<PT>::canon(row[min(p0 + EPL, rowLast)]);
+	HuRsRaw<PT>::unpack(v, o);
+	o[EPL] = (uint32_t) row[min(p0 + EPL, rowLast)];
+	if(p0 >= root) {
 #pragma unroll
-	for(int e = 0; e < EPL; ++e) k[e] = (p0 + e < root) ? o[e] : o[e + 1];
+		for(int e = 0; e < EPL; ++e) k[e] = o[e + 1];
+	}
+	else {
+#pragma unroll
+		for(int e = 0; e < EPL; ++e) k[e] = (p0 + e < root) ? o[e] : o[e + 1];
+	}
 }
-/* level 0 only: the two patches of the pivot's swap; a compared-site count of zero among the valid places is a NaN distance */
-template<int EPL>
+/* level 0 only: the two patches of the pivot's swap (raw values); a compared-site count of zero among the valid places is a NaN distance */
+template<class PT, int EPL>
 __device__ inline void rs_fix_l0(uint32_t (&k)[EPL], int p0, int pA, uint32_t vA, int pB, uint32_t vB, uint32_t vb, bool& nan) {
 	if((unsigned)(pA - p0) < (unsigned) EPL || (unsigned)(pB - p0) < (unsigned) EPL) {
 #pragma unroll
 		for(int e = 0; e < EPL; ++e) { k[e] = p0 + e == pA ? vA : k[e]; k[e] = p0 + e == pB ? vB : k[e]; }
 	}
-	uint32_t z = 0;
+	if(vb) {
+		uint32_t z = 0;
 #pragma unroll
-	for(int e = 0; e < EPL; ++e) z |= (uint32_t)((k[e] & 0xffffu) == 0) << e;
-	nan |= (z & vb) != 0;
+		for(int e = 0; e < EPL; ++e) z |= (uint32_t)(HuRsRaw<PT>::N(k[e]) == 0) << e;
+		nan |= (z & vb) != 0;
+	}
 }
 template<int EPL>
 __device__ inline uint32_t rs_valid(int q0, int qlo, int qhi) {
 	const int a = min(max(qlo - q0, 0), EPL), b = min(max(qhi - q0, 0), EPL);
 	return ((1u << b) - 1u) & ~((1u << a) - 1u);
 }
-/* stopper bits of a group against a pivot: left stopper = !(k < piv), right stopper = !(piv < k), both through the cross products */
-template<int EPL>
+/* stopper bits of a group of raw keys against a pivot (canonical pair): left stopper = !(k < piv), right stopper = !(piv < k), both through the cross products */
+template<class PT, int EPL>
 __device__ inline void rs_classify(const uint32_t (&k)[EPL], uint32_t piv, uint32_t vb, uint32_t& mLb, uint32_t& mRb) {
 	const uint32_t dp = piv >> 16, Np = piv & 0xffffu;
 	uint32_t l = 0, r = 0;
 #pragma unroll
-	for(int e = 0; e < EPL; ++e) { const uint32_t a = (k[e] >> 16) * Np, b = dp * (k[e] & 0xffffu); l |= (uint32_t)(a >= b) << e; r |= (uint32_t)(b >= a) << e; }
+	for(int e = 0; e < EPL; ++e) { const uint32_t a = HuRsRaw<PT>::d(k[e]) * Np, b = dp * HuRsRaw<PT>::N(k[e]); l |= (uint32_t)(a >= b) << e; r |= (uint32_t)(b >= a) << e; }
 	mLb = l & vb; mRb = r & vb;
+}
+/* a group's stopper bits as the pass that classified the level left them in its mask arrays (rs_emit, or the words the scan's masks became) */
+template<int EPL>
+__device__ inline uint32_t rs_mask_bits(const unsigned char* __restrict__ bits, int g) {
+	return EPL == 8 ? (uint32_t) bits[g] : (((uint32_t) bits[g >> 1] >> ((g & 1) * 4)) & 15u);
 }
 /* a group's bits into the level's mask arrays (as bytes: the arrays are bit arrays over the positions) and its subtile's counts */
 template<int EPL>
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	__shared__ uint32_t shP[4];              /* pivot pair, the pair it displaced, next pivot pair */
 	__shared__ int shI[12];                  /* broadcast slots */
 	__shared__ HuRsRange stash[12];
-	__shared__ int seqStack[72];
+	__shared__ int seqStack[72 * (HU_RS_THREADS / 64)];      /* one stack per wave: the sequential finishers of a read's stretches run side by side */
 	__shared__ int hLo[HU_RS_MAXLEV], hQB[HU_RS_MAXLEV], hW[HU_RS_MAXLEV], hCut[HU_RS_MAXLEV], hM[HU_RS_MAXLEV], hOff[HU_RS_MAXLEV], hNC[HU_RS_MAXLEV];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int rowLast = db.nNodesPad - 1;
@@ -332,23 +362,36 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const unsigned long long* nm = l0m + (size_t) read * npw * 2;
 					const unsigned long long below = rs_lane_lt(db.root & 63);
 					const bool efL = !rs_ltp(ef, pivP), efR = !rs_ltp(pivP, ef);
-					for(int t = tid; t < NTl; t += HU_RS_THREADS) {
-						const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t) t);
-						unsigned long long mL = a.x, mR = a.y;
-						if(t >= tr) {
-							ulonglong2 c = make_ulonglong2(0ull, 0ull);
-							if(t + 1 < npw) c = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t)(t + 1));
-							const unsigned long long sL = (a.x >> 1) | (c.x << 63), sR = (a.y >> 1) | (c.y << 63);
-							mL = t > tr ? sL : ((a.x & below) | (sL & ~below));
-							mR = t > tr ? sR : ((a.y & below) | (sR & ~below));
+					for(int tb = 0; tb < NTl; tb += 4 * HU_RS_THREADS) { /* four subtiles per thread and trip: eight 16-byte loads in flight (one at a time, the six trips of a
+					                                                      * gg_97-scale row cost a memory round trip each: 39 us of the read's 340) */
+						ulonglong2 a4[4], c4[4];
+#pragma unroll
+						for(int u = 0; u < 4; ++u) {
+							const int t = min(tb + u * HU_RS_THREADS + tid, NTl - 1);
+							a4[u] = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t) t);
+							c4[u] = *reinterpret_cast<const ulonglong2*>(nm + 2 * (size_t) min(t + 1, npw - 1));
 						}
-						/* valid places of this subtile: o0 <= 64 t + i < qEnd */
-						const int v0 = max(o0 - 64 * t, 0), v1 = min(qEnd - 64 * t, 64);
-						const unsigned long long vm = (v1 >= 64 ? ~0ull : rs_lane_lt(max(v1, 0))) & ~rs_lane_lt(min(v0, 63)) & (v0 >= 64 ? 0ull : ~0ull);
-						mL &= vm; mR &= vm;
-						if((wAbs >> 6) == t && wAbs > lo) { const unsigned long long bit = 1ull << (wAbs & 63); mL = efL ? (mL | bit) : (mL & ~bit); mR = efR ? (mR | bit) : (mR & ~bit); }
-						gML[off + t] = mL; gMR[off + t] = mR;
-						cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
+#pragma unroll
+						for(int u = 0; u < 4; ++u) {
+							const int t = tb + u * HU_RS_THREADS + tid;
+							if(t >= NTl) continue;
+							const ulonglong2 a = a4[u];
+							unsigned long long mL = a.x, mR = a.y;
+							if(t >= tr) {
+								ulonglong2 c = make_ulonglong2(0ull, 0ull);
+								if(t + 1 < npw) c = c4[u];
+								const unsigned long long sL = (a.x >> 1) | (c.x << 63), sR = (a.y >> 1) | (c.y << 63);
+								mL = t > tr ? sL : ((a.x & below) | (sL & ~below));
+								mR = t > tr ? sR : ((a.y & below) | (sR & ~below));
+							}
+							/* valid places of this subtile: o0 <= 64 t + i < qEnd */
+							const int v0 = max(o0 - 64 * t, 0), v1 = min(qEnd - 64 * t, 64);
+							const unsigned long long vm = (v1 >= 64 ? ~0ull : rs_lane_lt(max(v1, 0))) & ~rs_lane_lt(min(v0, 63)) & (v0 >= 64 ? 0ull : ~0ull);
+							mL &= vm; mR &= vm;
+							if((wAbs >> 6) == t && wAbs > lo) { const unsigned long long bit = 1ull << (wAbs & 63); mL = efL ? (mL | bit) : (mL & ~bit); mR = efR ? (mR | bit) : (mR & ~bit); }
+							gML[off + t] = mL; gMR[off + t] = mR;
+							cnt16[t] = (uint16_t)(__popcll(mL) | (__popcll(mR) << 8));
+						}
 					}
 				}
 				else {
@@ -380,9 +423,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 							for(int u = 0; u < VU; ++u) {
 								const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
 								const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
-								if(L0) rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, vb, nan);
+								if(L0) rs_fix_l0<PT, EPL>(k[u], qBase + g * EPL, pA, HuPair<PT>::pack(vA), pB, HuPair<PT>::pack(vB), vb, nan);
 								uint32_t mLb, mRb;
-								rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+								rs_classify<PT, EPL>(k[u], pivP, vb, mLb, mRb);
 								rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
 							}
 						}
@@ -507,24 +550,27 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			/* ---- pass B1: the right stoppers j_1 .. j_m (rank from the right <= m), from the subtile of j_m on */
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
+				const unsigned char* __restrict__ bRc = reinterpret_cast<const unsigned char*>(gMR + off);      /* this level's right-stopper bits: classified once, by the pass that wrote or counted it */
 				for(int gb = (jm >> 6) * LPS; gb < gEnd; gb += HU_RS_THREADS * VU) {
-					uint32_t k[VU][EPL];
+					uint32_t k[VU][EPL], mR[VU];
 #pragma unroll
-					for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd - 1) * EPL, k[u]);
+					for(int u = 0; u < VU; ++u) {
+						const int g = min(gb + u * HU_RS_THREADS + tid, gEnd - 1);
+						rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
+						mR[u] = rs_mask_bits<EPL>(bRc, g);
+					}
 #pragma unroll
 					for(int u = 0; u < VU; ++u) {
 						const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
-						const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, qEnd) : 0u;
-						if(L0) { bool dummy = false; rs_fix_l0<EPL>(k[u], qBase + g * EPL, pA, vA, pB, vB, 0u, dummy); }
-						uint32_t mLb, mRb;
-						rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+						if(L0) { bool dummy = false; rs_fix_l0<PT, EPL>(k[u], qBase + g * EPL, pA, HuPair<PT>::pack(vA), pB, HuPair<PT>::pack(vB), 0u, dummy); }
+						const uint32_t mRb = in ? mR[u] : 0u;
 						const int c = __popc(mRb);
 						int s = c;                                     /* right stoppers of this lane and the higher lanes of its subtile */
 #pragma unroll
 						for(int o = 1; o < LPS; o <<= 1) { const int v = __shfl_down(s, o); if((lane & (LPS - 1)) + o < LPS) s += v; }
 						const int above = (int) sufR[min(g / LPS, NTl - 1) + 1] + s - c;
 #pragma unroll
-						for(int e = 0; e < EPL; ++e) if((mRb >> e) & 1u) { const int rk = above + __popc(mRb >> e); if(rk <= m) RS[rk - 1] = HuPair<PT>::pack(k[u][e]); }
+						for(int e = 0; e < EPL; ++e) if((mRb >> e) & 1u) { const int rk = above + __popc(mRb >> e); if(rk <= m) RS[rk - 1] = (PT) k[u][e]; }
 					}
 				}
 			};
@@ -562,17 +608,22 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				auto passB2 = [&](auto l0) {
 					constexpr bool L0 = decltype(l0)::value;
 					unsigned char* bL = reinterpret_cast<unsigned char*>(gML + nOff); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + nOff);
+					const unsigned char* __restrict__ bLc = reinterpret_cast<const unsigned char*>(gML + off);      /* this level's left-stopper bits */
+					const uint32_t loRaw = HuPair<PT>::pack(loVal), pivRaw = HuPair<PT>::pack(pivP);
 					for(int gb = 0; gb < gEnd2; gb += HU_RS_THREADS * VU) {
-						uint32_t k[VU][EPL];
+						uint32_t k[VU][EPL], mLt[VU];
 #pragma unroll
-						for(int u = 0; u < VU; ++u) rs_load<L0, PT>(src, row, db.root, rowLast, qBase + min(gb + u * HU_RS_THREADS + tid, gEnd2 - 1) * EPL, k[u]);
+						for(int u = 0; u < VU; ++u) {
+							const int g = min(gb + u * HU_RS_THREADS + tid, gEnd2 - 1);
+							rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
+							mLt[u] = rs_mask_bits<EPL>(bLc, g);
+						}
 #pragma unroll
 						for(int u = 0; u < VU; ++u) {
 							const int g = gb + u * HU_RS_THREADS + tid, p0 = qBase + g * EPL; const bool in = g < gEnd2;
 							const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, cutq) : 0u;
-							if(L0) { bool dummy = false; rs_fix_l0<EPL>(k[u], p0, pA, vA, pB, vB, 0u, dummy); }
-							uint32_t mLb, mRb;
-							rs_classify<EPL>(k[u], pivP, vb, mLb, mRb);
+							if(L0) { bool dummy = false; rs_fix_l0<PT, EPL>(k[u], p0, pA, HuPair<PT>::pack(vA), pB, HuPair<PT>::pack(vB), 0u, dummy); }
+							const uint32_t mLb = mLt[u] & vb;
 							/* the left stoppers of a group have consecutive ranks: one (unaligned) vector of right stoppers, dealt out in order */
 							const int c = __popc(mLb);
 							int s = c;
@@ -585,10 +636,10 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 #pragma unroll
 							for(int e = 0; e < EPL; ++e) {
 								const bool bit = (mLb >> e) & 1u;
-								if(sizeof(PT) == 2) {
-									k[u][e] = bit ? HuPair<PT>::canon(rx & 0xffffu) : k[u][e];
-									const uint32_t sx = (rx >> 16) | (ry << 16), sy = (ry >> 16) | (rz << 16), sz = (rz >> 16) | (rw << 16), sw = rw >> 16;
-									rx = bit ? sx : rx; ry = bit ? sy : ry; rz = bit ? sz : rz; rw = bit ? sw : rw;
+								if(sizeof(PT) == 2) { /* the window of right stoppers moves on by one key (16 bits) where one was dealt: four funnel shifts by 0 or 16 */
+									k[u][e] = bit ? (rx & 0xffffu) : k[u][e];
+									const uint32_t sh = bit ? 16u : 0u;
+									rx = __builtin_amdgcn_alignbit(ry, rx, sh); ry = __builtin_amdgcn_alignbit(rz, ry, sh); rz = __builtin_amdgcn_alignbit(rw, rz, sh); rw >>= sh;
 								}
 								else {
 									k[u][e] = bit ? rx : k[u][e];
@@ -597,20 +648,21 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 							}
 							if((unsigned)(lo - p0) < (unsigned) EPL || (unsigned)(nW - p0) < (unsigned) EPL) {
 #pragma unroll
-								for(int e = 0; e < EPL; ++e) { k[u][e] = p0 + e == lo ? loVal : k[u][e]; k[u][e] = p0 + e == nW ? pivP : k[u][e]; }   /* the next pivot's swap: this level's pivot goes where that one stood */
+								for(int e = 0; e < EPL; ++e) { k[u][e] = p0 + e == lo ? loRaw : k[u][e]; k[u][e] = p0 + e == nW ? pivRaw : k[u][e]; }   /* the next pivot's swap: this level's pivot goes where that one stood */
 							}
 							if(in) {
 								uint4 v;
 								if(sizeof(PT) == 2) {
-									v.x = HuPair<PT>::pack(k[u][0]) | ((uint32_t) HuPair<PT>::pack(k[u][1]) << 16); v.y = HuPair<PT>::pack(k[u][2]) | ((uint32_t) HuPair<PT>::pack(k[u][3]) << 16);
-									v.z = HuPair<PT>::pack(k[u][4 % EPL]) | ((uint32_t) HuPair<PT>::pack(k[u][5 % EPL]) << 16); v.w = HuPair<PT>::pack(k[u][6 % EPL]) | ((uint32_t) HuPair<PT>::pack(k[u][7 % EPL]) << 16);
+									v.x = k[u][0] | (k[u][1] << 16); v.y = k[u][2] | (k[u][3] << 16);
+									v.z = k[u][4 % EPL] | (k[u][5 % EPL] << 16); v.w = k[u][6 % EPL] | (k[u][7 % EPL] << 16);
 								}
 								else { v.x = k[u][0]; v.y = k[u][1]; v.z = k[u][2]; v.w = k[u][3]; }
 								*reinterpret_cast<uint4*>(dst + p0) = v;
 							}
 							if(fuse) {
-								rs_classify<EPL>(k[u], nPiv, vb, mLb, mRb);
-								rs_emit<EPL>(mLb, mRb, g, in, lane, bL, bR, cnt16);
+								uint32_t nLb, nRb;
+								rs_classify<PT, EPL>(k[u], nPiv, vb, nLb, nRb);
+								rs_emit<EPL>(nLb, nRb, g, in, lane, bL, bR, cnt16);
 							}
 						}
 					}
@@ -662,23 +714,31 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | ((why ? why : 3) << 26); }
 			continue;
 		}
-		/* ---- the last range into LDS beside the set-aside prefix; one thread finishes with the literal algorithm */
+		/* ---- the last range into LDS beside the set-aside prefix; finished with the literal sequential algorithm */
 		for(int p = lo + tid; p < hi; p += HU_RS_THREADS) { const uint32_t e = E(p); if(!nan) fin[p] = rs_key(e, ((uint32_t) level << 24) | (uint32_t) p); }
 		if(__syncthreads_or(nan ? 1 : 0)) { if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | (3 << 26); } continue; }
 		RS_T(7);
-		if(tid == 0) {
-			bool ok = true;
-			for(int s = 0; s < nStash && ok; ++s) ok = rs_seq_loop(fin, seqStack, stash[s].lo, stash[s].hi, stash[s].depth, K);
-			if(ok) ok = rs_seq_loop(fin, seqStack, lo, hi, depth, K);
-			if(ok) { /* __final_insertion_sort over the blocks that hold the first K places */
-				const int e = min(hi, K + 16);
-				for(int i = 1; i < e; ++i) {
-					const uint64_t v = fin[i]; int j = i;
-					while(j > 0 && (v >> HU_RS_IDBITS) < (fin[j - 1] >> HU_RS_IDBITS)) { fin[j] = fin[j - 1]; --j; }
-					fin[j] = v;
-				}
+		/* the set-aside parts and the last range are disjoint stretches of fin: one THREAD each (lane 0 of a wave: the sequential loops of up to eight
+		 * stretches run side by side on different SIMDs instead of one after the other), each with a stack of its own */
+		if(tid == 0) shI[5] = 1;
+		__syncthreads();
+		if(lane == 0) {
+			for(int s = wave; s <= nStash; s += HU_RS_THREADS / 64) {
+				const bool ok = s < nStash ? rs_seq_loop(fin, seqStack + 72 * wave, stash[s].lo, stash[s].hi, stash[s].depth, K) : rs_seq_loop(fin, seqStack + 72 * wave, lo, hi, depth, K);
+				if(!ok) shI[5] = 0;
 			}
-			shI[5] = ok ? 1 : 0;
+		}
+		__syncthreads();
+		if(shI[5]) { /* __final_insertion_sort over the blocks that hold the first K places: an insertion sort is a STABLE sort, and a stable sort of e elements is a
+		              * rank per element — keys smaller, or equal and earlier — counted by e threads at once */
+			const int e = min(hi, K + 16);
+			uint64_t v = 0; int rank = 0;
+			if(tid < e) {
+				v = fin[tid]; const uint64_t kv = v >> HU_RS_IDBITS;
+				for(int j = 0; j < e; ++j) { const uint64_t kj = fin[j] >> HU_RS_IDBITS; rank += (kj < kv) || (kj == kv && j < tid); }
+			}
+			__syncthreads();
+			if(tid < e) fin[rank] = v;
 		}
 		__syncthreads();
 		RS_T(8);

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 		}
 	}
 	const bool counts = L0 && node < db.nNodes && node != db.root;      /* a place of the sort: every node but the root */
+	bool zero = false;
 #pragma unroll
 	for(int t = 0; t < T; ++t) {
 		const int read = slotRead[tile * T + t];
@@ -165,13 +166,20 @@ __global__ __launch_bounds__(256) void k_seed_pdist2(HuDbDev db, const uint32_t*
 			if(L0) { /* the pivot is wave-uniform (scalar); dist(e) < dist(pivot) <=> d_e N_p < d_p N_e, exact in 32 bits */
 				const uint32_t pp = piv[(size_t) read * 4];
 				const uint32_t a = (v >> 16) * (pp & 0xffffu), bb = (pp >> 16) * (v & 0xffffu);
-				const unsigned long long mL = __ballot(counts && a >= bb), mR = __ballot(counts && bb >= a), mZ = __ballot(counts && (v & 0xffffu) == 0u);
-				if((tid & 63) == 0) {
-					unsigned long long* o = l0m + ((size_t) read * (np / 64) + (size_t)(node >> 6)) * 2;
-					*reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(mL, mR);
-					if(mZ) atomicOr(&piv[(size_t) read * 4 + 3], 1u);
-				}
+				const unsigned long long mL = __ballot(counts && a >= bb), mR = __ballot(counts && bb >= a);
+				if((tid & 63) == 0) *reinterpret_cast<ulonglong2*>(l0m + ((size_t) read * (np / 64) + (size_t)(node >> 6)) * 2) = make_ulonglong2(mL, mR);
+				zero |= v == 0u;      /* d <= N: a compared-site count of zero is an all-zero pair */
 			}
+		}
+	}
+	if(L0 && __ballot(zero && counts)) { /* a node that shares no column with some read of the tile (dist = 0 / 0: std::sort is undefined, the read takes the fallback
+	                                      * rule): rare on complete sequences, so which read it was is looked up only here */
+#pragma unroll
+		for(int t = 0; t < T; ++t) {
+			const int read = slotRead[tile * T + t];
+			if(read < 0) continue;
+			const uint32_t v = ((d[t] << 16) | N[t]) + (ne ? acc[t][tid] : 0u);
+			if(__ballot(counts && v == 0u) && (tid & 63) == 0) atomicOr(&piv[(size_t) read * 4 + 3], 1u);
 		}
 	}
 }

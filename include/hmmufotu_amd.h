@@ -396,6 +396,9 @@ int64_t hu_batch_format_tsv_chimera(hu_batch* b, const char* const* ids, const c
  * two.  The lines of a batch are formatted on the host thread pool of the calling thread. */
 int64_t hu_batch_format_tsv_ptr(hu_batch* b, const char* const* ids, const char* const* descs, const char* const* annos,
 		const hu_chimera_rec* chi, int chimera_info, int which, const char** text);
+/* the bytes each read's line takes in the text of the LAST format call on this batch, newline included (0: the read has no line there): lens [n].
+ * For callers that reassemble lines from several batches in read order (the column-window mode of the CLI) */
+int hu_batch_tsv_line_lengths(hu_batch* b, int64_t* lens);
 /* header with the --chimera-info columns (src/hmmufotu.cpp:592-594 with CHIMERA_TSV_HEADER) */
 const char* hu_tsv_header_chimera(void);
 /* the header line of the assignment file (src/hmmufotu.cpp:592-594) */

@@ -87,3 +87,29 @@ def test_two_windows_give_the_records_of_the_whole_database(paired):
     for k in want.dtype.names:
         assert np.array_equal(got3[k][~un], want[k][~un], equal_nan=True), k
     W.close(); W3.close()
+
+
+@pytest.mark.gpu
+def test_cli_with_column_windows_writes_the_lines_of_the_whole_database(tmp_path):
+    """hmmufotu-amd --col-windows 2: the database files loaded as two column windows (hu_db_load_window), every batch split by window, re-routed,
+    reassembled in read order — the assignment file, the -a alignment file and the --chimera-info columns are those of the run on the whole database"""
+    import os, subprocess, sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import make_tsv_golden as M
+    db, pre, samples = M.make_inputs(str(tmp_path))
+    cli = os.path.join(os.path.dirname(gold), "..", "hmmufotu_amd", "bin", "hmmufotu-amd")
+    fa = samples["A"][0]
+    body = lambda t: [l for l in t.split("\n") if l and not l.startswith("#")]
+    for extra in ([], ["-C", "--chimera-info"], ["--batch", "7", "--inflight", "2"]):
+        a1, a2 = str(tmp_path / "w.aln"), str(tmp_path / "p.aln")
+        plain = subprocess.run([cli, pre, fa, "-s", "1", "-a", a2] + extra, capture_output=True, text=True, timeout=300)
+        assert plain.returncode == 0, plain.stderr
+        win = subprocess.run([cli, pre, fa, "-s", "1", "-a", a1, "--col-windows", "2", "--win-overlap", "600", "-v"] + extra, capture_output=True, text=True, timeout=300)
+        assert win.returncode == 0, win.stderr
+        assert "2 column windows: [0, 650) [50, 700)" in win.stderr and "0 whose region no window holds" in win.stderr, win.stderr
+        assert body(win.stdout) == body(plain.stdout) and len(body(plain.stdout)) == 24          # 23 reads placed + the header
+        assert open(a1).read() == open(a2).read()
+    # windows too narrow for some regions: those reads have no line, the run goes on and says how many
+    nar = subprocess.run([cli, pre, fa, "-s", "1", "--col-windows", "3", "--win-overlap", "100", "-v"], capture_output=True, text=True, timeout=300)
+    assert nar.returncode == 0 and " 0 whose region no window holds" not in nar.stderr and len(body(nar.stdout)) < 24, nar.stderr
