@@ -325,8 +325,8 @@ def main():
         else:
             B.set_reads([r.seq for r in all_reads[i]], all_vps[i])     # inputs resident in HBM before the timed region
         B.sync()
+        B.assign(opts); B.sync()        # every batch runs once here: its buffers exist, and the free memory the next one is checked against is what is really left
         if i == 0:
-            B.assign(opts); B.sync()
             per_batch = free_now - torch.cuda.mem_get_info(local)[0]
         batches.append(B)
     nb = len(batches)

@@ -781,7 +781,7 @@ struct HuKnobs {
 	int trace = 0;               /* one line per stage decision to stderr                                            */
 	int width_split = 1;         /* 0: one launch of the estimate / placement kernels for the whole batch, shaped by its widest region (rounds 1-2) */
 	int sort_seq = 0;            /* filterPlacements / the final sort by the restated std::sort for every read (else only where keys tie) */
-	int refsort_wgs = 768;       /* resident workgroups of k_seed_refsort (three per CU fill its LDS and wave slots; fewer leave room for the other batches' kernels beside it) */
+	int refsort_wgs = HU_RS_WGS_PER_CU * 256;       /* resident workgroups of k_seed_refsort (three per CU fill its LDS and wave slots; fewer leave room for the other batches' kernels beside it) */
 	int ref_nofuse = 0;          /* HU_SEED_ORDER_LIBSTDCXX: k_seed_refsort counts its level 0 itself (pass A over the pair row) instead of starting from the stopper masks the scan leaves */
 	int refsort_host = 0;        /* HU_SEED_ORDER_LIBSTDCXX: the host restatement of libstdc++'s sort for every read instead of the device kernel (k_seed_refsort) */
 	int inject_fault = 0;        /* fault injection for the tests of the exception barrier: 1 = std::bad_alloc inside a worker of the filter stage's
@@ -1426,7 +1426,7 @@ extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int r
 		HIPCHK(hipMemcpy(dP32.p, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
 	}
 	const size_t m0 = (size_t) n, rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0), lds = hu_refsort_lds(d.nNodes);
-	const int G = std::min(rows, getenv("HU_RS_GRID") ? atoi(getenv("HU_RS_GRID")) : 768);
+	const int G = std::min(rows, getenv("HU_RS_GRID") ? atoi(getenv("HU_RS_GRID")) : HU_RS_WGS_PER_CU * 256);
 	if((rc = scr.ensure((size_t) G * hu_refsort_words(m0, pair16 ? 2 : 4))) != HU_OK) return rc;
 	(void) hipGetLastError();
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1557,7 +1557,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 		return seed_order_libstdcxx(b, o);
 	}
 	b->refHostAll = 0;
-	int G = std::min(n, std::max(1, std::min(b->knob.refsort_wgs, 3 * 256)));        /* three workgroups of 512 threads per CU at <= 85 VGPRs (launch bounds); reads are handed out through a counter */
+	int G = std::min(n, std::max(1, std::min(b->knob.refsort_wgs, 8 * 256)));        /* HU_RS_WGS_PER_CU workgroups per CU (launch bounds, hu_kern_refsort.h); reads are handed out through a counter */
 	const size_t perWg = hu_refsort_words(m0, b->pair16 ? 2 : 4);
 	{ const size_t budget = (size_t) 5 << 30; G = (int) std::max<size_t>(1, std::min<size_t>((size_t) G, budget / (perWg * 8))); }
 	if((rc = b->dRefScratch.ensure((size_t) G * perWg)) != HU_OK || (rc = b->dBail.ensure((size_t) n + 2)) != HU_OK) return rc;

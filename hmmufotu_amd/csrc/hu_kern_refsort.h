@@ -33,9 +33,20 @@
 #include "hu_kern_sep.h"
 
 #define HU_RS_SMALL 128
-#define HU_RS_THREADS 512
+/* Geometry (round 4): workgroups of 256 threads, SIX per CU (<= 85 VGPRs by the launch bounds, ~26 KB of LDS each).  What this kernel costs the other batches in
+ * flight is the LDS / register share of its resident workgroups over their life, and a read's life is mostly dependent memory round trips (pivot look-ups, the cut's
+ * searches, level after level) that more threads do not shorten: half the threads per read and twice the reads per CU gave 365 k -> 377 k reads/s at cfg3 against
+ * three workgroups of 512 threads with 45 KB (the streaming levels' rank tables had to leave the LDS for that, hu_refsort_big).  Measured beside it (same run,
+ * `gpurun_out/b_r4l_*`, `b_r4m_*`): 512 x 3 with the tables in global memory 357 k, 512 x 2 with a 40 KB region 354 k, 256 x 5 with 20 KB 373 k, 256 x 8 with 10 KB
+ * (64 VGPRs) 367 k, three vector loads in flight per thread instead of two 366 k (spills). */
+#ifndef HU_RS_THREADS
+#define HU_RS_THREADS 256
+#endif
 #ifndef HU_RS_WAVES_PER_EU
-#define HU_RS_WAVES_PER_EU 6          /* 512 threads = 2 waves per SIMD and workgroup: three workgroups per CU need <= 85 VGPRs */
+#define HU_RS_WAVES_PER_EU 6          /* 256 threads = one wave per SIMD and workgroup: six workgroups per CU need <= 85 VGPRs */
+#endif
+#ifndef HU_RS_WGS_PER_CU
+#define HU_RS_WGS_PER_CU (HU_RS_WAVES_PER_EU * 256 / HU_RS_THREADS)      /* resident workgroups per CU the launch bounds allow (the LDS must hold them too) */
 #endif
 #define HU_RS_FIN (HU_RS_SMALL + 96)        /* LDS array of the sequential finisher: the set-aside prefix (< 64 places) + the last range */
 #define HU_RS_MAXLEV 64                     /* partitions of one read on the device; introsort's own limit is 2 lg n (<= 48 for n < 2^24) */
@@ -82,12 +93,17 @@ __device__ __attribute__((noinline)) uint64_t rs_key(uint32_t pr, uint32_t tag) 
  * rows, and a read whose tables do not fit goes to the host path) */
 static inline size_t hu_refsort_cap(size_t m0) { return (((m0 + 63) & ~(size_t) 63) + m0 / 2 + 128 + 63) & ~(size_t) 63; }
 static inline size_t hu_refsort_tabcap(size_t m0) { const size_t nt = ((m0 + 63) / 64 + 64) & ~(size_t) 63; return 8 * nt + 2048; }
-static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * hu_refsort_cap(m0) * (size_t) pairBytes + 7) / 8 + 3 * hu_refsort_tabcap(m0)) + 1) & ~(size_t) 1; }
+static inline size_t hu_refsort_words(size_t m0, int pairBytes) { return (((2 * hu_refsort_cap(m0) * (size_t) pairBytes + 7) / 8 + 3 * hu_refsort_tabcap(m0) + (hu_refsort_tabcap(m0) + 3) / 4) + 1) & ~(size_t) 1; }      /* + the stopper counts of a streaming level, 2 bytes per subtile */
 /* LDS bytes of k_seed_refsort for a tree of nNodes nodes */
-/* the region that holds the scanned counts of a streaming level (10 bytes per subtile) — or, once a range fits, the range itself and its tables */
+/* Round 4: the rank tables of a STREAMING level (scanned counts, 10 bytes per subtile: 31 KB for a gg_97-scale row) live in the workgroup's global scratch,
+ * where the trace-back wanted its copy anyway; LDS keeps every 64th entry (cPre / cSuf) for the searches.  The region below holds only a range that fits,
+ * with its tables — so a workgroup takes ~30 KB of LDS instead of 45, and its size no longer grows with the tree. */
 #define HU_RS_LTAB 260                 /* subtiles of a range held in LDS, + 1 */
 #define HU_RS_LHEAD (HU_RS_LTAB * (4 + 4 + 8 + 8 + 2) + 24)     /* = 6784: scanned counts, masks, counts of such a range; the keys follow */
-__host__ __device__ static inline size_t hu_refsort_big(size_t m0) { const size_t NT = (m0 + 63) / 64 + 1, b = (10 * (NT + 2) + 15) & ~(size_t) 15; return b > 36864 ? b : 36864; }
+#ifndef HU_RS_BIG
+#define HU_RS_BIG 16384                /* bytes of that region: 4,608 places of 16-bit keys, 2,240 of 32-bit pairs (12 KB measured the same, 24 KB costs the sixth workgroup) */
+#endif
+__host__ __device__ static inline size_t hu_refsort_big(size_t) { return HU_RS_BIG; }
 /* places a range may hold to live in LDS (the kernel's LCAP); a tree with more places than this starts with a streaming level on the pair row */
 template<class PT> __host__ __device__ static inline int hu_refsort_lcap(size_t m0) {
 	const int c = ((((int) hu_refsort_big(m0) - HU_RS_LHEAD) / (int) sizeof(PT)) - 128) & ~63;
@@ -270,10 +286,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	uint32_t* cPre = lsb + 64;                                             /* [NC]: every 64th entry of every level's scanned counts (trace-back) */
 	uint32_t* cSuf = cPre + NC;                                            /* [NC] */
 	unsigned char* big = reinterpret_cast<unsigned char*>(cSuf + NC);      /* hu_refsort_big bytes, 16-byte aligned */
-	/* streaming levels: */
-	uint32_t* const preLg = reinterpret_cast<uint32_t*>(big);              /* [NT + 2] */
-	uint32_t* const sufRg = preLg + (NT + 2);                              /* [NT + 2] */
-	uint16_t* const cnt16g = reinterpret_cast<uint16_t*>(sufRg + (NT + 2));/* [NT + 2]: stoppers per subtile, left | right << 8, before the scan */
+	/* streaming levels keep their tables in the global scratch (gPre / gSuf / gCnt below) */
 	/* a range that fits (at most LCAP places): its tables, its masks and the range itself, partitioned in place */
 	uint32_t* const preLs = reinterpret_cast<uint32_t*>(big); uint32_t* const sufRs = preLs + HU_RS_LTAB;
 	unsigned long long* const mLs = reinterpret_cast<unsigned long long*>(sufRs + HU_RS_LTAB); unsigned long long* const mRs = mLs + HU_RS_LTAB;
@@ -289,12 +302,13 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int rowLast = db.nNodesPad - 1;
 	/* this workgroup's scratch */
-	PT* bufA; PT* bufB; uint32_t* gPre; uint32_t* gSuf; unsigned long long* gML; unsigned long long* gMR;
+	PT* bufA; PT* bufB; uint32_t* gPre; uint32_t* gSuf; unsigned long long* gML; unsigned long long* gMR; uint16_t* gCnt;
 	{
 		unsigned long long* base = scratch + (size_t) blockIdx.x * wgWords;
 		gML = base; gMR = base + tabCap;
 		gPre = reinterpret_cast<uint32_t*>(base + 2 * (size_t) tabCap); gSuf = gPre + tabCap;
-		bufA = reinterpret_cast<PT*>(base + 3 * (size_t) tabCap); bufB = bufA + cap;
+		gCnt = reinterpret_cast<uint16_t*>(base + 3 * (size_t) tabCap);      /* [tabCap]: stoppers per subtile of the streaming level being counted, left | right << 8 */
+		bufA = reinterpret_cast<PT*>(base + 3 * (size_t) tabCap + ((size_t) tabCap + 3) / 4); bufB = bufA + cap;
 	}
 #ifdef HU_RS_PROF
 	unsigned long long t_prof = wall_clock64();
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		bool counted = false;                            /* this level's pivot, swap, masks and counts were made by the pass that wrote it */
 		uint32_t pivP = 0; int wAbs = -1, off = 0;
 		bool inLds = false; int lbase = 0;               /* the range lives in LDS from now on */
-		uint32_t* preL = preLg; uint32_t* sufR = sufRg; uint16_t* cnt16 = cnt16g;
+		uint32_t* preL = gPre; uint32_t* sufR = gSuf; uint16_t* cnt16 = gCnt;      /* streaming levels: set to the level's stretch of the global tables before its scan */
 		auto E = [&](int p) -> uint32_t {                /* any one element, off the streaming passes */
 			if(inLds) return HuPair<PT>::canon(lk[p - lbase + 64]);
 			if(!level0) return HuPair<PT>::canon(src[p]);
@@ -444,6 +458,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				RS_T(2);
 			}
 			counted = false;
+			if(!inLds) { preL = gPre + off; sufR = gSuf + off; }
 			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
 			{
 				const int per = (NTl + HU_RS_THREADS - 1) / HU_RS_THREADS, a0 = tid * per, a1 = min(NTl, a0 + per);
@@ -464,13 +479,16 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				for(int t = a0; t < a1; ++t) { const uint32_t v = cnt16[t] & 0xffu; preL[t] = accL; accL += v; }
 				for(int t = a1 - 1; t >= a0; --t) { accR += cnt16[t] >> 8; sufR[t] = accR; }
 				if(tid == 0) { preL[NTl] = (uint32_t) total; sufR[NTl] = 0; }
+				__threadfence_block();
 				__syncthreads();
-				/* the level's tables for the trace-back: entries 0 .. NTl, padded so that a block of 64 can be counted blindly */
+				/* the level's tables for the trace-back: entries 0 .. NTl, padded so that a block of 64 can be counted blindly (a streaming level's entries
+				 * 0 .. NTl ARE the global tables already) */
 				for(int t = tid; t < R; t += HU_RS_THREADS) {
 					const uint32_t vL = t <= NTl ? preL[t] : 0xffffffffu, vR = t <= NTl ? sufR[t] : 0u;
-					gPre[off + t] = vL; gSuf[off + t] = vR;
+					if(inLds || t > NTl) { gPre[off + t] = vL; gSuf[off + t] = vR; }
 					if((t & 63) == 0) { cPre[(off + t) >> 6] = vL; cSuf[(off + t) >> 6] = vR; }
 				}
+				if(!inLds) { __threadfence_block(); __syncthreads(); }      /* the cut's searches start from the coarse entries */
 			}
 			RS_T(3);
 			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
@@ -480,7 +498,16 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			if(wave == 0) {
 				/* first subtile t0 with preL[t0 + 1] >= sufR[t0 + 1] (positions of earlier subtiles all have g < 0) */
 				int t0;
-				{ int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
+				if(inLds) { int a = 0, b = NTl - 1; while(a < b) { const int md = (a + b) >> 1; if(preL[md + 1] >= sufR[md + 1]) b = md; else a = md + 1; } t0 = a; }
+				else { /* the tables are in global memory: every 64th entry from LDS (one compare per lane), then ONE block of 64 entries (one per lane) */
+					const int nc = R >> 6, cb = off >> 6;
+					int blk;                                                              /* the first true entry lies in (64 blk, 64 blk + 64] */
+					{ int a = 1, b = nc; while(a < b) { const int md = (a + b) >> 1; if(cPre[cb + md] >= cSuf[cb + md]) b = md; else a = md + 1; } blk = a - 1; }   /* first coarse entry x in [1, nc) that holds (nc: none), in LDS; the predicate is monotone */
+					const int i = 64 * blk + 1 + lane;                                    /* table index = subtile + 1 */
+					const unsigned long long fm = __ballot(i <= NTl - 1 && preL[i] >= sufR[i]);
+					t0 = fm ? 64 * blk + (__ffsll((long long) fm) - 1) : min(64 * blk + 64, NTl - 1);
+					if(!fm && 64 * blk + 64 < NTl - 1) t0 = NTl - 1;                      /* (not reached: the coarse entry said the block holds it) */
+				}
 				unsigned long long mL = ML(t0), mR = MR(t0);
 				int c0;
 				{
@@ -502,8 +529,16 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				else m = (int) preL[NTl];
 				int jm = -1;                                         /* j_m: the m-th right stopper from the right */
 				if(m >= 1) {
-					int a = 0, b = NTl - 1;                           /* last subtile t with sufR[t] >= m */
-					while(a < b) { const int md = (a + b + 1) >> 1; if((int) sufR[md] >= m) a = md; else b = md - 1; }
+					int a;                                             /* last subtile t with sufR[t] >= m (sufR does not increase with t; sufR[0] >= m) */
+					if(inLds) { int lo_ = 0, b = NTl - 1; while(lo_ < b) { const int md = (lo_ + b + 1) >> 1; if((int) sufR[md] >= m) lo_ = md; else b = md - 1; } a = lo_; }
+					else {
+						const int nc = R >> 6, cb = off >> 6;
+						int blk;                                                           /* the last coarse entry still >= m: the answer lies in [64 blk, 64 blk + 63] */
+						{ int a_ = 0, b = min(nc - 1, (NTl - 1) >> 6); while(a_ < b) { const int md = (a_ + b + 1) >> 1; if((int) cSuf[cb + md] >= m) a_ = md; else b = md - 1; } blk = a_; }
+						const int i = 64 * blk + lane;
+						const unsigned long long fm = __ballot(i <= NTl - 1 && (int) sufR[i] >= m);
+						a = fm ? 64 * blk + (63 - __clzll((long long) fm)) : 64 * blk;
+					}
 					jm = a * 64 + rs_nth_high(MR(a), m - (int) sufR[a + 1]);
 				}
 				const int cutq = (m >= 1 && (iNext < 0 || iNext > jm)) ? jm : iNext;
@@ -552,12 +587,13 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				constexpr bool L0 = decltype(l0)::value;
 				const unsigned char* __restrict__ bRc = reinterpret_cast<const unsigned char*>(gMR + off);      /* this level's right-stopper bits: classified once, by the pass that wrote or counted it */
 				for(int gb = (jm >> 6) * LPS; gb < gEnd; gb += HU_RS_THREADS * VU) {
-					uint32_t k[VU][EPL], mR[VU];
+					uint32_t k[VU][EPL], mR[VU], sufNext[VU];
 #pragma unroll
 					for(int u = 0; u < VU; ++u) {
 						const int g = min(gb + u * HU_RS_THREADS + tid, gEnd - 1);
 						rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
 						mR[u] = rs_mask_bits<EPL>(bRc, g);
+						sufNext[u] = sufR[min(g / LPS, NTl - 1) + 1];      /* (global: requested with the keys) */
 					}
 #pragma unroll
 					for(int u = 0; u < VU; ++u) {
@@ -568,7 +604,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 						int s = c;                                     /* right stoppers of this lane and the higher lanes of its subtile */
 #pragma unroll
 						for(int o = 1; o < LPS; o <<= 1) { const int v = __shfl_down(s, o); if((lane & (LPS - 1)) + o < LPS) s += v; }
-						const int above = (int) sufR[min(g / LPS, NTl - 1) + 1] + s - c;
+						const int above = (int) sufNext[u] + s - c;
 #pragma unroll
 						for(int e = 0; e < EPL; ++e) if((mRb >> e) & 1u) { const int rk = above + __popc(mRb >> e); if(rk <= m) RS[rk - 1] = (PT) k[u][e]; }
 					}
@@ -611,12 +647,13 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					const unsigned char* __restrict__ bLc = reinterpret_cast<const unsigned char*>(gML + off);      /* this level's left-stopper bits */
 					const uint32_t loRaw = HuPair<PT>::pack(loVal), pivRaw = HuPair<PT>::pack(pivP);
 					for(int gb = 0; gb < gEnd2; gb += HU_RS_THREADS * VU) {
-						uint32_t k[VU][EPL], mLt[VU];
+						uint32_t k[VU][EPL], mLt[VU], preHere[VU];
 #pragma unroll
 						for(int u = 0; u < VU; ++u) {
 							const int g = min(gb + u * HU_RS_THREADS + tid, gEnd2 - 1);
 							rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
 							mLt[u] = rs_mask_bits<EPL>(bLc, g);
+							preHere[u] = preL[min(g / LPS, NTl)];
 						}
 #pragma unroll
 						for(int u = 0; u < VU; ++u) {
@@ -629,7 +666,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 							int s = c;
 #pragma unroll
 							for(int o = 1; o < LPS; o <<= 1) { const int v = __shfl_up(s, o); if((lane & (LPS - 1)) >= o) s += v; }
-							const int r0 = min((int) preL[min(g / LPS, NTl)] + s - c, max(m - 1, 0));
+							const int r0 = min((int) preHere[u] + s - c, max(m - 1, 0));
 							uint32_t rx, ry, rz, rw;
 							if(sizeof(PT) == 2) { const HuRsU4h v = *reinterpret_cast<const HuRsU4h*>(RS + r0); rx = v.x; ry = v.y; rz = v.z; rw = v.w; }
 							else { const HuRsU4w v = *reinterpret_cast<const HuRsU4w*>(RS + r0); rx = v.x; ry = v.y; rz = v.z; rw = v.w; }

@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmmufotu_amd.so")
+LIB_PATH = os.environ.get("HU_LIB") or os.path.join(_HERE, "libhmmufotu_amd.so")      # HU_LIB: another build of the same library (kernel-geometry experiments)
 _LIB = None
 
 HU_MAX_SEEDS = 64
