@@ -479,6 +479,10 @@ def main():
                      "by HBM.  BASELINE.json's '>= 50 % HBM-bandwidth utilisation' is NOT met at configs 2-4 and cannot be by this formulation: after the bit-plane / tiling / "
                      "eigenbasis reformulations every kernel of the path is VALU-issue-bound (roofline_path.path_valu_issue_frac), and the path moves ~a fifth of the HBM peak "
                      "(roofline_path.hbm_measured_frac).  pmc_stale = the PMC summary was taken on other kernel sources than are running now.")
+    if dfrac > 1:      # (a seed-scan kernel dominates, e.g. config 5 in the reference's seed order)
+        roof["frac_above_1"] = ("the dominant kernel here is the node scan, whose ALGORITHMIC bytes (one int8 site per node, column and read, no reuse credited: SURVEY.md section 8d) are "
+                                "not bytes anybody moves: it reads three bit-planes per 32 sites once per tile of sixteen reads.  frac is kept as the contract defines it; "
+                                "hbm_measured_frac and valu_issue_frac say how busy the chip is")
     bytes_per_read = (D.n_nodes - 1) * R + S * 65 * R + C * 64 * R + (2 if args.paired else 1) * (args.read_len + 136 * Wp) + args.cs_len + 128
     step_traffic = sum(k["traffic"] for k in kern) if all(k["traffic"] for k in kern) else None
     # every vector instruction of a step, priced at its measured issue cost, over what 1,024 SIMDs could issue in the step's time: how busy the chip's VALUs are, the roof

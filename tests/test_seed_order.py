@@ -186,6 +186,11 @@ def test_device_sort_prefix_against_the_host_restatement():
     # d > N is not a p-distance: refused
     assert lib.hu_sort_prefix_device(C.c_int(0), np.array([(5 << 16) | 3] * 8, np.uint32).ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int64(8), C.c_int(4), C.c_int(0),
                                      np.zeros(4, np.int32).ctypes.data_as(C.c_void_p), np.zeros(1, np.int32).ctypes.data_as(C.c_void_p)) != 0
+    # the 16-bit form holds d and N in 8 bits each: a pair beyond that is refused, not cut (it would come back as a NaN row from the host path)
+    for bad in ((3 << 16) | 300, (256 << 16) | 300):
+        assert lib.hu_sort_prefix_device(C.c_int(0), np.array([bad] * 8, np.uint32).ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int64(8), C.c_int(4), C.c_int(1),
+                                         np.zeros(4, np.int32).ctypes.data_as(C.c_void_p), np.zeros(1, np.int32).ctypes.data_as(C.c_void_p)) != 0
+        assert b"16-bit form" in lib.hu_last_error()
     # the adversarial input reaches the depth limit: the kernel must hand the row back, not answer wrongly
     from oracle import oracle_py as O
     a = O.antiqsort(60000)
@@ -357,4 +362,29 @@ def test_reference_seed_order_on_a_tree_with_streaming_levels(capfd):
         assert (i0 == i2).all() and (d0 == d2).all() and (n0 == n2).all()
         if maxh is not None:
             assert (db.height[i0] <= maxh).all()
+    D.close()
+
+
+@pytest.mark.gpu
+def test_reference_order_under_a_height_filter_with_more_rows_than_one_grid_dimension():
+    """66,000 reads in one batch under -H: the rows compacted to the nodes that pass the filter are walked by a grid whose y dimension ends at 65,535
+    (k_compact_rows loops over the rows beyond it).  Device sort against the host restatement on every read."""
+    from conftest import get_db, sim_reads
+    from hmmufotu_amd import engine as E
+    if E.device_count() < 1:
+        pytest.fail("no gfx950 device")
+    db = get_db(60, 300, "JC69", dg_k=0, seed=5, n_match=200)
+    reads, vps = sim_reads(db, 330, 60)
+    rd = [r.seq for r in reads] * 200; vp = np.tile(vps, (200, 1, 1))
+    assert len(rd) == 66000
+    D = E.Database.from_synth(db)
+    opts = E.default_opts(seed_order=1, max_nseed=12, max_height=float(np.quantile(db.height, 0.8)))
+    lists = []
+    for host in (0, 1):
+        B = E.Batch(D, len(rd)); B.set_knob("refsort_host", host)
+        B.set_reads(rd, vp); B.align(opts); B.get_seed(opts)
+        cnt, ids, sd, sN = B.seeds(); lists.append((cnt.copy(), ids[:, :12].copy()))
+        B.close()
+    assert (lists[0][0] == lists[1][0]).all() and (lists[0][0] > 0).all() and (lists[0][1] == lists[1][1]).all()
+    assert (lists[0][1][:330] == lists[0][1][65670:]).all()                       # the rows past 65,535 are the rows of the same reads
     D.close()
