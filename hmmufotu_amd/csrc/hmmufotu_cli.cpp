@@ -3,7 +3,7 @@
 // FASTA/FASTQ reading, the seed scans (hu_seed_index_*), strand auto-detection (:500-542), batching, TSV.
 // -C/--chimera* run the segment check of src/hmmufotu.cpp:653-691 in a second batch (hu_chimera_batch).
 // -a writes the aligned reads as FASTA (60 columns, description + ";csStart=..;csEnd=..;", :709-715); --align-only stops
-// after the alignment.  Inputs may be gzip-compressed, outputs are when their name ends in .gz (zlib; no bz2).
+// after the alignment.  Inputs may be gzip- or bzip2-compressed (.bz2 by name), outputs are when their name ends in .gz / .bz2 (zlib; libbz2 bound at run time).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,17 +25,22 @@
 #include "../../include/hmmufotu_amd.h"
 #include "hu_reads_io.h"
 
-/* writer: gzip when the file name ends in .gz */
+/* writer: gzip when the file name ends in .gz, bzip2 when it ends in .bz2 */
 struct LineOut {
-	gzFile z = nullptr; std::ofstream f; bool on = false;
+	gzFile z = nullptr; void* bz = nullptr; std::ofstream f; bool on = false;
 	bool open(const std::string& fn) {
 		on = true;
 		if(fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) { z = gzopen(fn.c_str(), "wb"); return z != nullptr; }
+		if(HuBz2::named(fn)) { if(HuBz2::get().ok()) bz = HuBz2::get().bzopen(fn.c_str(), "wb"); return bz != nullptr; }
 		f.open(fn); return (bool) f;
 	}
-	void write(const char* p, size_t n) { if(z) { while(n) { const unsigned k = (unsigned) std::min<size_t>(n, 1u << 30); gzwrite(z, p, k); p += k; n -= k; } } else f.write(p, (std::streamsize) n); }
+	void write(const char* p, size_t n) {
+		if(z) { while(n) { const unsigned k = (unsigned) std::min<size_t>(n, 1u << 30); gzwrite(z, p, k); p += k; n -= k; } }
+		else if(bz) { while(n) { const int k = (int) std::min<size_t>(n, 1u << 30); HuBz2::get().bzwrite(bz, const_cast<char*>(p), k); p += k; n -= (size_t) k; } }
+		else f.write(p, (std::streamsize) n);
+	}
 	void write(const std::string& s) { write(s.data(), s.size()); }
-	~LineOut() { if(z) gzclose(z); }
+	~LineOut() { if(z) gzclose(z); if(bz) HuBz2::get().bzclose(bz); }
 };
 
 static void usage(const char* p) {
@@ -157,6 +162,7 @@ int main(int argc, char** argv) {
 	auto is_fastq = [&](std::string fn) {
 		if(!fmt.empty()) return fmt == "fastq";
 		if(fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) fn.resize(fn.size() - 3);
+		else if(HuBz2::named(fn)) fn.resize(fn.size() - 4);
 		return (fn.size() > 6 && fn.compare(fn.size() - 6, 6, ".fastq") == 0) || (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".fq") == 0);
 	};
 

@@ -12,15 +12,40 @@
 #include <string>
 #include <vector>
 #include <zlib.h>
+#include <dlfcn.h>
 
 struct Read { std::string id, desc, seq; };
 
-/* line reader over zlib: plain and gzip-compressed inputs alike (the reference reads .gz / .bz2 through boost::iostreams) */
+/* bzip2 (the reference reads and writes .bz2 through boost::iostreams, src/hmmufotu.cpp:22): the image ships libbz2.so.1 without its header, so the four
+ * entry points of its stdio-like interface are declared here as bzlib.h documents them and bound at run time; without the library a .bz2 name fails to open */
+struct HuBz2 {
+	void* lib = nullptr;
+	void* (*bzopen)(const char*, const char*) = nullptr; int (*bzread)(void*, void*, int) = nullptr; int (*bzwrite)(void*, void*, int) = nullptr; void (*bzclose)(void*) = nullptr;
+	static const HuBz2& get() {
+		static const HuBz2 b = [] {
+			HuBz2 x;
+			for(const char* nm : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if((x.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+			if(x.lib) {
+				x.bzopen = (void* (*)(const char*, const char*)) dlsym(x.lib, "BZ2_bzopen"); x.bzread = (int (*)(void*, void*, int)) dlsym(x.lib, "BZ2_bzread");
+				x.bzwrite = (int (*)(void*, void*, int)) dlsym(x.lib, "BZ2_bzwrite"); x.bzclose = (void (*)(void*)) dlsym(x.lib, "BZ2_bzclose");
+			}
+			return x;
+		}();
+		return b;
+	}
+	bool ok() const { return bzopen && bzread && bzwrite && bzclose; }
+	static bool named(const std::string& fn) { return fn.size() > 4 && fn.compare(fn.size() - 4, 4, ".bz2") == 0; }
+};
+
+/* line reader over zlib: plain and gzip-compressed inputs alike, bzip2 by name (the reference reads .gz / .bz2 through boost::iostreams) */
 struct LineIn {
-	gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
-	bool open(const std::string& fn) { f = gzopen(fn.c_str(), "rb"); if(f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr; }
-	~LineIn() { if(f) gzclose(f); }
-	bool fill() { if(eof) return false; const int k = gzread(f, buf.data(), (unsigned) buf.size()); pos = 0; len = k > 0 ? (size_t) k : 0; if(k <= 0) eof = true; return k > 0; }
+	gzFile f = nullptr; void* bz = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+	bool open(const std::string& fn) {
+		if(HuBz2::named(fn)) { if(HuBz2::get().ok()) bz = HuBz2::get().bzopen(fn.c_str(), "rb"); if(bz) buf.resize(1 << 20); return bz != nullptr; }
+		f = gzopen(fn.c_str(), "rb"); if(f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr;
+	}
+	~LineIn() { if(f) gzclose(f); if(bz) HuBz2::get().bzclose(bz); }
+	bool fill() { if(eof) return false; const int k = bz ? HuBz2::get().bzread(bz, buf.data(), (int) buf.size()) : gzread(f, buf.data(), (unsigned) buf.size()); pos = 0; len = k > 0 ? (size_t) k : 0; if(k <= 0) eof = true; return k > 0; }
 	int peek() { if(pos >= len && !fill()) return EOF; return (unsigned char) buf[pos]; }
 	bool getline(std::string& s) {
 		s.clear();

@@ -736,6 +736,14 @@ def test_cli_end_to_end(tmp_path):
     assert [l for l in outst.stdout.split("\n") if l and not l.startswith("#")][1:] == \
         B.format_tsv(["read%d" % i for i in range(len(reads))], ["sample=%d" % (i % 3) for i in range(len(reads))], db.annos).strip("\n").split("\n")
     assert subprocess.run([cli, pre, fa, "--seed-order", "x"], capture_output=True).returncode != 0
+    # bzip2-compressed input and output (.bz2 by name; libbz2 bound at run time)
+    import bz2
+    fqb = str(tmp_path / "r.fastq.bz2"); outb2 = str(tmp_path / "out.tsv.bz2")
+    with open(fq, "rb") as fi, bz2.open(fqb, "wb") as fo:
+        fo.write(fi.read())
+    outbz = subprocess.run([cli, pre, fqb, "-s", "1", "-o", outb2], capture_output=True, text=True, timeout=300)
+    assert outbz.returncode == 0, outbz.stderr
+    assert [l for l in bz2.open(outb2, "rt").read().split("\n") if l and not l.startswith("#")][1:] == want
     # gzip-compressed input and output (the reference reads / writes .gz through boost::iostreams)
     import gzip
     fqz = str(tmp_path / "r.fastq.gz"); outz = str(tmp_path / "out.tsv.gz")

@@ -220,7 +220,7 @@ def reads_driver(tmp_path_factory):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path_factory.mktemp("rd") / "reads_driver")
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                        "-I" + os.path.join(root, "hmmufotu_amd", "csrc"), "-o", exe, os.path.join(root, "tests", "san", "reads_driver.cpp"), "-lz"],
+                        "-I" + os.path.join(root, "hmmufotu_amd", "csrc"), "-o", exe, os.path.join(root, "tests", "san", "reads_driver.cpp"), "-lz", "-ldl"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return exe
