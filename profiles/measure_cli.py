@@ -37,7 +37,10 @@ cli = os.path.join(ROOT, "hmmufotu_amd", "bin", "hmmufotu-amd")
 res = {}
 flights = os.environ.get("HU_CLI_INFLIGHT", "6").split(",")          # several values: the /dev/null run is repeated for each
 runs = [("shm_file", ["-o", os.path.join(tmp, "out.tsv")], flights[0])] + [("devnull" if f == flights[0] else "devnull_inflight%s" % f, ["-o", "/dev/null"], f) for f in flights]
-runs.append(("devnull_reference_seed_order", ["-o", "/dev/null", "--seed-order", "reference"], flights[0]))      # the reference binary's own seed order (k_seed_refsort)
+# round 4: the reference binary's own seed order (k_seed_refsort) is the CLI's default; the (dist, node id) order and the column-window mode beside it
+runs.append(("devnull_stable_seed_order", ["-o", "/dev/null", "--seed-order", "stable"], flights[0]))
+if os.environ.get("HU_CLI_WINDOWS", "2") != "0":      # ONE database held as column windows on this one device (each window keeps its own columns' messages only)
+    runs.append(("devnull_col_windows", ["-o", "/dev/null", "--col-windows", os.environ.get("HU_CLI_WINDOWS", "2"), "--win-overlap", "3100"], flights[0]))
 for name, extra, fl in runs:
     t1 = time.time()
     p = subprocess.run([cli, pre, fa, "-s", "1", "-v", "--inflight", fl] + extra + os.environ.get("HU_CLI_EXTRA", "").split(), capture_output=True, text=True)
