@@ -1549,7 +1549,7 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	const size_t m0 = (size_t) d.nNodes - 1;
 	const size_t rsOff = (m0 + 63) & ~(size_t) 63, cap = hu_refsort_cap(m0);
 	const size_t lds = hu_refsort_lds(d.nNodes);
-	if(lds > 150 * 1024 || m0 >= ((size_t) 1 << 24)) {      /* the level-0 tables do not fit the LDS (above ~600 k nodes), or a place does not fit the 24 bits of the trace-back's tag */
+	if(lds > 150 * 1024 || m0 >= ((size_t) 1 << 24)) {      /* the kernel's LDS index of the level tables (every 64th entry) does not fit (above ~9 M nodes; until round 4 the whole level-0 tables had to: ~600 k), or a place does not fit the 24 bits of the trace-back's tag */
 		static std::atomic<bool> said{false};
 		if(!said.exchange(true)) fprintf(stderr, "[hu] reference seed order: a tree of %d nodes is beyond the device sort (k_seed_refsort: %zu KB of LDS tables, limit 150): every read takes the "
 				"host restatement of std::sort — tens of times slower (DESIGN.md section 4); --seed-order stable runs on the device at any size\n", d.nNodes, lds / 1024);

@@ -123,7 +123,7 @@ typedef struct {
 	                           * k_seed_refsort: data-parallel Hoare partitions restricted to the ranges that reach the first max_nseed places).
 	                           * The host restatement (hu_sort_prefix_libstdcxx) finishes only the reads the kernel lists: a row that reaches
 	                           * introsort's heap-sort branch, level tables that overflow, and every read of a tree whose sort tables exceed
-	                           * 150 KB of LDS (above ~600 k nodes; reported once on stderr and in hu_batch_refsort_stats).  A read with a NaN
+	                           * 150 KB of LDS (its index of every 64th table entry: above ~9 M nodes; reported once on stderr and in hu_batch_refsort_stats).  A read with a NaN
 	                           * distance (a node sharing no column with it: std::sort is undefined) takes (dist, node id) with NaN last.
 	                           * HU_SEED_ORDER_STABLE (0): ascending (dist, node id) — independent of any library's tie permutation, selected by
 	                           * the distance-only scan + top-k; ~25 % faster, differs from a g++-built reference wherever nodes tie at the
@@ -436,7 +436,7 @@ int hu_batch_profile(hu_batch* b, int enable);
 int hu_batch_wall(hu_batch* b, double* ms4);
 /* the last hu_seed_batch under HU_SEED_ORDER_LIBSTDCXX: reads the device sort (k_seed_refsort) handed to the host restatement (heap-sort branch, table
  * overflow; the NaN-distance reads of a database with partial sequences are counted too), and whether the WHOLE batch took the host path (a tree beyond
- * the kernel's LDS tables, ~600 k nodes: said once on stderr) — so that a rate quoted for the mode is never silently a host-path rate */
+ * the kernel's LDS index, ~9 M nodes: said once on stderr) — so that a rate quoted for the mode is never silently a host-path rate */
 int hu_batch_refsort_stats(hu_batch* b, int32_t* left_to_host, int32_t* whole_batch_on_host);
 
 #ifdef __cplusplus
