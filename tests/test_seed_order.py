@@ -138,7 +138,7 @@ def test_device_sort_prefix_against_the_host_restatement():
         assert rc == 0, lib.hu_last_error()
         return out, cnt
     handed_back = 0
-    for n in (1, 2, 17, 40, 300, 512, 513, 600, 1025, 2000, 5000, 33333, 198642):
+    for n in (1, 2, 17, 40, 300, 512, 513, 600, 1025, 2000, 2240, 2241, 4608, 4609, 5000, 33333, 198642):      # 2,240 / 4,608: the places of a range held in LDS (32- / 16-bit pairs)
         rows = 6 if n > 50000 else 24
         for shape in ("row", "few", "equal", "asc", "desc", "pipe", "wideN"):
             p16 = shape != "wideN"
