@@ -1445,10 +1445,11 @@ extern "C" int hu_sort_prefix_device_at(int device, const uint32_t* pairs, int r
 	HIPCHK(hipDeviceSynchronize());
 	if(getenv("HU_RS_TIMING")) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d rows x %lld elements, grid %d: %.3f ms\n", rows, (long long) n, G, ms);
 #ifdef HU_RS_PROF
-		unsigned long long pr[16]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
+		unsigned long long pr[176]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
 		static const char* nm[10] = {"idle", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher", "trace-back"};
-		for(int i = 0; i < 10; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
-		unsigned long long z[16] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
+		for(int i = 0; i < 10; ++i) { fprintf(stderr, "[hu]   %-12s %12llu ticks |", nm[i], pr[i]); for(int l = 0; l < 10; ++l) fprintf(stderr, " %9llu", pr[16 + 10 * l + i] / 1000); fprintf(stderr, "\n"); }
+		fprintf(stderr, "[hu]   level 0 sums: cut %llu, j_m %llu, m %llu; range sizes of levels 0 / 1 / 2: %llu %llu %llu\n", pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
+		unsigned long long z[176] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
 #endif
 	}
 	std::vector<int32_t> cnt(rows), ids((size_t) rows * HU_MAX_SEEDS), hb((size_t) rows + 2);
@@ -1587,10 +1588,11 @@ static int seed_order_libstdcxx_device(hu_batch* b, const hu_opts* o) {
 	b->nRefBail = hb[0];
 	if(e1) { float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[hu] k_seed_refsort: %d reads, grid %d, %s pairs%s: %.3f ms, %d reads left to the host\n", n, G, b->pair16 ? "16-bit" : "32-bit", fused ? ", level 0 from the scan" : "", ms, hb[0]);
 #ifdef HU_RS_PROF
-		unsigned long long pr[16]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
+		unsigned long long pr[176]; (void) hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_rs_prof), sizeof pr);
 		static const char* nm[10] = {"idle", "pivot", "passA", "scan", "cut", "B1", "B2/tiny", "fin-load", "finisher", "trace-back"};
-		for(int i = 0; i < 10; ++i) fprintf(stderr, "[hu]   %-12s %12llu ticks\n", nm[i], pr[i]);
-		unsigned long long z[16] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
+		for(int i = 0; i < 10; ++i) { fprintf(stderr, "[hu]   %-12s %12llu ticks |", nm[i], pr[i]); for(int l = 0; l < 10; ++l) fprintf(stderr, " %9llu", pr[16 + 10 * l + i] / 1000); fprintf(stderr, "\n"); }
+		fprintf(stderr, "[hu]   level 0 sums: cut %llu, j_m %llu, m %llu; range sizes of levels 0 / 1 / 2: %llu %llu %llu\n", pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
+		unsigned long long z[176] = {0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), z, sizeof z);
 #endif
 	}
 	if(hb[0] > 0) {

@@ -54,8 +54,8 @@
 struct HuRsRange { int lo, hi, depth; };
 
 #ifdef HU_RS_PROF     /* development only: cycles of thread 0 per phase, summed over the reads of every workgroup */
-__device__ unsigned long long g_rs_prof[16];
-#define RS_T(i) do { if(tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_rs_prof[i], now_ - t_prof); t_prof = now_; } } while(0)
+__device__ unsigned long long g_rs_prof[16 + 160];   /* [16 ..): the same per level (0 .. 8, 9 = after the levels) */
+#define RS_T(i) do { if(tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_rs_prof[i], now_ - t_prof); atomicAdd(&g_rs_prof[16 + 10 * rs_lv + (i)], now_ - t_prof); t_prof = now_; } } while(0)
 #else
 #define RS_T(i) do { } while(0)
 #endif
@@ -169,6 +169,12 @@ template<class PT> struct HuRsGeom { static constexpr int EPL = 16 / (int) sizeo
 #ifndef HU_RS_VU
 #define HU_RS_VU 2                /* vector loads in flight per thread */
 #endif
+#ifndef HU_RS_VU_B1
+#define HU_RS_VU_B1 HU_RS_VU
+#endif
+#ifndef HU_RS_VU_B2
+#define HU_RS_VU_B2 HU_RS_VU
+#endif
 struct __attribute__((packed, aligned(2))) HuRsU4h { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) HuRsU4w { uint32_t x, y, z, w; };
 
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		unsigned long long* __restrict__ scratch, size_t wgWords, size_t cap, int rsOff, int tabCap,
 		int32_t* __restrict__ seedCnt, int32_t* __restrict__ seedId, uint32_t* __restrict__ seedDN, uint32_t* __restrict__ parDN,
 		int32_t* __restrict__ bail, const uint32_t* __restrict__ l0piv = nullptr, const unsigned long long* __restrict__ l0m = nullptr) {
-	constexpr int EPL = HuRsGeom<PT>::EPL, LPS = HuRsGeom<PT>::LPS, VU = HU_RS_VU;
+	constexpr int EPL = HuRsGeom<PT>::EPL, LPS = HuRsGeom<PT>::LPS, VU = HU_RS_VU, VU1 = HU_RS_VU_B1, VU2 = HU_RS_VU_B2;
 	extern __shared__ unsigned char rs_smem[];
 	const int m0 = db.nNodes - 1;
 	const int NT = ((m0 + 63) >> 6) + 1;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		bufA = reinterpret_cast<PT*>(base + 3 * (size_t) tabCap + ((size_t) tabCap + 3) / 4); bufB = bufA + cap;
 	}
 #ifdef HU_RS_PROF
-	unsigned long long t_prof = wall_clock64();
+	unsigned long long t_prof = wall_clock64(); int rs_lv = 9;
 #endif
 	/* reads are handed out through a counter (bail[1]): their cost differs with the pivots they meet, and the last ones do not wait for the
 	 * slowest workgroup of a fixed schedule */
@@ -334,7 +340,14 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 		bool counted = false;                            /* this level's pivot, swap, masks and counts were made by the pass that wrote it */
 		uint32_t pivP = 0; int wAbs = -1, off = 0;
 		bool inLds = false; int lbase = 0;               /* the range lives in LDS from now on */
-		uint32_t* preL = gPre; uint32_t* sufR = gSuf; uint16_t* cnt16 = gCnt;      /* streaming levels: set to the level's stretch of the global tables before its scan */
+		uint32_t* preL = gPre; uint32_t* sufR = gSuf;      /* streaming levels: set to the level's stretch of the global tables before its scan */
+#ifndef HU_RS_CNT_GLOBAL
+		uint16_t* cnt16 = (size_t) NT * 2 <= (size_t) HU_RS_BIG ? reinterpret_cast<uint16_t*>(big) : gCnt;   /* the stopper counts of a streaming level live in the (still unused) LDS region of the
+		                                                                                                        * later in-LDS ranges when they fit: the scan below reads each of them three times, one
+		                                                                                                        * dependent round trip each from global memory (40 us of a gg_97-scale read's level 0) */
+#else
+		uint16_t* cnt16 = gCnt;
+#endif
 		auto E = [&](int p) -> uint32_t {                /* any one element, off the streaming passes */
 			if(inLds) return HuPair<PT>::canon(lk[p - lbase + 64]);
 			if(!level0) return HuPair<PT>::canon(src[p]);
@@ -344,6 +357,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			return p == pB ? vB : pr;
 		};
 		for(;;) {
+#ifdef HU_RS_PROF
+			rs_lv = level < 9 ? level : 8;
+#endif
 			if(!inLds && hi - lo <= LCAP) {
 				/* ---- the range fits: into LDS, where the remaining partitions run in place without a round trip to memory */
 				lbase = (lo + 1) & ~63;
@@ -460,7 +476,43 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			counted = false;
 			if(!inLds) { preL = gPre + off; sufR = gSuf + off; }
 			/* ---- scans: preL[t] = left stoppers before subtile t (exclusive), sufR[t] = right stoppers in subtiles >= t */
-			{
+			if(!inLds) {
+				/* a streaming level: every wave takes a quarter of the subtiles in rows of 64 — counts in, tables out in whole lines (the chunk-per-thread form below
+				 * wrote them 4 bytes at a stride of 52 and read them back for the coarse entries: 40 us of a gg_97-scale read's level 0) */
+				constexpr int NW = HU_RS_THREADS / 64;
+				const int Q = (((NTl + NW - 1) / NW) + 63) & ~63, q0 = wave * Q, q1 = min(NTl, q0 + Q);
+				unsigned long long w = 0;                         /* left | right << 32 */
+				for(int t = q0 + lane; t < q1; t += 64) { const uint32_t c = cnt16[t]; w += (unsigned long long)(c & 0xffu) | ((unsigned long long)(c >> 8) << 32); }
+#pragma unroll
+				for(int o = 32; o >= 1; o >>= 1) w += __shfl_xor(w, o);
+				if(lane == 0) wtot[wave] = w;
+				__syncthreads();
+				unsigned long long base = 0, total = 0;
+#pragma unroll
+				for(int x = 0; x < NW; ++x) { const unsigned long long t = wtot[x]; if(x < wave) base += t; total += t; }
+				const uint32_t totR = (uint32_t)(total >> 32);
+				for(int tb = q0; tb < q1; tb += 64) {
+					const int t = tb + lane; const bool in = t < q1;
+					const uint32_t c = in ? cnt16[t] : 0u;
+					const unsigned long long mine = (unsigned long long)(c & 0xffu) | ((unsigned long long)(c >> 8) << 32);
+					unsigned long long inc = mine;
+#pragma unroll
+					for(int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(inc, o); if(lane >= o) inc += v; }
+					const unsigned long long ex = base + inc - mine;
+					const uint32_t vL = (uint32_t) ex, vR = totR - (uint32_t)(ex >> 32);
+					if(in) { preL[t] = vL; sufR[t] = vR; if(lane == 0) { cPre[(off + t) >> 6] = vL; cSuf[(off + t) >> 6] = vR; } }
+					base += __shfl(inc, 63);
+				}
+				/* entries NTl (the totals) .. R - 1, padded so that a block of 64 can be counted blindly */
+				for(int t = NTl + tid; t < R; t += HU_RS_THREADS) {
+					const uint32_t vL = t == NTl ? (uint32_t) total : 0xffffffffu, vR = 0u;
+					preL[t] = vL; sufR[t] = vR;
+					if((t & 63) == 0) { cPre[(off + t) >> 6] = vL; cSuf[(off + t) >> 6] = vR; }
+				}
+				__threadfence_block();
+				__syncthreads();      /* the cut's searches start from the coarse entries */
+			}
+			else {
 				const int per = (NTl + HU_RS_THREADS - 1) / HU_RS_THREADS, a0 = tid * per, a1 = min(NTl, a0 + per);
 				uint32_t sL = 0, sR = 0;
 				for(int t = a0; t < a1; ++t) { const uint32_t c = cnt16[t]; sL += c & 0xffu; sR += c >> 8; }
@@ -481,14 +533,12 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 				if(tid == 0) { preL[NTl] = (uint32_t) total; sufR[NTl] = 0; }
 				__threadfence_block();
 				__syncthreads();
-				/* the level's tables for the trace-back: entries 0 .. NTl, padded so that a block of 64 can be counted blindly (a streaming level's entries
-				 * 0 .. NTl ARE the global tables already) */
+				/* the level's tables for the trace-back: entries 0 .. NTl, padded so that a block of 64 can be counted blindly */
 				for(int t = tid; t < R; t += HU_RS_THREADS) {
 					const uint32_t vL = t <= NTl ? preL[t] : 0xffffffffu, vR = t <= NTl ? sufR[t] : 0u;
-					if(inLds || t > NTl) { gPre[off + t] = vL; gSuf[off + t] = vR; }
+					gPre[off + t] = vL; gSuf[off + t] = vR;
 					if((t & 63) == 0) { cPre[(off + t) >> 6] = vL; cSuf[(off + t) >> 6] = vR; }
 				}
-				if(!inLds) { __threadfence_block(); __syncthreads(); }      /* the cut's searches start from the coarse entries */
 			}
 			RS_T(3);
 			/* ---- cut and m (wave 0).  g(q) = L(q) - R(q + 1): left stoppers before q minus right stoppers after q, non-decreasing in q;
@@ -547,6 +597,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			__syncthreads();
 			RS_T(4);
 			const int cutq = shI[2], m = shI[3], jm = shI[4];
+#ifdef HU_RS_PROF
+			if(tid == 0 && level < 3) { atomicAdd(&g_rs_prof[10], (unsigned long long)(level == 0 ? cutq : 0)); atomicAdd(&g_rs_prof[11], (unsigned long long)(level == 0 ? max(jm, 0) : 0)); atomicAdd(&g_rs_prof[12], (unsigned long long)(level == 0 ? m : 0)); atomicAdd(&g_rs_prof[13 + level], (unsigned long long)(hi - lo)); }
+#endif
 			if(cutq < 0) { failed = true; why = 4; break; }         /* no stopper where the sentinels guarantee one: not reached on consistent data */
 			const int cutAbs = qBase + cutq;
 			PT* RS = dst + rsOff;                                   /* right stoppers by rank, beyond the positions */
@@ -586,17 +639,17 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			auto passB1 = [&](auto l0) {
 				constexpr bool L0 = decltype(l0)::value;
 				const unsigned char* __restrict__ bRc = reinterpret_cast<const unsigned char*>(gMR + off);      /* this level's right-stopper bits: classified once, by the pass that wrote or counted it */
-				for(int gb = (jm >> 6) * LPS; gb < gEnd; gb += HU_RS_THREADS * VU) {
-					uint32_t k[VU][EPL], mR[VU], sufNext[VU];
+				for(int gb = (jm >> 6) * LPS; gb < gEnd; gb += HU_RS_THREADS * VU1) {
+					uint32_t k[VU1][EPL], mR[VU1], sufNext[VU1];
 #pragma unroll
-					for(int u = 0; u < VU; ++u) {
+					for(int u = 0; u < VU1; ++u) {
 						const int g = min(gb + u * HU_RS_THREADS + tid, gEnd - 1);
 						rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
 						mR[u] = rs_mask_bits<EPL>(bRc, g);
 						sufNext[u] = sufR[min(g / LPS, NTl - 1) + 1];      /* (global: requested with the keys) */
 					}
 #pragma unroll
-					for(int u = 0; u < VU; ++u) {
+					for(int u = 0; u < VU1; ++u) {
 						const int g = gb + u * HU_RS_THREADS + tid; const bool in = g < gEnd;
 						if(L0) { bool dummy = false; rs_fix_l0<PT, EPL>(k[u], qBase + g * EPL, pA, HuPair<PT>::pack(vA), pB, HuPair<PT>::pack(vB), 0u, dummy); }
 						const uint32_t mRb = in ? mR[u] : 0u;
@@ -646,17 +699,17 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 					unsigned char* bL = reinterpret_cast<unsigned char*>(gML + nOff); unsigned char* bR = reinterpret_cast<unsigned char*>(gMR + nOff);
 					const unsigned char* __restrict__ bLc = reinterpret_cast<const unsigned char*>(gML + off);      /* this level's left-stopper bits */
 					const uint32_t loRaw = HuPair<PT>::pack(loVal), pivRaw = HuPair<PT>::pack(pivP);
-					for(int gb = 0; gb < gEnd2; gb += HU_RS_THREADS * VU) {
-						uint32_t k[VU][EPL], mLt[VU], preHere[VU];
+					for(int gb = 0; gb < gEnd2; gb += HU_RS_THREADS * VU2) {
+						uint32_t k[VU2][EPL], mLt[VU2], preHere[VU2];
 #pragma unroll
-						for(int u = 0; u < VU; ++u) {
+						for(int u = 0; u < VU2; ++u) {
 							const int g = min(gb + u * HU_RS_THREADS + tid, gEnd2 - 1);
 							rs_load<L0, PT>(src, row, db.root, rowLast, qBase + g * EPL, k[u]);
 							mLt[u] = rs_mask_bits<EPL>(bLc, g);
 							preHere[u] = preL[min(g / LPS, NTl)];
 						}
 #pragma unroll
-						for(int u = 0; u < VU; ++u) {
+						for(int u = 0; u < VU2; ++u) {
 							const int g = gb + u * HU_RS_THREADS + tid, p0 = qBase + g * EPL; const bool in = g < gEnd2;
 							const uint32_t vb = in ? rs_valid<EPL>(g * EPL, o0, cutq) : 0u;
 							if(L0) { bool dummy = false; rs_fix_l0<PT, EPL>(k[u], p0, pA, HuPair<PT>::pack(vA), pB, HuPair<PT>::pack(vB), 0u, dummy); }
@@ -747,6 +800,9 @@ __global__ __launch_bounds__(HU_RS_THREADS, HU_RS_WAVES_PER_EU) void k_seed_refs
 			pA = pB = -1;
 			++level;
 		}
+#ifdef HU_RS_PROF
+		rs_lv = 9;
+#endif
 		if(__syncthreads_or((failed || nan) ? 1 : 0)) { /* the host path finishes this read */
 			if(tid == 0) { seedCnt[read] = 0; const int at = atomicAdd(bail, 1); bail[2 + at] = read | ((why ? why : 3) << 26); }
 			continue;
