@@ -320,6 +320,8 @@ def main():
             log("%d batches in flight instead of %d: %.1f GB free, %.1f GB per batch" % (i, nb, free_now / 1e9, per_batch / 1e9))
             break
         B = E.Batch(D, args.batch)
+        for kv in filter(None, os.environ.get("HU_BENCH_KNOBS", "").split(",")):      # development: engine knobs for an A/B run, "name=value,..." (noted in the line)
+            B.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
         if args.paired:
             B.set_reads([r.seq for r in all_reads[i]], all_vps[i], [r.seq for r in all_mates[i]], all_mvps[i])
         else:
@@ -513,6 +515,7 @@ def main():
                            hbm_in_use_gb=(total_b - free_b) / 1e9, hbm_total_gb=total_b / 1e9),
                timed_region="the engine's whole per-read task on reads and seed paths already resident (hu_assign_batch + result fetch per step); the host seed "
                             "lookup, FASTA parsing, the read upload (< 1 KB per read) and the TSV are outside it: `end_to_end` below measures them in this same process",
+               **({"engine_knobs": os.environ["HU_BENCH_KNOBS"]} if os.environ.get("HU_BENCH_KNOBS") else {}),
                host_cores_busy_per_rank=round(host_cores_busy, 1), host_cpus=os.cpu_count(), host_cpu_quota=cpu_quota(),
                rccl_ranks=rccl_ranks, rccl_error=rccl_error, backend=backend if (world > 1 or rccl_ranks) else None, gathered_records=(int(len(gathered)) if gathered is not None else None),
                roofline=roof, roofline_kernels=kern, roofline_path=path,
