@@ -36,7 +36,7 @@ del db
 cli = os.path.join(ROOT, "hmmufotu_amd", "bin", "hmmufotu-amd")
 res = {}
 flights = os.environ.get("HU_CLI_INFLIGHT", "6").split(",")          # several values: the /dev/null run is repeated for each
-runs = [("shm_file", ["-o", os.path.join(tmp, "out.tsv")], flights[0])] + [("devnull" if f == flights[0] else "devnull_inflight%s" % f, ["-o", "/dev/null"], f) for f in flights]
+runs = ([] if os.environ.get("HU_CLI_SKIP_FILE") else [("shm_file", ["-o", os.path.join(tmp, "out.tsv")], flights[0])]) + [("devnull" if f == flights[0] else "devnull_inflight%s" % f, ["-o", "/dev/null"], f) for f in flights]
 # round 4: the reference binary's own seed order (k_seed_refsort) is the CLI's default; the (dist, node id) order and the column-window mode beside it
 runs.append(("devnull_stable_seed_order", ["-o", "/dev/null", "--seed-order", "stable"], flights[0]))
 if os.environ.get("HU_CLI_WINDOWS", "2") != "0":      # ONE database held as column windows on this one device (each window keeps its own columns' messages only)
